@@ -1,0 +1,229 @@
+"""oracle/gen_golden.py — TEST INFRASTRUCTURE ONLY; runs in the BUILD CONTAINER only.
+
+Generates the golden vectors under tests/golden/ by importing the reference's own Python classes from
+/root/reference (through oracle/ref_shims.py), loading the deterministic synthetic weights of
+oracle/weights.py into them, and recording inputs + outputs.  Only data is written: no reference source
+or bytecode enters the repo (sys.dont_write_bytecode is set by ref_shims).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [dac] [flow] [llm] [sampler]
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_shims as R  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import weights as W  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED = 7
+torch.set_grad_enabled(False)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_dac():
+    m = R.import_dac()
+    for lat in (80, 128):
+        torch.manual_seed(0)
+        d = m.DACVAE(encoder_dim=64, encoder_rates=[2, 3, 4, 4, 5], latent_dim=lat, decoder_dim=1536,
+                     decoder_rates=[5, 4, 4, 3, 2], sample_rate=24000, d_in=1, d_out=1, weight_init="xavier",
+                     activation="snake", gain=1.0).eval()
+        sd = {k: v for k, v in d.state_dict().items() if k.startswith("decoder.") or k.startswith("de_conv_pre.")}
+        W.save_manifest(sd, os.path.join(GOLD, f"manifest_dac{lat}.json"))
+        syn = W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED)
+        missing, unexpected = d.load_state_dict(syn, strict=False)
+        assert not unexpected
+        out = {}
+        for T in (8, 50):
+            z = torch.randn(1, lat, T, generator=torch.Generator().manual_seed(100 + T))
+            y = d.decode(z)
+            out[f"z_T{T}"] = np_(z)
+            out[f"wav_T{T}"] = np_(y)
+            print(f"dac{lat} T={T}: wav {tuple(y.shape)} absmax {y.abs().max():.4f} std {y.std():.4f}")
+        # per-stage activations of the T=8 case (shape + a strided sample, for debugging kernels)
+        z = torch.from_numpy(out["z_T8"])
+        h = d.de_conv_pre(z)
+        out["pre_T8"] = np_(h)
+        for i, layer in enumerate(d.decoder.model):
+            h = layer(h)
+            if i < 6:
+                print(f"   stage{i}: {tuple(h.shape)} std {h.std():.3f}")
+            if i < 3:
+                out[f"stage{i}_T8"] = np_(h)
+        np.savez_compressed(os.path.join(GOLD, f"dac{lat}.npz"), **out)
+
+
+def build_flow():
+    R.import_cosyvoice()
+    from cosyvoice.flow.flow import CausalMaskedDiffWithXvec
+    from cosyvoice.flow.flow_matching import CausalConditionalCFM
+    from cosyvoice.flow.decoder import CausalConditionalDecoder
+    from cosyvoice.transformer.upsample_encoder import UpsampleConformerEncoder
+    from omegaconf import DictConfig
+    torch.manual_seed(0)
+    # speech/config.yaml:60-116
+    enc = UpsampleConformerEncoder(output_size=512, attention_heads=8, linear_units=2048, num_blocks=6,
+                                   dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.1,
+                                   normalize_before=True, input_layer="linear", pos_enc_layer_type="rel_pos_espnet",
+                                   selfattention_layer_type="rel_selfattn", input_size=512, use_cnn_module=False,
+                                   macaron_style=False, static_chunk_size=25)
+    est = CausalConditionalDecoder(in_channels=320, out_channels=80, channels=[256], dropout=0.0,
+                                   attention_head_dim=64, n_blocks=4, num_mid_blocks=12, num_heads=8, act_fn="gelu",
+                                   static_chunk_size=50, num_decoding_left_chunks=-1)
+    cfm = CausalConditionalCFM(in_channels=240, n_spks=1, spk_emb_dim=80, cfm_params=DictConfig(dict(
+        sigma_min=1e-6, solver="euler", t_scheduler="cosine", training_cfg_rate=0.2, inference_cfg_rate=0.7,
+        reg_loss_type="l1", use_immiscible=True, immiscible_k=8, use_contrastive_fm=True,
+        contrastive_lambda=0.05)), estimator=est)
+    flow = CausalMaskedDiffWithXvec(input_size=512, output_size=80, spk_embed_dim=192, output_type="mel",
+                                    vocab_size=6561, input_frame_rate=25, only_mask_loss=True, token_latent_ratio=2,
+                                    pre_lookahead_len=3, use_speaker_encoder=False, encoder=enc, decoder=cfm).eval()
+    return flow
+
+
+def gen_flow():
+    flow = build_flow()
+    sd = flow.state_dict()
+    W.save_manifest(sd, os.path.join(GOLD, "manifest_flow.json"))
+    syn = W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED)
+    flow.load_state_dict(syn, strict=True)
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # (ii) estimator: one call, T=64, CFG pair, both streaming flags, padded second row
+    T = 64
+    x = torch.randn(2, 80, T, generator=g)
+    mu = torch.randn(2, 80, T, generator=g)
+    cond = torch.randn(2, 80, T, generator=g) * 0.5
+    spks = torch.randn(2, 80, generator=g)
+    t = torch.tensor([0.3, 0.3])
+    mask = torch.ones(2, 1, T)
+    est = flow.decoder.estimator
+    for name, streaming, mk in (("est_full", False, mask), ("est_stream", True, mask)):
+        y = est(x, mk, mu, t, spks, cond, streaming=streaming)
+        out[name] = np_(y)
+        print(name, tuple(y.shape), f"std {y.std():.3f} absmax {y.abs().max():.3f}")
+    mask2 = mask.clone()
+    mask2[1, :, 40:] = 0
+    y = est(x, mask2, mu, t, spks, cond, streaming=False)
+    out["est_padmask"] = np_(y)
+    out.update(est_x=np_(x), est_mu=np_(mu), est_cond=np_(cond), est_spks=np_(spks), est_t=np_(t), est_mask2=np_(mask2))
+    # (iii) encoder
+    xs = torch.randn(1, 25, 512, generator=g)
+    ctx = torch.randn(1, 3, 512, generator=g)
+    for name, c, streaming in (("enc_full", None, False), ("enc_ctx_stream", ctx, True)):
+        kw = {} if c is None else {"context": c}
+        h, m = flow.encoder(xs, torch.tensor([25]), streaming=streaming, **kw)
+        out[name] = np_(h)
+        print(name, tuple(h.shape), f"std {h.std():.3f}")
+    out.update(enc_xs=np_(xs), enc_ctx=np_(ctx))
+    # (iv) full flow.inference
+    tok = torch.randint(0, 6561, (1, 25), generator=g)
+    ptok = torch.randint(0, 6561, (1, 7), generator=g)
+    pfeat = torch.randn(1, 14, 80, generator=g)
+    emb = torch.randn(1, 192, generator=g)
+    none_tok, none_feat = torch.zeros(1, 0, dtype=torch.long), torch.zeros(1, 0, 80)
+    cases = {
+        "flow_noprompt": (tok, none_tok, none_feat, False, True),
+        "flow_prompt": (tok, ptok, pfeat, False, True),
+        "flow_stream_nofinal": (tok, ptok, pfeat, True, False),
+        "flow_stream_final": (tok, ptok, pfeat, True, True),
+    }
+    for name, (tk, pt, pf, streaming, finalize) in cases.items():
+        y, _ = flow.inference(token=tk, token_len=torch.tensor([tk.shape[1]]), prompt_token=pt,
+                              prompt_token_len=torch.tensor([pt.shape[1]]), prompt_feat=pf,
+                              prompt_feat_len=torch.tensor([pf.shape[1]]), embedding=emb, streaming=streaming,
+                              finalize=finalize)
+        out[name] = np_(y)
+        print(name, tuple(y.shape), f"std {y.std():.3f} absmax {y.abs().max():.3f}")
+    out.update(flow_tok=np_(tok), flow_ptok=np_(ptok), flow_pfeat=np_(pfeat), flow_emb=np_(emb))
+    out["rand_noise_head"] = np_(flow.decoder.rand_noise[:, :, :64])
+    np.savez_compressed(os.path.join(GOLD, "flow.npz"), **out)
+
+
+def gen_llm():
+    R.import_cosyvoice()
+    from functools import partial
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM
+    from cosyvoice.utils.common import ras_sampling
+    # CosyVoice-BlankEN == Qwen2.5-0.5B shape; random init written to a temp dir
+    cfg = Qwen2Config(vocab_size=151936, hidden_size=896, intermediate_size=4864, num_hidden_layers=24,
+                      num_attention_heads=14, num_key_value_heads=2, rope_theta=1e6, rms_norm_eps=1e-6,
+                      tie_word_embeddings=True, max_position_embeddings=32768)
+    d = tempfile.mkdtemp()
+    t0 = time.time()
+    Qwen2ForCausalLM(cfg).save_pretrained(d)
+    enc = Qwen2Encoder(d)
+    lm = Qwen2LM(896, 896, 6561, enc, partial(ras_sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1),
+                 True, 0, [5, 15], use_speaker_encoder=False).eval()
+    sd = {k: v for k, v in lm.state_dict().items() if k != "llm.model.lm_head.weight"}   # tied to embed_tokens
+    W.save_manifest(sd, os.path.join(GOLD, "manifest_llm.json"))
+    syn = W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED)
+    syn["llm.model.lm_head.weight"] = syn["llm.model.model.embed_tokens.weight"]
+    lm.load_state_dict(syn, strict=True)
+    print("llm built", time.time() - t0)
+    g = torch.Generator().manual_seed(21)
+    text = torch.randint(0, 151936, (1, 12), generator=g)
+    ptext = torch.randint(0, 151936, (1, 5), generator=g)
+    pspeech = torch.randint(0, 6561, (1, 9), generator=g)
+    forced = torch.randint(0, 6561, (16,), generator=g)
+    # lm_input as Qwen2LM.inference builds it (llm.py:691-703)
+    tk = torch.cat([ptext, text], dim=1)
+    temb = lm.llm.model.model.embed_tokens(tk)
+    sos = lm.llm_embedding.weight[0].reshape(1, 1, -1)
+    task = lm.llm_embedding.weight[1].reshape(1, 1, -1)
+    lm_input = torch.cat([sos, temb, task, lm.speech_embedding(pspeech)], dim=1)
+    # full causal attention over the cache: drive HF with attention_mask=None
+    logps, hiddens = [], []
+    cache = None
+    x = lm_input
+    for i in range(17):
+        o = lm.llm.model(inputs_embeds=x, output_hidden_states=True, return_dict=True, use_cache=True,
+                         past_key_values=cache)
+        cache = o.past_key_values
+        y = o.hidden_states[-1]
+        logp = lm.llm_decoder(y[:, -1]).log_softmax(dim=-1)
+        logps.append(np_(logp[0]))
+        if i == 0:
+            hiddens = np_(y)
+        if i < 16:
+            x = lm.speech_embedding.weight[forced[i]].reshape(1, 1, -1)
+    out = dict(text=np_(text), ptext=np_(ptext), pspeech=np_(pspeech), forced=np_(forced),
+               lm_input=np_(lm_input), prefill_hidden=hiddens, logp=np.stack(logps))
+    print("logp", out["logp"].shape, "max prob", float(np.exp(out["logp"]).max()))
+    np.savez_compressed(os.path.join(GOLD, "llm.npz"), **out)
+
+
+def gen_sampler():
+    R.import_cosyvoice()
+    from cosyvoice.utils.common import ras_sampling, nucleus_sampling, random_sampling
+    ids, nuc, rnd = [], [], []
+    for s, (logp, hist) in enumerate(W.sampler_cases()):
+        torch.manual_seed(1000 + s)
+        ids.append(int(ras_sampling(logp, hist, 25, top_p=0.8, top_k=25, win_size=10, tau_r=0.1)))
+        torch.manual_seed(1000 + s)
+        nuc.append(int(nucleus_sampling(logp, top_p=0.8, top_k=25)))
+        torch.manual_seed(1000 + s)
+        rnd.append(int(random_sampling(logp, hist, 25)))
+    np.savez_compressed(os.path.join(GOLD, "sampler.npz"), ras=np.array(ids), nucleus=np.array(nuc),
+                        random=np.array(rnd))
+    print("sampler: 200 cases; distinct ids", len(set(ids)))
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["dac", "flow", "llm", "sampler"]
+    for w in which:
+        t0 = time.time()
+        {"dac": gen_dac, "flow": gen_flow, "llm": gen_llm, "sampler": gen_sampler}[w]()
+        print(f"[{w}] done in {time.time() - t0:.1f}s")

@@ -1,0 +1,133 @@
+"""Pins the CPU oracle (oracle/*.py) to the golden vectors produced by the REFERENCE's own classes
+(oracle/gen_golden.py, run in the build container; fixtures under tests/golden/).
+The reference holds no tests or known-answer vectors for this path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dac as ODAC
+from oracle import flow as OFLOW
+from oracle import llm as OLLM
+from oracle import weights as W
+
+SEED = 7
+RATES = [5, 4, 4, 3, 2]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("lat", [80, 128])
+def test_dac_decode_matches_reference(golden_dir, lat):
+    g = _load(golden_dir, f"dac{lat}.npz")
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, f"manifest_dac{lat}.json")), SEED)
+    for T in (8, 50):
+        y = ODAC.decode(sd, torch.from_numpy(g[f"z_T{T}"]), RATES)
+        ref = torch.from_numpy(g[f"wav_T{T}"])
+        assert y.shape == ref.shape == (1, 1, T * 480)
+        assert (y - ref).abs().max() < 2e-5, float((y - ref).abs().max())
+    # stage activations
+    x = ODAC.wnconv1d_act(sd, "de_conv_pre", torch.from_numpy(g["z_T8"]))
+    assert torch.allclose(x, torch.from_numpy(g["pre_T8"]), atol=1e-5)
+    _, st = ODAC.decoder_forward(sd, x, RATES, return_stages=True)
+    for i in range(3):
+        assert torch.allclose(st[i], torch.from_numpy(g[f"stage{i}_T8"]), atol=2e-5), i
+
+
+@pytest.fixture(scope="module")
+def flow_sd(golden_dir):
+    return W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_flow.json")), SEED)
+
+
+def test_flow_rand_noise(golden_dir):
+    g = _load(golden_dir, "flow.npz")
+    assert np.array_equal(OFLOW.rand_noise()[:, :, :64].numpy(), g["rand_noise_head"])
+
+
+def test_flow_estimator_matches_reference(golden_dir, flow_sd):
+    g = _load(golden_dir, "flow.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    T = 64
+    mask = torch.ones(2, 1, T)
+    for name, streaming, mk in (("est_full", False, mask), ("est_stream", True, mask),
+                                ("est_padmask", False, t("est_mask2"))):
+        y = OFLOW.estimator_forward(flow_sd, "decoder.estimator", t("est_x"), mk, t("est_mu"), t("est_t"),
+                                    t("est_spks"), t("est_cond"), streaming)
+        err = (y - t(name)).abs().max()
+        assert err < 2e-5, (name, float(err))
+
+
+def test_flow_encoder_matches_reference(golden_dir, flow_sd):
+    g = _load(golden_dir, "flow.npz")
+    xs, ctx = torch.from_numpy(g["enc_xs"]), torch.from_numpy(g["enc_ctx"])
+    h, _ = OFLOW.encoder_forward(flow_sd, "encoder", xs, torch.tensor([25]), None, False)
+    assert (h - torch.from_numpy(g["enc_full"])).abs().max() < 2e-5
+    h, _ = OFLOW.encoder_forward(flow_sd, "encoder", xs, torch.tensor([25]), ctx, True)
+    assert (h - torch.from_numpy(g["enc_ctx_stream"])).abs().max() < 2e-5
+
+
+def test_flow_inference_matches_reference(golden_dir, flow_sd):
+    g = _load(golden_dir, "flow.npz")
+    tok, ptok = torch.from_numpy(g["flow_tok"]), torch.from_numpy(g["flow_ptok"])
+    pfeat, emb = torch.from_numpy(g["flow_pfeat"]), torch.from_numpy(g["flow_emb"])
+    none_tok, none_feat = torch.zeros(1, 0, dtype=torch.long), torch.zeros(1, 0, 80)
+    cases = {
+        "flow_noprompt": (tok, none_tok, none_feat, False, True),
+        "flow_prompt": (tok, ptok, pfeat, False, True),
+        "flow_stream_nofinal": (tok, ptok, pfeat, True, False),
+        "flow_stream_final": (tok, ptok, pfeat, True, True),
+    }
+    for name, (tk, pt, pf, streaming, finalize) in cases.items():
+        y = OFLOW.flow_inference(flow_sd, tk, pt, pf, emb, streaming, finalize)
+        ref = torch.from_numpy(g[name])
+        assert y.shape == ref.shape
+        assert (y - ref).abs().max() < 1e-4, (name, float((y - ref).abs().max()))
+
+
+def test_llm_teacher_forced_logp_matches_reference(golden_dir):
+    """Full-size (24-layer, 494 M parameter) Qwen2 backbone: prefill + 16 teacher-forced decode steps."""
+    g = _load(golden_dir, "llm.npz")
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_llm.json")), SEED)
+    cfg = OLLM.QwenCfg()
+    lm_input = OLLM.build_lm_input(sd, torch.from_numpy(g["text"]), torch.from_numpy(g["ptext"]),
+                                   torch.from_numpy(g["pspeech"]))
+    assert torch.allclose(lm_input, torch.from_numpy(g["lm_input"]), atol=1e-6)
+    x, cache = lm_input, None
+    for i in range(17):
+        y, cache = OLLM.qwen2_forward(sd, cfg, x, cache)
+        if i == 0:
+            assert (y - torch.from_numpy(g["prefill_hidden"])).abs().max() < 1e-4
+        logp = torch.nn.functional.linear(y[:, -1], sd["llm_decoder.weight"], sd["llm_decoder.bias"]).log_softmax(-1)[0]
+        err = (logp - torch.from_numpy(g["logp"][i])).abs().max()
+        assert err < 2e-4, (i, float(err))
+        if i < 16:
+            x = sd["speech_embedding.weight"][int(g["forced"][i])].reshape(1, 1, -1)
+
+
+def test_sampler_matches_reference_under_torch_seeds(golden_dir):
+    """ras/nucleus/random sampling with torch's own generator as the noise source: ids identical to the
+    reference's (common.py:111-139) for 200 recorded seeds."""
+    g = _load(golden_dir, "sampler.npz")
+    for s, (logp, hist) in enumerate(W.sampler_cases()):
+        torch.manual_seed(1000 + s)
+        assert OLLM.ras_sampling_e(logp, hist, OLLM.torch_noise) == int(g["ras"][s]), s
+        torch.manual_seed(1000 + s)
+        p, idx = OLLM.nucleus_candidates(logp)
+        assert int(idx[OLLM.multinomial_e(p, OLLM.torch_noise(0, p.numel()))]) == int(g["nucleus"][s]), s
+        torch.manual_seed(1000 + s)
+        pr = logp.softmax(0)
+        assert OLLM.multinomial_e(pr, OLLM.torch_noise(1, 6564)) == int(g["random"][s]), s
+
+
+def test_multinomial_is_exponential_race():
+    """torch.multinomial(p, 1) == argmax(p / Exp(1) noise) on the same generator stream."""
+    for s in range(200):
+        n = 25 if s % 2 else 6564
+        p = torch.rand(n, generator=torch.Generator().manual_seed(s)) ** 3
+        torch.manual_seed(s)
+        a = int(p.multinomial(1, replacement=True))
+        torch.manual_seed(s)
+        assert OLLM.multinomial_e(p, OLLM.torch_noise(0, n)) == a
