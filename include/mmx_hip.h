@@ -1,0 +1,190 @@
+/* mmx_hip.h — C ABI of libmmx_hip.so: the MI355X (gfx950) kernels behind the TTS inference hot path
+ * of ishine/minimax-speech (Qwen2 AR speech-token LM -> CosyVoice2 flow-matching decoder -> DAC-VAE
+ * decoder).  SURVEY.md §8(b) "C-ABI underneath".
+ *
+ * The reference has no FFI for this path (it is torch.nn all the way down); each entry point below
+ * replaces the torch operator sequence of the cited reference lines, and is what a ctypes binding in
+ * the reference would call (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless named h_*;
+ *  - the caller owns all buffers; the library keeps no pointer after a call returns and has no
+ *    global mutable state -> re-entrant, one stream per caller thread
+ *    (reference threading: speech/cosyvoice/cli/model.py:332-335, one llm_job thread per request);
+ *  - every launch goes to the `hipStream_t` argument (NULL = legacy default stream), is asynchronous and
+ *    capture-safe (no allocation, no synchronisation) so callers can record hipGraphs;
+ *  - return 0 on success, MMX_EARG (-1) on an argument/shape error (nothing launched),
+ *    <= -1000 for -(hipError_t) - 1000.  The Python host turns non-zero into RuntimeError, matching the
+ *    reference's exception/assert convention (flow.py:453, llm.py:273);
+ *  - `dtype`: MMX_F32 (parity build: fp32 storage, exact fp32 MFMA) or MMX_BF16 (bf16 storage of weights
+ *    and GEMM-input activations, fp32 accumulation and fp32 residual streams).  "T" below means that type.
+ *  - activations are TIME-MAJOR: a [B,C,T] tensor of the reference is stored as rows of C channels.
+ */
+#ifndef MMX_HIP_H
+#define MMX_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define MMX_F32 0
+#define MMX_BF16 1
+
+/* activation codes */
+#define MMX_ACT_NONE 0
+#define MMX_ACT_LRELU 1
+#define MMX_ACT_GELU 2   /* exact erf gelu (diffusers 0.29 GELU) */
+#define MMX_ACT_SILU 3
+#define MMX_ACT_MISH 4
+#define MMX_ACT_TANH 5
+
+int mmx_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Windowed GEMM:  C[b][m][n] = sum_tap sum_c A[b][m + tap*dil + row_off][c] * W[b][n][tap*cin + c]
+ * Replaces torch Linear / Conv1d / ConvTranspose1d (+ the elementwise ops fused in its epilogue):
+ *   dac-vae/model.py:107-143,237-323,342-371 (WNConv1d+LeakyReLU, Snake, WNConvTranspose1d, residual add)
+ *   speech/cosyvoice/flow/decoder.py:36-85 (CausalConv1d), speech/matcha/models/components/transformer.py:243-316
+ *   (to_q/k/v, to_out, GELU proj, ff out), speech/cosyvoice/transformer Linear layers.
+ * Epilogue, per element v:  v += bias;  v = act(v);  v += residual;  v *= rowmask[m];
+ *   out_f32[lin] = v;   out_act[lin] = T( alpha ? snake(act2(v), alpha) : act2(v) )
+ *   with lin = m*ldo + n + out_off, written only when 0 <= lin < out_len (ConvTranspose1d edge clip).
+ */
+typedef struct MmxGemmParams {
+    const void* A;          /* T, rows of lda elements */
+    const void* W;          /* T, [N][ldw], K contiguous, zero padded to a multiple of 32 */
+    const float* bias;      /* [bias_mod] (or [M] when bias_per_row) or NULL */
+    const float* residual;  /* fp32 [M][ldr] or NULL */
+    const float* rowmask;   /* fp32 [M] or NULL */
+    const float* alpha;     /* Snake alpha [alpha_mod] for the out_act copy, or NULL */
+    float* out_f32;         /* fp32 output or NULL */
+    void* out_act;          /* T output or NULL */
+    int64_t lda, ldw, ldr, ldo_f, ldo_a;
+    int64_t a_bstride, w_bstride, r_bstride, rm_bstride, of_bstride, oa_bstride;   /* per batch, in elements */
+    int64_t row_off, row_lo, row_hi;   /* A row = m + tap*dil + row_off, rows outside [row_lo,row_hi) read 0 */
+    int64_t out_off, out_len;
+    int32_t M, N, batch;
+    int32_t ntaps, cin, dil;
+    int32_t bias_mod, alpha_mod, bias_per_row;
+    int32_t act, act2;
+    float slope;
+} MmxGemmParams;
+int mmx_gemm_win(const MmxGemmParams* p, int dtype, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row-wise normalisation (LayerNorm / RMSNorm) with fused tail:
+ *   y = norm(x[b][t][:]) * gamma (+ beta);  y = act(y);  y = (y*rowmask + addvec[b][:]) * rowmask
+ * written to out_f32 and/or out_act (T).  rms != 0 selects RMSNorm (no mean, beta ignored).
+ * Replaces nn.LayerNorm (+Mish, + time-embedding add) of decoder.py:65-85 / matcha decoder.py:56-61,
+ * transformer.py norm1/norm3, encoder_layer.py norm_mha/norm_ff, Qwen2 RMSNorm (prefill).
+ */
+int mmx_rownorm(const float* x, int64_t ldx, int64_t x_bstride, int rows, int C, int batch,
+                const float* gamma, const float* beta, float eps, int rms, int act,
+                const float* rowmask, int64_t rm_bstride, const float* addvec, int64_t av_bstride,
+                float* out_f32, int64_t ldo_f, int64_t of_bstride,
+                void* out_act, int64_t ldo_a, int64_t oa_bstride, int dtype, hipStream_t stream);
+
+/* out[i][:] = table[ids[i]][:] * scale * (rowmask ? rowmask[i] : 1)   (ids < 0 are clamped to 0,
+ * flow.py:477).  Replaces nn.Embedding lookups (flow.py:477, llm.py:694-700). */
+int mmx_gather_rows(const int64_t* ids, int n, const float* table, int C, float scale, const float* rowmask,
+                    float* out_f32, int64_t ldo_f, void* out_act, int64_t ldo_a, int dtype, hipStream_t stream);
+
+/* Strided copy/cast: out[b][r][c] = T(in[b*ibs + r*irs + c*ics]) for r<rows, c<cols; used for
+ * [B,C,T] <-> time-major conversions at the API boundary and nearest-neighbour upsampling
+ * (row r reads input row r / rep; upsample_encoder.py:60). in_dtype/out_dtype may differ. */
+int mmx_copy2d(const void* in, int in_dtype, int64_t ibs, int64_t irs, int64_t ics, int rep,
+               void* out, int out_dtype, int64_t obs, int64_t ors, int64_t ocs,
+               int rows, int cols, int batch, hipStream_t stream);
+
+/* Estimator input pack (decoder.py:424-432): h[b][t] = [x | mu | spks | cond] as T, + sinusoidal
+ * timestep embedding (matcha decoder.py:14-29, scale 1000) emb[b][:] as T.
+ * x/mu/cond are fp32 time-major [B][T][80]; spks [B][80]; NULL mu/spks/cond rows read as zero. */
+int mmx_est_pack(const float* x, const float* mu, const float* spks, const float* cond, int B, int T, int C,
+                 void* h, int64_t ldh, int dtype, hipStream_t stream);
+int mmx_sinusoidal_emb(const float* t, int B, int dim, float scale, void* out, int dtype, hipStream_t stream);
+
+/* CFG + Euler update (flow_matching.py:118-120): x += dt * ((1+cfg)*d[0] - cfg*d[1]); n elements. */
+int mmx_cfg_euler(float* x, const float* d_cond, const float* d_uncond, float cfg, float dt, int64_t n,
+                  hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention.
+ * mmx_attn_dense: softmax(q k^T * scale [+ rel-pos term] masked) v for [B][T][H*D] T-typed q/k/v
+ *   (row strides ldq/ldk/ldv, head h at column h*D).  Key j is visible to query i iff
+ *   j < Tk  and (keymask == NULL or keymask[b][j] != 0) and (chunk == 0 or j < (i/chunk + 1)*chunk);
+ *   rows with no visible key output 0 (they are padding rows, masked by every consumer).
+ *   rel-pos (pos != NULL): score = ((q+u).k + (q+v).pos[T-1-i+j]) * scale — attention.py:225-330 with
+ *   rel_shift folded into the index; pos is [2T-1][H*D] T-typed, u/v fp32 [H][D].
+ *   Replaces diffusers Attention (SDPA) of transformer.py:196-204 with the additive bias of
+ *   decoder.py:441-445 / common.py:160-168, and RelPositionMultiHeadedAttention.
+ * mmx_attn_flash_bf16: the MFMA flash-attention kernel for the same contract without rel-pos, bf16,
+ *   D = 64, V given TRANSPOSED as vt[b][h*D + d][t] (ldvt elements per row, zero padded).
+ */
+int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
+                   const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
+                   int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs, int chunk,
+                   const void* pos, int64_t ldp, const float* pos_u, const float* pos_v,
+                   int dtype, hipStream_t stream);
+int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
+                        const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
+                        int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk,
+                        hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DAC tail: Conv1d(C -> 1, k) + LeakyReLU(0.1) + tanh (dac-vae/model.py:364-370,509-514).
+ * act: T [B][T][C] (Snake already applied by the producer); w fp32 [k][C]; out fp32 [B][T]. */
+int mmx_conv_cout1_tanh(const void* act, int64_t a_bs, int T, int C, int k, const float* w, const float* bias,
+                        float slope, int use_tanh, float* out, int64_t o_bs, int batch, int dtype, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Autoregressive LM decode step (speech/cosyvoice/llm/llm.py:745-760 + HF Qwen2 layer).
+ *
+ * mmx_skinny_gemm: out[b][n] = (rs ? rstd[b] : 1) * sum_k x[b][k] * Wp[n][k] (+bias) for B <= 64 rows:
+ *   weights are streamed once, straight to registers, in MFMA-fragment order (pack with mmx_pack_skinny).
+ *   x is fp32 [B][ldx] (x_dtype MMX_F32) or T.  rs != 0: rstd[b] = rsqrt(mean_k x^2 + eps) is computed
+ *   in-kernel (RMSNorm with its weight pre-folded into Wp).  epi: 0 store fp32 (+bias);
+ *   1 SwiGLU: Wp rows are [gate tile | up tile] pairs, out_act[b][n] = T(silu(g)*u);
+ *   2 residual: out_f32[b][n] += acc (in place).
+ */
+int mmx_pack_skinny(const void* w, int64_t ldw, int N, int K, const float* kscale, int interleave_half,
+                    void* wp, int dtype, hipStream_t stream);
+int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N, const void* wp,
+                    const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
+                    void* out_act, int64_t ldo_a, int dtype, hipStream_t stream);
+
+/* RoPE (HF rotate_half; inv_freq[D/2] fp32 = 1/theta^(2i/D) as HF computes it) on q/k of
+ * qkv[b][t][: (Hq+2Hkv)*D] at position pos[b] + t, K/V appended to the paged cache, q written as T.  Cache layout:
+ * kc/vc [n_pages][Hkv][page][D] T, block_table [B][max_pages] int32.  rows = tokens per sequence. */
+int mmx_rope_kv_store(const float* qkv, int64_t ldqkv, int64_t qkv_bs, int B, int rows, int Hq, int Hkv, int D,
+                      const float* inv_freq, const int32_t* pos, void* q_out, int64_t ldq, int64_t q_bs,
+                      void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
+                      int dtype, hipStream_t stream);
+/* Causal GQA attention over the paged cache: query row t of sequence b sees keys [0, pos[b] + t]. */
+int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, int Hq, int Hkv, int D, float scale,
+                   const int32_t* pos, const void* kc, const void* vc, const int32_t* block_table, int max_pages,
+                   int page, void* out, int64_t ldo, int64_t o_bs, int dtype, hipStream_t stream);
+/* SwiGLU for prefill: out = T(silu(gu[:, :I]) * gu[:, I:2I]) */
+int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* out, int64_t ldo, int dtype, hipStream_t stream);
+
+/* Sampler = log_softmax + ras_sampling + sampling_ids + the loop bookkeeping of inference_wrapper
+ * (llm.py:259-274,751-760; utils/common.py:111-139), one workgroup per sequence, all state on device:
+ *   state[b] = {pos, step, n_out, finished, min_len, max_len, seq_id, _}  (int32 x 8)
+ * Draws follow oracle/philox.py (Philox4x32-10 keyed by seed; exponential race == torch.multinomial).
+ * On an accepted token: appended to out_tokens[b][n_out++], next_x[b][:] = speech_emb[token][:].
+ * EOS (== eos_id) sets finished; ids > eos_id leave next_x unchanged (llm.py:755-756).
+ * Every call advances state.step and state.pos (+1) of unfinished sequences.
+ * forced != NULL: teacher forcing, forced[b*max_out + step] replaces the accepted token (the sampled id is
+ * still recorded in sampled[b][step]).  logp_out (optional) receives log_softmax(logits). */
+int mmx_sample_step(const float* logits, int64_t ldl, int V, int B, int eos_id, int top_k, float top_p,
+                    int win_size, float tau_r, uint64_t seed, int32_t* state, int32_t* out_tokens, int max_out,
+                    int32_t* sampled, const int32_t* forced, const float* speech_emb, int E, float* next_x,
+                    int64_t ldx, float* logp_out, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,279 @@
+// Attention kernels of the flow decoder (see include/mmx_hip.h for the contracts).
+//   attn_dense_kernel : general fp32-accumulating kernel (any T, optional ESPnet rel-pos term, key / chunk
+//                       masks) — the parity path and the conformer encoder (10 layers, once per utterance).
+//   attn_flash_kernel : bf16 MFMA flash attention for the estimator's 56 blocks x 10 Euler steps
+//                       (the flow's dominant FLOPs: SURVEY.md §8d, 57.3 of 189.5 GFLOP per call).
+#include "common.h"
+#include "../../include/mmx_hip.h"
+
+__device__ __forceinline__ bool key_visible(int i, int j, int Tk, const float* km, int chunk) {
+    if (j >= Tk) return false;
+    if (km && km[j] == 0.f) return false;
+    if (chunk > 0 && j >= (i / chunk + 1) * chunk) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ dense
+// block = (b, h, 8 queries); scores live in LDS ([8][Tk] fp32), so Tk <= ~4500.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dense_kernel(
+    const T* __restrict__ q, long ldq, long q_bs, const T* __restrict__ k, long ldk, long k_bs,
+    const T* __restrict__ v, long ldv, long v_bs, T* __restrict__ out, long ldo, long o_bs,
+    int H, int Tq, int Tk, float scale, const float* __restrict__ keymask, long km_bs, int chunk,
+    const T* __restrict__ pos, long ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v) {
+    constexpr int D = 64, QT = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qu = reinterpret_cast<float*>(smem);        // [QT][D]  q (+u)
+    float* qv = qu + QT * D;                           // [QT][D]  q + v (rel-pos only)
+    float* inv_l = qv + QT * D;                        // [QT]
+    float* S = inv_l + QT;                             // [QT][Tk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QT;
+    q += (long)b * q_bs + h * D;
+    k += (long)b * k_bs + h * D;
+    v += (long)b * v_bs + h * D;
+    out += (long)b * o_bs + h * D;
+    const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
+
+    for (int i = tid; i < QT * D; i += 256) {
+        int qi = i / D, d = i % D;
+        int row = q0 + qi < Tq ? q0 + qi : Tq - 1;
+        float x = Cvt<T>::to_f(q[(long)row * ldq + d]);
+        qu[i] = x + (pos ? pos_u[h * D + d] : 0.f);
+        qv[i] = x + (pos ? pos_v[h * D + d] : 0.f);
+    }
+    __syncthreads();
+    // phase 1: scores
+    for (int j = tid; j < Tk; j += 256) {
+        float kr[D];
+        const T* kp = k + (long)j * ldk;
+#pragma unroll
+        for (int d = 0; d < D; ++d) kr[d] = Cvt<T>::to_f(kp[d]);
+#pragma unroll 1
+        for (int qi = 0; qi < QT; ++qi) {
+            const int i = q0 + qi;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += qu[qi * D + d] * kr[d];
+            if (pos && i < Tq) {
+                // rel_shift folded: bd[i][j] = (q_i + v) . pos[Tq - 1 - i + j]
+                const T* pp = pos + (long)(Tq - 1 - i + j) * ldp + h * D;
+                float s2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) s2 += qv[qi * D + d] * Cvt<T>::to_f(pp[d]);
+                s += s2;
+            }
+            S[(long)qi * Tk + j] = key_visible(i, j, Tk, km, chunk) ? s * scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    // phase 2: softmax per row (wave per row)
+    for (int qi = wave; qi < QT; qi += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < Tk; j += 64) m = fmaxf(m, S[(long)qi * Tk + j]);
+        m = wave_max(m);
+        float l = 0.f;
+        if (m > -INFINITY) {
+            for (int j = lane; j < Tk; j += 64) {
+                float e = expf(S[(long)qi * Tk + j] - m);
+                S[(long)qi * Tk + j] = e;
+                l += e;
+            }
+            l = wave_sum(l);
+        } else {
+            for (int j = lane; j < Tk; j += 64) S[(long)qi * Tk + j] = 0.f;
+        }
+        if (lane == 0) inv_l[qi] = l > 0.f ? 1.f / l : 0.f;
+    }
+    __syncthreads();
+    // phase 3: O = P V ; thread -> (query, 2 consecutive d)
+    {
+        const int qi = tid >> 5, d0 = (tid & 31) * 2;
+        float a0 = 0.f, a1 = 0.f;
+        const float* Sr = S + (long)qi * Tk;
+        for (int j = 0; j < Tk; ++j) {
+            float p = Sr[j];
+            const T* vp = v + (long)j * ldv + d0;
+            a0 += p * Cvt<T>::to_f(vp[0]);
+            a1 += p * Cvt<T>::to_f(vp[1]);
+        }
+        const int i = q0 + qi;
+        if (i < Tq) {
+            out[(long)i * ldo + d0] = Cvt<T>::from_f(a0 * inv_l[qi]);
+            out[(long)i * ldo + d0 + 1] = Cvt<T>::from_f(a1 * inv_l[qi]);
+        }
+    }
+}
+
+extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
+                              const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
+                              int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs,
+                              int chunk, const void* pos, int64_t ldp, const float* pos_u, const float* pos_v,
+                              int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(q && k && v && out && B > 0 && H > 0 && D == 64 && Tq > 0 && Tk > 0 && chunk >= 0);
+    MMX_CHECK_ARG(!pos || (pos_u && pos_v && Tq == Tk));
+    size_t lds = (size_t)(2 * 8 * 64 + 8 + 8 * (size_t)Tk) * 4;
+    MMX_CHECK_ARG(lds <= 160 * 1024);
+    dim3 grid((Tq + 7) / 8, H, B);
+    if (dtype == MMX_BF16)
+        hipLaunchKernelGGL(attn_dense_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+                           (const bf16_t*)v, ldv, v_bs, (bf16_t*)out, ldo, o_bs, H, Tq, Tk, scale, keymask, km_bs, chunk,
+                           (const bf16_t*)pos, ldp, pos_u, pos_v);
+    else if (dtype == MMX_F32)
+        hipLaunchKernelGGL(attn_dense_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, ldq, q_bs, (const float*)k, ldk, k_bs,
+                           (const float*)v, ldv, v_bs, (float*)out, ldo, o_bs, H, Tq, Tk, scale, keymask, km_bs, chunk,
+                           (const float*)pos, ldp, pos_u, pos_v);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ flash (bf16, D = 64)
+// block = 4 waves x 16 queries; K tile [64 keys][64 d] and V^T tile [64 d][64 keys] in LDS with 144-byte
+// rows (72 bf16: 16 rows x 144 B hit 16 distinct 16-byte bank slots -> conflict-free ds_read_b128);
+// S = Q K^T and O += P V on v_mfma_f32_16x16x32_bf16; online softmax in registers, row reductions over
+// the 16 lanes that share a query row via 4 xor-shuffles; P goes through a 2 KB per-wave LDS patch to
+// turn the C-layout tile into the A-operand layout.
+__global__ __launch_bounds__(256) void attn_flash_kernel(
+    const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
+    const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
+    int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk) {
+    constexpr int D = 64, KT = 64, LD = 72;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[D * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[4 * 16 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qb = blockIdx.x * 64 + wave * 16;        // this wave's first query
+    q += (long)b * q_bs + h * D;
+    k += (long)b * k_bs + h * D;
+    vt += (long)b * vt_bs + (long)h * D * ldvt;
+    out += (long)b * o_bs + h * D;
+    const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
+
+    // Q fragments (A operand): lane (row l16, k-group g) holds Q[row][ks*32 + 8g .. +7]
+    short8_t aq[2];
+    {
+        int row = qb + l16 < Tn ? qb + l16 : Tn - 1;
+        const bf16_t* qp = q + (long)row * ldq + 8 * g;
+        aq[0] = *reinterpret_cast<const short8_t*>(qp);
+        aq[1] = *reinterpret_cast<const short8_t*>(qp + 32);
+    }
+    float4_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+
+    // keys beyond the last query's chunk are invisible to the whole block
+    int kend = Tn;
+    if (chunk > 0) {
+        int qlast = blockIdx.x * 64 + 63;
+        if (qlast > Tn - 1) qlast = Tn - 1;
+        int e = (qlast / chunk + 1) * chunk;
+        if (e < kend) kend = e;
+    }
+    bf16_t* Pw = Ps + wave * 16 * LD;
+
+    for (int j0 = 0; j0 < kend; j0 += KT) {
+        __syncthreads();                               // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int id = tid + i * 256;                    // 512 chunks of 16 B per tile
+            int r = id >> 3, c = (id & 7) * 8;
+            int key = j0 + r;
+            uint4 kv = key < Tn ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Ks + r * LD + c) = kv;
+            // V^T rows are d; columns j0 + c .. +7 (buffer is zero padded to a multiple of 8 columns)
+            uint4 vv = (j0 + c < Tn) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Vs + r * LD + c) = vv;
+        }
+        __syncthreads();
+        // S = Q K^T  (4 key fragments of 16)
+        float4_t s[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            s[nf] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                short8_t bk = *reinterpret_cast<const short8_t*>(Ks + (nf * 16 + l16) * LD + ks * 32 + 8 * g);
+                s[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ks], bk, s[nf], 0, 0, 0);
+            }
+        }
+        // mask + online softmax; C layout: row = 4g + r (query), col = nf*16 + l16 (key)
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = qb + 4 * g + r;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int j = j0 + nf * 16 + l16;
+                float x = key_visible(i, j, Tn, km, chunk) ? s[nf][r] * scale : -INFINITY;
+                s[nf][r] = x;
+                mx = fmaxf(mx, x);
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float m_new = fmaxf(m_run[r], mx);
+            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+            alpha[r] = __expf(m_run[r] - m_safe);      // m_run = -inf -> 0
+            float rs = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                float p = __expf(s[nf][r] - m_safe);
+                s[nf][r] = p;
+                rs += p;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+            l_run[r] = l_run[r] * alpha[r] + rs;
+            m_run[r] = m_new;
+        }
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[df][r] *= alpha[r];
+        // P -> LDS (row-major [16 q][64 keys]) -> A fragments
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pw[(4 * g + r) * LD + nf * 16 + l16] = f2bf(s[nf][r]);
+        __syncthreads();
+        short8_t ap[2];
+        ap[0] = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 8 * g);
+        ap[1] = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 32 + 8 * g);
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                short8_t bv = *reinterpret_cast<const short8_t*>(Vs + (df * 16 + l16) * LD + ks * 32 + 8 * g);
+                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[ks], bv, o[df], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = qb + 4 * g + r;
+        if (i >= Tn) continue;
+        const float inv = l_run[r] > 0.f ? 1.f / l_run[r] : 0.f;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) out[(long)i * ldo + df * 16 + l16] = f2bf(o[df][r] * inv);
+    }
+}
+
+extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
+                                   const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
+                                   int B, int H, int T_, float scale, const float* keymask, int64_t km_bs, int chunk,
+                                   hipStream_t stream) {
+    MMX_CHECK_ARG(q && k && vt && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0);
+    MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
+    MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8);
+    MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0);
+    dim3 grid((T_ + 63) / 64, H, B);
+    hipLaunchKernelGGL(attn_flash_kernel, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+                       (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}

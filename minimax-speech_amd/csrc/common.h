@@ -1,0 +1,68 @@
+// Shared device helpers for libmmx_hip.so (gfx950 / CDNA4 only: wave64, MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MMX_OK 0
+#define MMX_EARG (-1)
+#define MMX_CHECK_ARG(c) do { if (!(c)) return MMX_EARG; } while (0)
+#define MMX_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return -(int)e_ - 1000; } while (0)
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    static __device__ __forceinline__ float to_f(float v) { return v; }
+    static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+    static __device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+    static __device__ __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activations used by the fused epilogues (codes are part of the C ABI, include/mmx_hip.h)
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_MISH = 4, ACT_TANH = 5 };
+
+template <bool PRECISE>
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case ACT_LRELU: return v > 0.f ? v : v * slope;
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case ACT_SILU: return v / (1.f + (PRECISE ? expf(-v) : __expf(-v)));
+        case ACT_MISH: {   // x * tanh(softplus(x)), torch softplus threshold 20
+            float sp = v > 20.f ? v : log1pf(PRECISE ? expf(v) : __expf(v));
+            return v * tanhf(sp);
+        }
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// dac-vae/layers.py:22  snake(x,a) = x + (a + 1e-9)^-1 * sin(a x)^2   (exact operation order)
+template <bool PRECISE>
+__device__ __forceinline__ float snake_apply(float x, float alpha) {
+    float s = PRECISE ? sinf(alpha * x) : __sinf(alpha * x);
+    return x + (1.0f / (alpha + 1e-9f)) * (s * s);
+}

@@ -1,0 +1,266 @@
+// Row-wise and elementwise kernels of the hot path (all HBM-bound: coalesced rows, wave-shuffle
+// reductions, one pass over the data).  See include/mmx_hip.h for the contracts.
+#include "common.h"
+#include "../../include/mmx_hip.h"
+
+// ---------------------------------------------------------------------------- rownorm
+// one wave per row; C <= 1024*? handled by a strided loop. fp32 statistics (two-pass over registers).
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void rownorm_kernel(
+    const float* __restrict__ x, long ldx, long x_bs, int rows, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rms, int act,
+    const float* __restrict__ rowmask, long rm_bs, const float* __restrict__ addvec, long av_bs,
+    float* __restrict__ outf, long ldo_f, long of_bs, T* __restrict__ outa, long ldo_a, long oa_bs) {
+    constexpr bool PRECISE = sizeof(T) == 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* xr = x + (long)b * x_bs + (long)row * ldx;
+    float v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + i * 64;
+        v[i] = c < C ? xr[c] : 0.f;
+        s += v[i];
+    }
+    float mean = 0.f;
+    if (!rms) mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + i * 64;
+        float d = c < C ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const float rm = rowmask ? rowmask[(long)b * rm_bs + row] : 1.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + i * 64;
+        if (c >= C) continue;
+        float y = (v[i] - mean) * rstd * gamma[c];
+        if (!rms && beta) y += beta[c];
+        y = act_apply<PRECISE>(y, act, 0.f);
+        y *= rm;
+        if (addvec) y = (y + addvec[(long)b * av_bs + c]) * rm;
+        if (outf) outf[(long)b * of_bs + (long)row * ldo_f + c] = y;
+        if (outa) outa[(long)b * oa_bs + (long)row * ldo_a + c] = Cvt<T>::from_f(y);
+    }
+}
+
+extern "C" int mmx_rownorm(const float* x, int64_t ldx, int64_t x_bstride, int rows, int C, int batch,
+                           const float* gamma, const float* beta, float eps, int rms, int act,
+                           const float* rowmask, int64_t rm_bstride, const float* addvec, int64_t av_bstride,
+                           float* out_f32, int64_t ldo_f, int64_t of_bstride,
+                           void* out_act, int64_t ldo_a, int64_t oa_bstride, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(x && gamma && rows > 0 && C > 0 && C <= 1024 && batch > 0 && (out_f32 || out_act));
+    dim3 grid((rows + 3) / 4, batch);
+#define RN(T, MV) hipLaunchKernelGGL((rownorm_kernel<T, MV>), grid, dim3(256), 0, stream, x, ldx, x_bstride, rows, C, \
+        gamma, beta, eps, rms, act, rowmask, rm_bstride, addvec, av_bstride, out_f32, ldo_f, of_bstride, (T*)out_act, ldo_a, oa_bstride)
+    if (dtype == MMX_BF16) { if (C <= 256) RN(bf16_t, 4); else if (C <= 512) RN(bf16_t, 8); else RN(bf16_t, 16); }
+    else if (dtype == MMX_F32) { if (C <= 256) RN(float, 4); else if (C <= 512) RN(float, 8); else RN(float, 16); }
+    else return MMX_EARG;
+#undef RN
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ---------------------------------------------------------------------------- gather rows
+template <typename T>
+__global__ void gather_rows_kernel(const int64_t* __restrict__ ids, int n, const float* __restrict__ table, int C,
+                                   float scale, const float* __restrict__ rowmask, float* __restrict__ outf, long ldo_f,
+                                   T* __restrict__ outa, long ldo_a) {
+    const int i = blockIdx.x;
+    long id = ids[i];
+    if (id < 0) id = 0;
+    const float m = scale * (rowmask ? rowmask[i] : 1.f);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v = table[id * C + c] * m;
+        if (outf) outf[(long)i * ldo_f + c] = v;
+        if (outa) outa[(long)i * ldo_a + c] = Cvt<T>::from_f(v);
+    }
+}
+extern "C" int mmx_gather_rows(const int64_t* ids, int n, const float* table, int C, float scale, const float* rowmask,
+                               float* out_f32, int64_t ldo_f, void* out_act, int64_t ldo_a, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(ids && table && n > 0 && C > 0 && (out_f32 || out_act));
+    if (dtype == MMX_BF16)
+        hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(n), dim3(256), 0, stream, ids, n, table, C, scale, rowmask, out_f32, ldo_f, (bf16_t*)out_act, ldo_a);
+    else if (dtype == MMX_F32)
+        hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(n), dim3(256), 0, stream, ids, n, table, C, scale, rowmask, out_f32, ldo_f, (float*)out_act, ldo_a);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ---------------------------------------------------------------------------- copy2d (transposing cast through LDS)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy2d_kernel(const TI* __restrict__ in, long ibs, long irs, long ics, int rep,
+                                                     TO* __restrict__ out, long obs, long ors, long ocs, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    in += (long)b * ibs;
+    out += (long)b * obs;
+    // read with the faster-varying INPUT index on tx
+    const bool in_col_fast = (ics <= irs);
+    for (int j = ty; j < 32; j += 8) {
+        int r = in_col_fast ? r0 + j : r0 + tx;
+        int c = in_col_fast ? c0 + tx : c0 + j;
+        if (r < rows && c < cols) {
+            float v = Cvt<TI>::to_f(in[(long)(r / rep) * irs + (long)c * ics]);
+            tile[r - r0][c - c0] = v;
+        }
+    }
+    __syncthreads();
+    const bool out_col_fast = (ocs <= ors);
+    for (int j = ty; j < 32; j += 8) {
+        int r = out_col_fast ? r0 + j : r0 + tx;
+        int c = out_col_fast ? c0 + tx : c0 + j;
+        if (r < rows && c < cols) out[(long)r * ors + (long)c * ocs] = Cvt<TO>::from_f(tile[r - r0][c - c0]);
+    }
+}
+extern "C" int mmx_copy2d(const void* in, int in_dtype, int64_t ibs, int64_t irs, int64_t ics, int rep,
+                          void* out, int out_dtype, int64_t obs, int64_t ors, int64_t ocs,
+                          int rows, int cols, int batch, hipStream_t stream) {
+    MMX_CHECK_ARG(in && out && rows > 0 && cols > 0 && batch > 0 && rep >= 1);
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+#define CP(TI, TO) hipLaunchKernelGGL((copy2d_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)in, ibs, irs, ics, rep, (TO*)out, obs, ors, ocs, rows, cols)
+    if (in_dtype == MMX_F32 && out_dtype == MMX_F32) CP(float, float);
+    else if (in_dtype == MMX_F32 && out_dtype == MMX_BF16) CP(float, bf16_t);
+    else if (in_dtype == MMX_BF16 && out_dtype == MMX_F32) CP(bf16_t, float);
+    else if (in_dtype == MMX_BF16 && out_dtype == MMX_BF16) CP(bf16_t, bf16_t);
+    else return MMX_EARG;
+#undef CP
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ---------------------------------------------------------------------------- estimator input pack / time embedding
+template <typename T>
+__global__ void est_pack_kernel(const float* __restrict__ x, const float* __restrict__ mu, const float* __restrict__ spks,
+                                const float* __restrict__ cond, int Tn, int C, T* __restrict__ h, long ldh) {
+    const int b = blockIdx.y;
+    const long row = blockIdx.x;                   // frame
+    const long o = ((long)b * Tn + row);
+    for (int c = threadIdx.x; c < 4 * C; c += blockDim.x) {
+        int part = c / C, cc = c % C;
+        float v;
+        if (part == 0) v = x[o * C + cc];
+        else if (part == 1) v = mu ? mu[o * C + cc] : 0.f;
+        else if (part == 2) v = spks ? spks[(long)b * C + cc] : 0.f;
+        else v = cond ? cond[o * C + cc] : 0.f;
+        h[o * ldh + c] = Cvt<T>::from_f(v);
+    }
+}
+extern "C" int mmx_est_pack(const float* x, const float* mu, const float* spks, const float* cond, int B, int T_, int C,
+                            void* h, int64_t ldh, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(x && h && B > 0 && T_ > 0 && C > 0 && ldh >= 4 * C);
+    dim3 grid(T_, B);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(est_pack_kernel<bf16_t>, grid, dim3(128), 0, stream, x, mu, spks, cond, T_, C, (bf16_t*)h, ldh);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(est_pack_kernel<float>, grid, dim3(128), 0, stream, x, mu, spks, cond, T_, C, (float*)h, ldh);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+template <typename T>
+__global__ void sinusoidal_kernel(const float* __restrict__ t, int dim, float scale, T* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int half = dim / 2;
+    const float k = logf(10000.f) / (float)(half - 1);
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        int j = i < half ? i : i - half;
+        float e = scale * t[b] * expf((float)j * -k);
+        out[(long)b * dim + i] = Cvt<T>::from_f(i < half ? sinf(e) : cosf(e));
+    }
+}
+extern "C" int mmx_sinusoidal_emb(const float* t, int B, int dim, float scale, void* out, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(t && out && B > 0 && dim >= 4 && dim % 2 == 0);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(sinusoidal_kernel<bf16_t>, dim3(B), dim3(128), 0, stream, t, dim, scale, (bf16_t*)out);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(sinusoidal_kernel<float>, dim3(B), dim3(128), 0, stream, t, dim, scale, (float*)out);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+__global__ void cfg_euler_kernel(float* __restrict__ x, const float* __restrict__ dc, const float* __restrict__ du,
+                                 float cfg, float dt, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] + dt * ((1.0f + cfg) * dc[i] - cfg * du[i]);
+}
+extern "C" int mmx_cfg_euler(float* x, const float* d_cond, const float* d_uncond, float cfg, float dt, int64_t n,
+                             hipStream_t stream) {
+    MMX_CHECK_ARG(x && d_cond && d_uncond && n > 0);
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, d_cond, d_uncond, cfg, dt, (long)n);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ---------------------------------------------------------------------------- DAC tail conv (C -> 1) + LeakyReLU + tanh
+// One thread per output sample; the k*C weights sit in LDS; a block's 256 consecutive samples read a
+// (256 + k - 1) x C window of the activation, staged once through LDS (coalesced 16-byte rows).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const T* __restrict__ act, long a_bs, int Tn, int C, int k,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float slope, int use_tanh, float* __restrict__ out, long o_bs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = reinterpret_cast<float*>(smem);              // [k*C]
+    T* xs = reinterpret_cast<T*>(ws + k * C);                // [(256 + k - 1)][C]
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 256;
+    const int pad = (k - 1) / 2;
+    const T* a = act + (long)b * a_bs;
+    for (int i = threadIdx.x; i < k * C; i += 256) ws[i] = w[i];
+    const int nrow = 256 + k - 1;
+    for (int i = threadIdx.x; i < nrow * C; i += 256) {
+        int r = i / C, c = i % C;
+        long t = (long)t0 + r - pad;
+        xs[i] = (t >= 0 && t < Tn) ? a[t * C + c] : Cvt<T>::from_f(0.f);
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= Tn) return;
+    float acc = bias ? bias[0] : 0.f;
+    const T* xr = xs + threadIdx.x * C;                      // window rows [tid, tid + k)
+    for (int i = 0; i < k * C; ++i) acc += Cvt<T>::to_f(xr[i]) * ws[i];
+    acc = acc > 0.f ? acc : acc * slope;
+    out[(long)b * o_bs + t] = use_tanh ? tanhf(acc) : fminf(fmaxf(acc, -1.f), 1.f);
+}
+extern "C" int mmx_conv_cout1_tanh(const void* act, int64_t a_bs, int T_, int C, int k, const float* w, const float* bias,
+                                   float slope, int use_tanh, float* out, int64_t o_bs, int batch, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(act && w && out && T_ > 0 && C > 0 && k > 0 && (k & 1) && batch > 0);
+    dim3 grid((T_ + 255) / 256, batch);
+    size_t esz = dtype == MMX_BF16 ? 2 : 4;
+    size_t lds = (size_t)k * C * 4 + (size_t)(256 + k - 1) * C * esz;
+    MMX_CHECK_ARG(lds <= 160 * 1024);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(conv_cout1_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)act, a_bs, T_, C, k, w, bias, slope, use_tanh, out, o_bs);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(conv_cout1_kernel<float>, grid, dim3(256), lds, stream, (const float*)act, a_bs, T_, C, k, w, bias, slope, use_tanh, out, o_bs);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ---------------------------------------------------------------------------- SwiGLU (prefill)
+template <typename T>
+__global__ void swiglu_kernel(const float* __restrict__ gu, long ldgu, int I, T* __restrict__ out, long ldo) {
+    const long r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= I) return;
+    float g = gu[r * ldgu + c], u = gu[r * ldgu + I + c];
+    float s = g / (1.f + expf(-g));
+    out[r * ldo + c] = Cvt<T>::from_f(s * u);
+}
+extern "C" int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* out, int64_t ldo, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(gu && out && rows > 0 && I > 0);
+    dim3 grid((I + 255) / 256, rows);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(swiglu_kernel<bf16_t>, grid, dim3(256), 0, stream, gu, ldgu, I, (bf16_t*)out, ldo);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(swiglu_kernel<float>, grid, dim3(256), 0, stream, gu, ldgu, I, (float*)out, ldo);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+extern "C" int mmx_abi_version(void) { return 1; }

@@ -1,0 +1,224 @@
+// Windowed MFMA GEMM for gfx950: the one kernel family behind every Linear, Conv1d and
+// ConvTranspose1d of the flow decoder and the DAC-VAE decoder.
+//
+//   C[b][m][n] = sum_{tap < ntaps} sum_{c < cin}  A[b][(m + tap*dil + row_off)][c] * W[n][tap*cin + c]
+//
+// A is a time-major activation matrix (row = frame, lda elements per row); a k-tap convolution is a
+// GEMM whose A rows are overlapping windows of it, so Conv1d needs no im2col buffer and no physical
+// zero padding (rows outside [row_lo,row_hi) read as 0).  ConvTranspose1d (kernel 2s, stride s) is
+// the same GEMM with ntaps = 2 and N = s*Cout (all s output phases side by side), whose row-major
+// output IS the interleaved signal shifted by `out_off` (see dac-vae/model.py:260-267 for the op).
+//
+// Tiling: 256 threads = 4 waves (WM x WN); each wave owns (BM/WM) x (BN/WN) of the block tile as
+// 16x16 MFMA fragments; K is walked in steps of 32 through a 2-stage LDS ring (register-staged
+// prefetch of tile k+1 while tile k is multiplied).  bf16 uses v_mfma_f32_16x16x32_bf16; the fp32
+// parity build uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, cdna_hip_programming.md §3).
+// LDS rows are 64 B (bf16): one wave's ds_read_b128 covers a contiguous 1 KiB -> conflict free.
+//
+// Fused epilogue: + bias -> activation -> + residual -> * row mask -> store fp32 (residual stream)
+// and/or store T after an optional Snake (the NEXT conv's input activation, dac-vae/layers.py:22),
+// so no elementwise kernel ever round-trips HBM between two convs.
+#include "common.h"
+#include "gemm.h"
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+    static constexpr int CH = 8;              // elements per 16-byte chunk
+    static constexpr int LDS_ROW = 32;        // elements per LDS row (64 B)
+};
+template <> struct Frag<float> {
+    static constexpr int CH = 4;
+    static constexpr int LDS_ROW = 36;        // 32 + 4 pad (144 B rows) to spread banks
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
+    constexpr int BK = 32;
+    constexpr int CH = Frag<T>::CH;
+    constexpr int CPR = BK / CH;                       // chunks per row per k-tile
+    constexpr int LR = Frag<T>::LDS_ROW;
+    constexpr int MF = BM / WM / 16, NF = BN / WN / 16;
+    constexpr int A_CHUNKS = (BM * CPR + 255) / 256, W_CHUNKS = (BN * CPR + 255) / 256;
+    constexpr bool A_FULL = (BM * CPR) % 256 == 0, W_FULL = (BN * CPR) % 256 == 0;
+    constexpr bool PRECISE = sizeof(T) == 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);                // [2][BM][LR]
+    T* Ws = As + 2 * BM * LR;                          // [2][BN][LR]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    const T* A = reinterpret_cast<const T*>(p.A) + (long)b * p.a_bstride;
+    const T* W = reinterpret_cast<const T*>(p.W) + (long)b * p.w_bstride;
+
+    // per-thread chunk coordinates (constant across k tiles) and incremental (tap, c) trackers
+    int a_row[A_CHUNKS], a_tap[A_CHUNKS], a_c[A_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+        int id = tid + i * 256;
+        a_row[i] = id / CPR;
+        int k = (id % CPR) * CH;
+        a_tap[i] = k / p.cin;
+        a_c[i] = k % p.cin;
+    }
+    uint4 a_reg[A_CHUNKS], w_reg[W_CHUNKS];
+    const int K = p.ntaps * p.cin;
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            int m = m0 + a_row[i];
+            long srow = (long)m + (long)a_tap[i] * p.dil + p.row_off;
+            bool ok = (m < p.M) && (a_tap[i] < p.ntaps) && (srow >= p.row_lo) && (srow < p.row_hi);
+            if (!A_FULL) ok = ok && (tid + i * 256 < BM * CPR);
+            a_reg[i] = ok ? *reinterpret_cast<const uint4*>(A + srow * p.lda + a_c[i]) : make_uint4(0, 0, 0, 0);
+            a_c[i] += BK;
+            while (a_c[i] >= p.cin) { a_c[i] -= p.cin; a_tap[i]++; }
+        }
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i) {
+            int id = tid + i * 256;
+            int r = id / CPR, kc = (id % CPR) * CH;
+            int n = n0 + r;
+            w_reg[i] = (n < p.N && (W_FULL || id < BN * CPR)) ? *reinterpret_cast<const uint4*>(W + (long)n * p.ldw + kt * BK + kc)
+                                 : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            int id = tid + i * 256;
+            if (A_FULL || id < BM * CPR)
+                *reinterpret_cast<uint4*>(As + (stage * BM + id / CPR) * LR + (id % CPR) * CH) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i) {
+            int id = tid + i * 256;
+            if (W_FULL || id < BN * CPR)
+                *reinterpret_cast<uint4*>(Ws + (stage * BN + id / CPR) * LR + (id % CPR) * CH) = w_reg[i];
+        }
+    };
+
+    float4_t acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + BK - 1) / BK;                  // W is zero padded to nk*BK columns (ldw >= nk*BK)
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const T* as = As + (st * BM + wm * (BM / WM) + l16) * LR;
+        const T* ws = Ws + (st * BN + wn * (BN / WN) + l16) * LR;
+        if constexpr (sizeof(T) == 2) {
+            short8_t af[MF], bfr[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const short8_t*>(as + i * 16 * LR + 8 * g);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bfr[j] = *reinterpret_cast<const short8_t*>(ws + j * 16 * LR + 8 * g);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {              // two 16-deep chunks; step s multiplies k = 16c + 4g' + s
+                float4_t af[MF], bfr[NF];
+#pragma unroll
+                for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const float4_t*>(as + i * 16 * LR + 16 * c + 4 * g);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bfr[j] = *reinterpret_cast<const float4_t*>(ws + j * 16 * LR + 16 * c + 4 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile(st ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ fused epilogue
+    float* outf = p.out_f32 ? p.out_f32 + (long)b * p.of_bstride : nullptr;
+    T* outa = p.out_act ? reinterpret_cast<T*>(p.out_act) + (long)b * p.oa_bstride : nullptr;
+    const float* res = p.residual ? p.residual + (long)b * p.r_bstride : nullptr;
+    const float* rmask = p.rowmask ? p.rowmask + (long)b * p.rm_bstride : nullptr;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + 4 * g + r;
+            if (m >= p.M) continue;
+            const float rm = rmask ? rmask[m] : 1.f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int n = n0 + wn * (BN / WN) + j * 16 + l16;
+                if (n >= p.N) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[p.bias_per_row ? m : (n % p.bias_mod)];
+                v = act_apply<PRECISE>(v, p.act, p.slope);
+                if (res) v += res[(long)m * p.ldr + n];
+                v *= rm;
+                if (outf) {
+                    long lin = (long)m * p.ldo_f + n + p.out_off;
+                    if (lin >= 0 && lin < p.out_len) outf[lin] = v;
+                }
+                if (outa) {
+                    long lin = (long)m * p.ldo_a + n + p.out_off;
+                    if (lin >= 0 && lin < p.out_len) {
+                        float w = act_apply<PRECISE>(v, p.act2, p.slope);
+                        if (p.alpha) w = snake_apply<PRECISE>(w, p.alpha[n % p.alpha_mod]);
+                        outa[lin] = Cvt<T>::from_f(w);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmParams& p, hipStream_t s) {
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch);
+    size_t lds = (size_t)2 * (BM + BN) * Frag<T>::LDS_ROW * sizeof(T);
+    hipLaunchKernelGGL((gemm_win_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+template <typename T>
+static int launch_T(const GemmParams& p, hipStream_t s) {
+    // shape validation the kernel relies on (16-byte chunk loads)
+    constexpr int CH = Frag<T>::CH;
+    MMX_CHECK_ARG(p.A && p.W && p.M > 0 && p.N > 0 && p.batch > 0 && p.ntaps >= 1);
+    MMX_CHECK_ARG(p.cin % CH == 0 && p.lda % CH == 0 && p.ldw % CH == 0);
+    MMX_CHECK_ARG(p.a_bstride % CH == 0 && p.w_bstride % CH == 0);
+    MMX_CHECK_ARG(p.ldw >= ((p.ntaps * p.cin + 31) / 32) * 32);
+    MMX_CHECK_ARG(p.bias_mod > 0 && p.alpha_mod > 0);
+    MMX_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0);
+    MMX_CHECK_ARG(p.out_f32 || p.out_act);
+    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
+    if (tiles128 >= 192 && p.N > 64) return launch_cfg<T, 128, 128, 2, 2>(p, s);
+    if (p.N <= 64 && (long)((p.M + 127) / 128) * p.batch >= 192) return launch_cfg<T, 128, 64, 4, 1>(p, s);
+    const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
+    if (tiles64 >= 128 || p.M > 32) return launch_cfg<T, 64, 64, 2, 2>(p, s);
+    return launch_cfg<T, 32, 64, 1, 4>(p, s);
+}
+
+extern "C" int mmx_gemm_win(const GemmParams* p, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(p != nullptr);
+    if (dtype == MMX_BF16) return launch_T<bf16_t>(*p, stream);
+    if (dtype == MMX_F32) return launch_T<float>(*p, stream);
+    return MMX_EARG;
+}

@@ -1,0 +1,377 @@
+// Autoregressive speech-token LM decode step (Qwen2-0.5B backbone) for gfx950.
+// At batch 1..64 every projection is a weight-streaming problem (727.6 MB of bf16 weights per token,
+// SURVEY.md §8d): weights are pre-packed in MFMA-fragment order so one wave-instruction reads a
+// contiguous 1 KiB straight into registers (no LDS round trip: cdna_hip_programming.md §5 "GEMV / M <= 16"),
+// the <= 64 activation rows ride the A operand of v_mfma_f32_16x16x32_bf16, K is split across the waves
+// of a workgroup and reduced through LDS (deterministic: no atomics), RMSNorm is folded into the
+// projection (its weight into Wp at pack time, 1/rms as a per-row scale computed from the same x loads).
+#include "common.h"
+#include "../../include/mmx_hip.h"
+
+// ------------------------------------------------------------------------------------------ pack
+// bf16: Wp[tile][kt][lane][8]  = W[row(tile, lane&15)][kt*32 + 8*(lane>>4) + j] * kscale[k]
+// fp32: Wp[tile][kc][lane][4]  = W[row(tile, lane&15)][kc*16 + 4*(lane>>4) + s] * kscale[k]
+// interleave_half (SwiGLU): N = 2I; packed tile 2t = gate rows 16t.., 2t+1 = up rows I+16t..
+template <typename T>
+__global__ void pack_skinny_kernel(const T* __restrict__ w, long ldw, int N, int K, const float* __restrict__ kscale,
+                                   int half, T* __restrict__ wp) {
+    constexpr int E = sizeof(T) == 2 ? 8 : 4;          // elements per lane per k block
+    constexpr int KB = E * 4;                          // k per block (32 / 16)
+    const long total = (long)((N + 15) / 16) * (K / KB) * 64 * E;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int j = idx % E;
+        long t = idx / E;
+        int lane = t % 64;
+        t /= 64;
+        int kb = t % (K / KB);
+        int tile = t / (K / KB);
+        int col = lane & 15, g = lane >> 4;
+        int row;
+        if (half > 0) row = (tile & 1) * half + (tile >> 1) * 16 + col;
+        else row = tile * 16 + col;
+        int kk = kb * KB + g * E + j;
+        float v = 0.f;
+        if (row < N && (half == 0 || ((tile >> 1) * 16 + col) < half)) {
+            v = Cvt<T>::to_f(w[(long)row * ldw + kk]);
+            if (kscale) v *= kscale[kk];
+        }
+        wp[idx] = Cvt<T>::from_f(v);
+    }
+}
+extern "C" int mmx_pack_skinny(const void* w, int64_t ldw, int N, int K, const float* kscale, int interleave_half,
+                               void* wp, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(w && wp && N > 0 && K > 0 && K % 32 == 0);
+    MMX_CHECK_ARG(interleave_half == 0 || (N == 2 * interleave_half && interleave_half % 16 == 0));
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(pack_skinny_kernel<bf16_t>, dim3(2048), dim3(256), 0, stream, (const bf16_t*)w, ldw, N, K, kscale, interleave_half, (bf16_t*)wp);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(pack_skinny_kernel<float>, dim3(2048), dim3(256), 0, stream, (const float*)w, ldw, N, K, kscale, interleave_half, (float*)wp);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ skinny GEMM
+// wave -> (output tile of 16 columns [x2 for SwiGLU], k slice); MT = row tiles of 16 (B <= 16*MT)
+template <typename T, typename TX, int MT, int EPI>
+__global__ void skinny_gemm_kernel(const TX* __restrict__ x, long ldx, int B, int K, int N,
+                                   const T* __restrict__ wp, const float* __restrict__ bias, int rs, float eps,
+                                   float* __restrict__ outf, long ldo_f, T* __restrict__ outa, long ldo_a,
+                                   int ksplit, int ntiles) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int E = BF ? 8 : 4;
+    constexpr int KB = E * 4;
+    constexpr int NB = EPI == 1 ? 2 : 1;               // B fragments per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);       // [waves][NB*MT*4 + MT] x 64 lanes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int tpb = nwaves / ksplit;
+    const int tile = blockIdx.x * tpb + wave / ksplit;
+    const int ksl = wave % ksplit;
+    const int nkb = K / KB;
+    const int kb_per = (nkb + ksplit - 1) / ksplit;
+    const int kb0 = ksl * kb_per, kb1 = min(nkb, kb0 + kb_per);
+    const bool active = tile < ntiles;
+
+    float4_t acc[NB][MT];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float ssq[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ssq[m] = 0.f;
+
+    if (active) {
+        const T* wbase = wp + ((long)tile * NB * nkb) * 64 * E + (long)lane * E;
+#pragma unroll 4
+        for (int kb = kb0; kb < kb1; ++kb) {
+            // weight fragments: contiguous 1 KiB (bf16) per wave-instruction
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+            u32x4_t wf[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                wf[n] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wbase + ((long)n * nkb + kb) * 64 * E));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int row = m * 16 + l16;
+                float xv[E];
+                if (row < B) {
+                    const TX* xp = x + (long)row * ldx + kb * KB + g * E;
+                    if constexpr (sizeof(TX) == 4) {
+#pragma unroll
+                        for (int e4 = 0; e4 < E / 4; ++e4) {
+                            float4 t4 = *reinterpret_cast<const float4*>(xp + e4 * 4);
+                            xv[e4 * 4 + 0] = t4.x; xv[e4 * 4 + 1] = t4.y; xv[e4 * 4 + 2] = t4.z; xv[e4 * 4 + 3] = t4.w;
+                        }
+                    } else {
+                        uint4 t4 = *reinterpret_cast<const uint4*>(xp);
+                        const bf16_t* hp = reinterpret_cast<const bf16_t*>(&t4);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) xv[e] = bf2f(hp[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xv[e] = 0.f;
+                }
+                if (rs) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) ssq[m] += xv[e] * xv[e];
+                }
+                if constexpr (BF) {
+                    short8_t af;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[e] = (short)f2bf(xv[e]);
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        short8_t bfr = *reinterpret_cast<const short8_t*>(&wf[n]);
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[n][m], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        float4_t bfr = *reinterpret_cast<const float4_t*>(&wf[n]);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], bfr[s], acc[n][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // sum of squares: reduce across the 4 k-groups of the wave (lanes l16, l16+16, +32, +48)
+    if (rs) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ssq[m] += __shfl_xor(ssq[m], 16, 64);
+            ssq[m] += __shfl_xor(ssq[m], 32, 64);
+        }
+    }
+    // cross-wave (k split) reduction through LDS, fixed order -> deterministic
+    constexpr int PER = NB * MT * 4 + MT;
+    if (ksplit > 1) {
+        float* mine = red + ((long)wave * PER) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[((n * MT + m) * 4 + r) * 64] = acc[n][m][r];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) mine[(NB * MT * 4 + m) * 64] = ssq[m];
+        __syncthreads();
+        if (ksl != 0) return;
+        for (int w2 = 1; w2 < ksplit; ++w2) {
+            const float* o = red + ((long)(wave + w2) * PER) * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[n][m][r] += o[((n * MT + m) * 4 + r) * 64];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) ssq[m] += o[(NB * MT * 4 + m) * 64];
+        }
+    }
+    if (!active) return;
+    // epilogue: acc rows are 4g + r, columns l16; ssq is held per A-row l16 -> fetch row 4g+r from lane 4g+r
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m * 16 + 4 * g + r;
+            float sc = 1.f;
+            if (rs) {
+                float sq = __shfl(ssq[m], 4 * g + r, 64);
+                sc = rsqrtf(sq / (float)K + eps);
+            }
+            if (row >= B) continue;
+            if constexpr (EPI == 1) {
+                const int n = tile * 16 + l16;
+                if (n < N) {
+                    float gte = acc[0][m][r] * sc, up = acc[1][m][r] * sc;
+                    float sl = gte / (1.f + expf(-gte));
+                    outa[(long)row * ldo_a + n] = Cvt<T>::from_f(sl * up);
+                }
+            } else {
+                const int n = tile * 16 + l16;
+                if (n < N) {
+                    float v = acc[0][m][r] * sc + (bias ? bias[n] : 0.f);
+                    if constexpr (EPI == 2) v += outf[(long)row * ldo_f + n];
+                    if (outf) outf[(long)row * ldo_f + n] = v;
+                    if (outa) outa[(long)row * ldo_a + n] = Cvt<T>::from_f(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TX, int EPI>
+static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, int rs,
+                            float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s) {
+    constexpr int KB = sizeof(T) == 2 ? 32 : 16;
+    const int ntiles = (N + 15) / 16;                  // for EPI==1, N is the activation width I
+    const int nkb = K / KB;
+    // choose the k split so that ~>= 256 waves stream weights and each wave keeps >= 4 k blocks
+    int ksplit = 1;
+    while (ksplit < 16 && (long)ntiles * ksplit < 512 && nkb / (ksplit * 2) >= 4) ksplit *= 2;
+    int waves = ksplit >= 4 ? ksplit : 4;
+    int tpb = waves / ksplit;
+    dim3 grid((ntiles + tpb - 1) / tpb), block(waves * 64);
+    const int mt = (B + 15) / 16;
+    constexpr int NB = EPI == 1 ? 2 : 1;
+    size_t lds = ksplit > 1 ? (size_t)waves * (NB * mt * 4 + mt) * 64 * 4 : 0;
+#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
+        bias, rs, eps, outf, ldo_f, (T*)outa, ldo_a, ksplit, ntiles)
+    switch (mt) {
+        case 1: SK(1); break;
+        case 2: SK(2); break;
+        case 3: SK(3); break;
+        case 4: SK(4); break;
+        default: return MMX_EARG;
+    }
+#undef SK
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+template <typename T, typename TX>
+static int skinny_launch_epi(int epi, const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias,
+                             int rs, float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s) {
+    if (epi == 0) return skinny_launch_mt<T, TX, 0>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    if (epi == 1) return skinny_launch_mt<T, TX, 1>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    if (epi == 2) return skinny_launch_mt<T, TX, 2>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    return MMX_EARG;
+}
+extern "C" int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N, const void* wp,
+                               const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
+                               void* out_act, int64_t ldo_a, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(x && wp && B > 0 && B <= 64 && K > 0 && K % 32 == 0 && N > 0);
+    MMX_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0);
+    MMX_CHECK_ARG(epi == 1 ? out_act != nullptr : (out_f32 != nullptr || (epi == 0 && out_act != nullptr)));
+    MMX_CHECK_ARG(epi != 2 || out_f32 != nullptr);
+    if (dtype == MMX_BF16) {
+        if (x_dtype == MMX_F32) return skinny_launch_epi<bf16_t, float>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
+        if (x_dtype == MMX_BF16) return skinny_launch_epi<bf16_t, bf16_t>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
+    } else if (dtype == MMX_F32 && x_dtype == MMX_F32) {
+        return skinny_launch_epi<float, float>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
+    }
+    return MMX_EARG;
+}
+
+// ------------------------------------------------------------------------------------------ RoPE + paged KV append
+template <typename T>
+__global__ void rope_kv_kernel(const float* __restrict__ qkv, long ldqkv, long qkv_bs, int Hq, int Hkv,
+                               const float* __restrict__ inv_freq, const int32_t* __restrict__ pos,
+                               T* __restrict__ q_out, long ldq, long q_bs, T* __restrict__ kc, T* __restrict__ vc,
+                               const int32_t* __restrict__ block_table, int max_pages, int page) {
+    constexpr int D = 64, HALF = 32;
+    const int b = blockIdx.y, t = blockIdx.x;
+    const int p = pos[b] + t;
+    const float* src = qkv + (long)b * qkv_bs + (long)t * ldqkv;
+    const int nh = Hq + 2 * Hkv;
+    const int phys = block_table[(long)b * max_pages + p / page];
+    const int slot = p % page;
+    for (int i = threadIdx.x; i < nh * HALF; i += blockDim.x) {
+        const int hh = i / HALF, d = i % HALF;
+        const float x0 = src[hh * D + d], x1 = src[hh * D + d + HALF];
+        float y0 = x0, y1 = x1;
+        if (hh < Hq + Hkv) {                            // q and k heads are rotated, v is not
+            const float ang = (float)p * inv_freq[d];
+            const float c = cosf(ang), s = sinf(ang);
+            y0 = x0 * c - x1 * s;
+            y1 = x1 * c + x0 * s;
+        }
+        if (hh < Hq) {
+            T* o = q_out + (long)b * q_bs + (long)t * ldq + hh * D;
+            o[d] = Cvt<T>::from_f(y0);
+            o[d + HALF] = Cvt<T>::from_f(y1);
+        } else {
+            const int hk = (hh - Hq) % Hkv;
+            T* base = (hh < Hq + Hkv ? kc : vc) + (((long)phys * Hkv + hk) * page + slot) * D;
+            base[d] = Cvt<T>::from_f(y0);
+            base[d + HALF] = Cvt<T>::from_f(y1);
+        }
+    }
+}
+extern "C" int mmx_rope_kv_store(const float* qkv, int64_t ldqkv, int64_t qkv_bs, int B, int rows, int Hq, int Hkv, int D,
+                                 const float* inv_freq, const int32_t* pos, void* q_out, int64_t ldq, int64_t q_bs,
+                                 void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
+                                 int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(qkv && inv_freq && pos && q_out && kc && vc && block_table && B > 0 && rows > 0 && D == 64 && page > 0);
+    dim3 grid(rows, B);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(rope_kv_kernel<bf16_t>, grid, dim3(256), 0, stream, qkv, ldqkv, qkv_bs, Hq, Hkv, inv_freq, pos, (bf16_t*)q_out, ldq, q_bs, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, page);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(rope_kv_kernel<float>, grid, dim3(256), 0, stream, qkv, ldqkv, qkv_bs, Hq, Hkv, inv_freq, pos, (float*)q_out, ldq, q_bs, (float*)kc, (float*)vc, block_table, max_pages, page);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ paged causal GQA attention
+template <typename T>
+__global__ __launch_bounds__(256) void paged_attn_kernel(
+    const T* __restrict__ q, long ldq, long q_bs, int Hq, int Hkv, float scale, const int32_t* __restrict__ pos,
+    const T* __restrict__ kc, const T* __restrict__ vc, const int32_t* __restrict__ block_table, int max_pages,
+    int page, T* __restrict__ out, long ldo, long o_bs) {
+    constexpr int D = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);        // [D]
+    float* red = qs + D;                               // [8 + 4*D]
+    float* S = red + 8 + 4 * D;                        // [ctx]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, t = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (Hq / Hkv);
+    const int ctx = pos[b] + t + 1;
+    const int32_t* bt = block_table + (long)b * max_pages;
+    if (tid < D) qs[tid] = Cvt<T>::to_f(q[(long)b * q_bs + (long)t * ldq + h * D + tid]);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < ctx; j += 256) {
+        const T* kp = kc + (((long)bt[j / page] * Hkv + hk) * page + j % page) * D;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s += qs[d] * Cvt<T>::to_f(kp[d]);
+        s *= scale;
+        S[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int j = tid; j < ctx; j += 256) {
+        float e = expf(S[j] - mx);
+        S[j] = e;
+        l += e;
+    }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+    // PV: thread -> (d = lane, key partition = wave)
+    float acc = 0.f;
+    for (int j = wave; j < ctx; j += 4) {
+        const T* vp = vc + (((long)bt[j / page] * Hkv + hk) * page + j % page) * D;
+        acc += S[j] * Cvt<T>::to_f(vp[lane]);
+    }
+    red[8 + wave * D + lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        float o = (red[8 + lane] + red[8 + D + lane]) + (red[8 + 2 * D + lane] + red[8 + 3 * D + lane]);
+        out[(long)b * o_bs + (long)t * ldo + h * D + lane] = Cvt<T>::from_f(o / l);
+    }
+}
+extern "C" int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, int Hq, int Hkv, int D, float scale,
+                              const int32_t* pos, const void* kc, const void* vc, const int32_t* block_table, int max_pages,
+                              int page, void* out, int64_t ldo, int64_t o_bs, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(q && pos && kc && vc && block_table && out && B > 0 && rows > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
+    const size_t max_ctx = (size_t)max_pages * page;
+    size_t lds = (64 + 8 + 4 * 64 + max_ctx) * 4;
+    MMX_CHECK_ARG(lds <= 160 * 1024);
+    dim3 grid(Hq, rows, B);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(paged_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, ldq, q_bs, Hq, Hkv, scale, pos, (const bf16_t*)kc, (const bf16_t*)vc, block_table, max_pages, page, (bf16_t*)out, ldo, o_bs);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(paged_attn_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, ldq, q_bs, Hq, Hkv, scale, pos, (const float*)kc, (const float*)vc, block_table, max_pages, page, (float*)out, ldo, o_bs);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}

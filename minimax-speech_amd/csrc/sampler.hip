@@ -1,0 +1,201 @@
+// Device-resident token sampler + AR-loop bookkeeping: one workgroup per sequence, no host round trip
+// per token (the reference pays one .item() sync per token, llm.py:752).  Restates
+//   llm.py:751        logp = log_softmax(logits)
+//   common.py:111-139 ras_sampling -> nucleus_sampling (softmax, stable sort desc, cum < top_p, n < top_k,
+//                     multinomial) and random_sampling on repetition within the last win_size tokens
+//   llm.py:259-274    sampling_ids: re-draw (<= 100 trials) while EOS is drawn and ignore_eos
+//   llm.py:753-760    EOS stops; ids > EOS are skipped WITHOUT updating lm_input; otherwise append + embed
+// torch.multinomial(p,1) == argmax(p / e), e ~ Exp(1): the draws come from Philox4x32-10 exactly as
+// oracle/philox.py defines them, so the CPU oracle and this kernel consume identical noise.
+#include "common.h"
+#include "../../include/mmx_hip.h"
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float exp_noise(unsigned long long seed, unsigned seq, unsigned step, unsigned trial, unsigned which,
+                                           unsigned i) {
+    unsigned w[4];
+    philox4x32_10(i >> 2, 2u * trial + which, step, seq, (unsigned)seed, (unsigned)(seed >> 32), w);
+    const float u = ((float)(w[i & 3] >> 8) + 0.5f) * 5.9604644775390625e-08f;   // 2^-24
+    return -logf(u);
+}
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {     // larger value, then smaller index (stable sort order)
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax x, ArgMax* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax y;
+        y.v = __shfl_xor(x.v, o, 64);
+        y.i = __shfl_xor(x.i, o, 64);
+        x = better(x, y);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    ArgMax r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = better(r, sh[w]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sh[w]);
+    return r;
+}
+
+constexpr int SAMP_THREADS = 256;
+constexpr int SAMP_MAXV = 32;        // V <= 8192
+constexpr int SAMP_MAXK = 64;
+
+__global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
+    const float* __restrict__ logits, long ldl, int V, int eos_id, int top_k, float top_p, int win_size, float tau_r,
+    unsigned long long seed, int32_t* __restrict__ state, int32_t* __restrict__ out_tokens, int max_out,
+    int32_t* __restrict__ sampled, const int32_t* __restrict__ forced, const float* __restrict__ speech_emb, int E,
+    float* __restrict__ next_x, long ldx, float* __restrict__ logp_out) {
+    __shared__ float shf[8];
+    __shared__ ArgMax sha[8];
+    __shared__ float cand_p[SAMP_MAXK];
+    __shared__ int cand_i[SAMP_MAXK];
+    __shared__ int sh_n, sh_top;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int32_t* st = state + b * 8;
+    const int pos = st[0], step = st[1], n_out = st[2], finished = st[3], min_len = st[4], seq = st[6];
+    if (finished) return;                              // uniform per block
+    const float* lg = logits + (long)b * ldl;
+
+    // log_softmax, then softmax of it (the reference's two stages, common.py:122)
+    float x[SAMP_MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SAMP_MAXV; ++i) {
+        int idx = tid + i * SAMP_THREADS;
+        x[i] = idx < V ? lg[idx] : -INFINITY;
+        mx = fmaxf(mx, x[i]);
+    }
+    mx = block_max(mx, shf);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMP_MAXV; ++i) se += (tid + i * SAMP_THREADS < V) ? expf(x[i] - mx) : 0.f;
+    se = block_sum(se, shf);
+    const float lse = logf(se);
+    float mx2 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SAMP_MAXV; ++i) {
+        int idx = tid + i * SAMP_THREADS;
+        if (idx < V) {
+            x[i] = (x[i] - mx) - lse;                  // logp
+            if (logp_out) logp_out[(long)b * V + idx] = x[i];
+            mx2 = fmaxf(mx2, x[i]);
+        }
+    }
+    mx2 = block_max(mx2, shf);
+    float se2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMP_MAXV; ++i) {
+        int idx = tid + i * SAMP_THREADS;
+        x[i] = idx < V ? expf(x[i] - mx2) : -1.f;      // unnormalised p (padding -1 never wins)
+        se2 += idx < V ? x[i] : 0.f;
+    }
+    se2 = block_sum(se2, shf);
+#pragma unroll
+    for (int i = 0; i < SAMP_MAXV; ++i)
+        if (tid + i * SAMP_THREADS < V) x[i] = x[i] / se2;   // p
+
+    // nucleus candidates: repeated block arg-max == stable descending sort prefix
+    float p_work[SAMP_MAXV];
+#pragma unroll
+    for (int i = 0; i < SAMP_MAXV; ++i) p_work[i] = x[i];
+    float cum = 0.f;
+    int nc = 0;
+    while (cum < top_p && nc < top_k) {
+        ArgMax a{-2.f, 0x7fffffff};
+#pragma unroll
+        for (int i = 0; i < SAMP_MAXV; ++i) a = better(a, ArgMax{p_work[i], tid + i * SAMP_THREADS});
+        a = block_argmax(a, sha);
+        if (tid == 0) { cand_p[nc] = a.v; cand_i[nc] = a.i; }
+#pragma unroll
+        for (int i = 0; i < SAMP_MAXV; ++i)
+            if (tid + i * SAMP_THREADS == a.i) p_work[i] = -1.f;
+        cum += a.v;                                    // fp32 running sum, same order as common.py:127
+        nc++;
+    }
+    __syncthreads();
+
+    const bool ignore_eos = step < min_len;
+    int top = 0;
+    for (int trial = 0;; ++trial) {
+        // nucleus draw: argmax_i cand_p[i] / e_i
+        ArgMax a{-1.f, 0x7fffffff};
+        if (tid < nc) a = ArgMax{cand_p[tid] / exp_noise(seed, seq, step, trial, 0, tid), tid};
+        a = block_argmax(a, sha);
+        top = cand_i[a.i];
+        // repetition-aware fallback (common.py:113-115)
+        int rep = 0;
+        for (int j = max(0, n_out - win_size); j < n_out; ++j) rep += out_tokens[(long)b * max_out + j] == top;
+        if ((float)rep >= (float)win_size * tau_r) {
+            ArgMax r{-1.f, 0x7fffffff};
+#pragma unroll
+            for (int i = 0; i < SAMP_MAXV; ++i) {
+                int idx = tid + i * SAMP_THREADS;
+                if (idx < V) r = better(r, ArgMax{x[i] / exp_noise(seed, seq, step, trial, 1, idx), idx});
+            }
+            r = block_argmax(r, sha);
+            top = r.i;
+        }
+        if (!ignore_eos || top != eos_id) break;
+        if (trial >= 100) { if (tid == 0) st[7] = 1; break; }    // llm.py:271-273 raises here; flag + accept
+    }
+    if (tid == 0) {
+        if (sampled) sampled[(long)b * max_out + step] = top;
+        if (forced) top = forced[(long)b * max_out + step];
+        sh_top = top;
+    }
+    __syncthreads();
+    top = sh_top;
+    if (top == eos_id) {
+        if (tid == 0) { st[3] = 1; st[1] = step + 1; }
+        return;
+    }
+    if (top < eos_id) {
+        for (int c = tid; c < E; c += SAMP_THREADS) next_x[(long)b * ldx + c] = speech_emb[(long)top * E + c];
+        if (tid == 0) { out_tokens[(long)b * max_out + n_out] = top; st[2] = n_out + 1; }
+    }
+    if (tid == 0) { st[0] = pos + 1; st[1] = step + 1; }
+}
+
+extern "C" int mmx_sample_step(const float* logits, int64_t ldl, int V, int B, int eos_id, int top_k, float top_p,
+                               int win_size, float tau_r, uint64_t seed, int32_t* state, int32_t* out_tokens, int max_out,
+                               int32_t* sampled, const int32_t* forced, const float* speech_emb, int E, float* next_x,
+                               int64_t ldx, float* logp_out, hipStream_t stream) {
+    MMX_CHECK_ARG(logits && state && out_tokens && speech_emb && next_x && B > 0 && V > 0 && V <= SAMP_THREADS * SAMP_MAXV);
+    MMX_CHECK_ARG(top_k > 0 && top_k <= SAMP_MAXK && max_out > 0 && E > 0 && eos_id < V);
+    hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(SAMP_THREADS), 0, stream, logits, ldl, V, eos_id, top_k, top_p, win_size,
+                       tau_r, (unsigned long long)seed, state, out_tokens, max_out, sampled, forced, speech_emb, E, next_x, ldx, logp_out);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}

@@ -1,0 +1,102 @@
+"""ctypes binding of libmmx_hip.so (include/mmx_hip.h).  Thin: tensors in, raw pointers out."""
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, "lrelu": 1, "gelu": 2, "silu": 3, "mish": 4, "tanh": 5}
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+ESIZE = {F32: 4, BF16: 2}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")
+
+SYMBOLS = [
+    "mmx_abi_version", "mmx_gemm_win", "mmx_rownorm", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
+    "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_conv_cout1_tanh",
+    "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_swiglu", "mmx_sample_step",
+]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("rowmask", C.c_void_p), ("alpha", C.c_void_p), ("out_f32", C.c_void_p), ("out_act", C.c_void_p),
+        ("lda", C.c_int64), ("ldw", C.c_int64), ("ldr", C.c_int64), ("ldo_f", C.c_int64), ("ldo_a", C.c_int64),
+        ("a_bstride", C.c_int64), ("w_bstride", C.c_int64), ("r_bstride", C.c_int64), ("rm_bstride", C.c_int64),
+        ("of_bstride", C.c_int64), ("oa_bstride", C.c_int64),
+        ("row_off", C.c_int64), ("row_lo", C.c_int64), ("row_hi", C.c_int64),
+        ("out_off", C.c_int64), ("out_len", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("batch", C.c_int32),
+        ("ntaps", C.c_int32), ("cin", C.c_int32), ("dil", C.c_int32),
+        ("bias_mod", C.c_int32), ("alpha_mod", C.c_int32), ("bias_per_row", C.c_int32),
+        ("act", C.c_int32), ("act2", C.c_int32), ("slope", C.c_float),
+    ]
+
+
+_lib = None
+
+
+class MmxError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (fails loudly: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MmxError(f"{LIB_PATH} not found: build it with `make -C minimax-speech_amd/csrc` "
+                           "(or __graft_entry__.build()); the hot path has no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(_lib, s).restype = C.c_int
+    return _lib
+
+
+def _p(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    assert t.is_cuda, "libmmx_hip works on device memory only (no CPU fallback)"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MmxError(f"{what} failed with code {rc}" + (" (argument/shape error)" if rc == -1 else ""))
+
+
+def dt_of(t):
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def i64(x):
+    return C.c_int64(int(x))
+
+
+def gemm_params(**kw):
+    p = GemmParams()
+    p.bias_mod = 1
+    p.alpha_mod = 1
+    p.ntaps = 1
+    p.dil = 1
+    p.batch = 1
+    p.row_lo = 0
+    p.out_len = 1 << 62
+    p.slope = 0.1
+    for k, v in kw.items():
+        if k in ("A", "W", "bias", "residual", "rowmask", "alpha", "out_f32", "out_act"):
+            v = None if v is None else (v if isinstance(v, int) else v.data_ptr())
+        setattr(p, k, v)
+    return p
+
+
+def gemm_win(p, dtype):
+    check(load().mmx_gemm_win(C.byref(p), C.c_int(dtype), stream()), "mmx_gemm_win")

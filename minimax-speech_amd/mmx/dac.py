@@ -1,0 +1,105 @@
+"""DAC-VAE decoder engine: latents [B, D, T] -> 24 kHz waveform [B, 1, T*hop] on libmmx_hip kernels.
+
+Reference op sequence: dac-vae/model.py:485-488 (DACVAE.decode), :326-379 (Decoder), :237-323 (DecoderBlock),
+:107-143 (ResidualUnit), :509-514 (every Conv1d is followed by LeakyReLU(0.1)), layers.py:18-24 (Snake).
+
+Mapping: every Conv1d / ConvTranspose1d is ONE windowed-GEMM launch (csrc/gemm.hip) on time-major
+activations, with bias, LeakyReLU, the residual add and the NEXT layer's Snake fused into its epilogue;
+the fp32 residual stream x and the compute-dtype activation snake(x) are the only tensors that touch HBM.
+37 convs -> 37 launches + 1 transpose + 1 tail kernel.  Weight norm (w = g*v/||v||) is folded at load.
+"""
+import math
+from typing import Dict, List
+
+import torch
+
+from . import ops
+from ._lib import BF16, F32, TORCH_DT
+
+
+class DacDecoderEngine:
+    def __init__(self, sd: Dict[str, torch.Tensor], rates: List[int], dtype=BF16, device="cuda", use_tanh=True):
+        self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.rates = list(rates)
+        self.hop = int(math.prod(rates))
+        self.use_tanh = use_tanh
+        f = lambda k: sd[k].detach().to(self.dev, torch.float32)
+        wn = lambda p: ops.fold_weight_norm(f(p + ".weight_g"), f(p + ".weight_v"))
+        bias = lambda p: f(p + ".bias").contiguous() if (p + ".bias") in sd else None
+        alpha = lambda k: f(k).reshape(-1).contiguous()
+        self.D = sd["de_conv_pre.0.weight_v"].shape[1]
+        self.w_pre = ops.pack_conv1d(wn("de_conv_pre.0"), dtype)
+        self.b_pre = bias("de_conv_pre.0")
+        p = "decoder.model"
+        self.C0 = sd[p + ".0.0.weight_v"].shape[0]
+        self.w0 = ops.pack_conv1d(wn(p + ".0.0"), dtype)
+        self.b0 = bias(p + ".0.0")
+        self.blocks = []
+        n = len(rates)
+        for i, s in enumerate(rates):
+            q = f"{p}.{1 + i}.block"
+            wt = wn(q + ".1")                                   # [Cin, Cout, 2s]
+            blk = dict(stride=s, cin=wt.shape[0], cout=wt.shape[1], alpha_in=alpha(q + ".0.alpha"),
+                       wt=ops.pack_convtranspose1d(wt, s, dtype), bt=bias(q + ".1"), rus=[])
+            for j, d in enumerate((1, 3, 9)):
+                r = f"{q}.{2 + j}.block"
+                blk["rus"].append(dict(dil=d, a0=alpha(r + ".0.alpha"), w7=ops.pack_conv1d(wn(r + ".1.0"), dtype),
+                                       b7=bias(r + ".1.0"), a2=alpha(r + ".2.alpha"),
+                                       w1=ops.pack_conv1d(wn(r + ".3.0"), dtype), b1=bias(r + ".3.0")))
+            self.blocks.append(blk)
+        self.alpha_final = alpha(f"{p}.{n + 1}.alpha")
+        wf = wn(f"{p}.{n + 2}.0")                                # [1, C, 7]
+        assert wf.shape[0] == 1, "d_out != 1 is outside the hot path (configx2.yml: d_out 1)"
+        self.k_final = wf.shape[2]
+        self.w_final = wf[0].t().contiguous()                    # [k][C] fp32
+        self.b_final = bias(f"{p}.{n + 2}.0")
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """z [B, D, T] fp32 cuda -> [B, 1, T*hop] fp32 (reference layout)."""
+        assert z.is_cuda and z.dtype == torch.float32 and z.dim() == 3 and z.shape[1] == self.D
+        B, D, T = z.shape
+        z = z.contiguous()
+        zt = torch.empty(B, T, D, dtype=self.tdt, device=self.dev)
+        ops.copy2d(z, F32, D * T, 1, T, zt, self.dtype, T * D, D, 1, rows=T, cols=D, batch=B)
+        return self.decode_time_major(zt, B, T)
+
+    @torch.no_grad()
+    def decode_time_major(self, zt: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """zt [B, T, D] in the compute dtype (what the flow engine hands over)."""
+        dt, tdt, dev = self.dtype, self.tdt, self.dev
+        new = lambda t, c, d=None: torch.empty(B, t, c, dtype=(d or tdt), device=dev)
+        h = new(T, self.D)
+        ops.conv1d(zt, self.w_pre, T=T, Cin=self.D, k=1, dtype=dt, batch=B, bias=self.b_pre, act="lrelu", out_act=h)
+        a = new(T, self.C0)
+        ops.conv1d(h, self.w0, T=T, Cin=self.D, k=7, pad_left=3, dtype=dt, batch=B, bias=self.b0, act="lrelu",
+                   alpha=self.blocks[0]["alpha_in"], out_act=a)
+        for bi, blk in enumerate(self.blocks):
+            s, cin, cout = blk["stride"], blk["cin"], blk["cout"]
+            T2 = T * s
+            x = new(T2, cout, torch.float32)
+            a2 = new(T2, cout)
+            ops.convtranspose1d(a, blk["wt"], T=T, Cin=cin, Cout=cout, stride=s, dtype=dt, batch=B, bias=blk["bt"],
+                                alpha=blk["rus"][0]["a0"], out_f32=x, out_act=a2)
+            T, a = T2, a2
+            for j, ru in enumerate(blk["rus"]):
+                d = ru["dil"]
+                hmid = new(T, cout)
+                ops.conv1d(a, ru["w7"], T=T, Cin=cout, k=7, dil=d, pad_left=3 * d, dtype=dt, batch=B, bias=ru["b7"],
+                           act="lrelu", alpha=ru["a2"], out_act=hmid)
+                last = j == 2
+                if not last:
+                    nxt = blk["rus"][j + 1]["a0"]
+                elif bi + 1 < len(self.blocks):
+                    nxt = self.blocks[bi + 1]["alpha_in"]
+                else:
+                    nxt = self.alpha_final
+                x2 = None if last else new(T, cout, torch.float32)
+                a3 = new(T, cout)
+                ops.conv1d(hmid, ru["w1"], T=T, Cin=cout, k=1, dtype=dt, batch=B, bias=ru["b1"], act="lrelu",
+                           residual=x, alpha=nxt, out_f32=x2, out_act=a3)
+                x, a = x2, a3
+        wav = torch.empty(B, 1, T, dtype=torch.float32, device=dev)
+        ops.conv_cout1_tanh(a, self.w_final, self.b_final, wav, T=T, C_=self.blocks[-1]["cout"], k=self.k_final,
+                            batch=B, dtype=dt, use_tanh=self.use_tanh)
+        return wav

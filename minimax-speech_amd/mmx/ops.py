@@ -1,0 +1,203 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point) + weight packing helpers.
+
+Layout convention: activations are time-major [B, T, C] contiguous tensors; "act" tensors have the
+compute dtype (bf16 or fp32), residual streams are fp32.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT, BF16, F32, check, i64, load, stream, _p
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- weight packing (load time)
+def pack_linear(w: torch.Tensor, dtype) -> torch.Tensor:
+    """[N, K] -> [N, Kpad] (K contiguous, zero padded to a multiple of 32) in the compute dtype."""
+    N, K = w.shape
+    out = torch.zeros(N, round_up(K, 32), dtype=L.TORCH_DT[dtype], device=w.device)
+    out[:, :K] = w
+    return out
+
+
+def pack_conv1d(w: torch.Tensor, dtype) -> torch.Tensor:
+    """Conv1d weight [Cout, Cin, k] -> GEMM weight [Cout, k*Cin] (tap-major, then channel)."""
+    Cout, Cin, k = w.shape
+    return pack_linear(w.permute(0, 2, 1).reshape(Cout, k * Cin), dtype)
+
+
+def pack_convtranspose1d(w: torch.Tensor, stride: int, dtype) -> torch.Tensor:
+    """ConvTranspose1d weight [Cin, Cout, 2s] -> [s*Cout, 2*Cin]: row (k0, co); column tap*Cin + ci with
+    tap 0 multiplying x[q-1] (kernel index k0 + s) and tap 1 multiplying x[q] (kernel index k0)."""
+    Cin, Cout, k = w.shape
+    s = stride
+    assert k == 2 * s
+    wk = w.permute(2, 1, 0)                      # [k, Cout, Cin]
+    tap0 = wk[s:2 * s]                           # [s, Cout, Cin]
+    tap1 = wk[0:s]
+    g = torch.cat([tap0, tap1], dim=2)           # [s, Cout, 2*Cin]
+    return pack_linear(g.reshape(s * Cout, 2 * Cin), dtype)
+
+
+def fold_weight_norm(g, v):
+    n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+    return g * (v / n)
+
+
+# ----------------------------------------------------------------------------- GEMM family
+def gemm(A, W, M, N, *, dtype, lda=None, cin=None, ntaps=1, dil=1, row_off=0, row_lo=0, row_hi=None, batch=1,
+         a_bstride=0, w_bstride=0, bias=None, bias_mod=None, bias_per_row=False, act="none", act2="none", slope=0.1,
+         residual=None, ldr=0, r_bstride=0, rowmask=None, rm_bstride=0, alpha=None, alpha_mod=None,
+         out_f32=None, ldo_f=0, of_bstride=0, out_act=None, ldo_a=0, oa_bstride=0, out_off=0, out_len=None):
+    """Launches mmx_gemm_win. A/W/out_* may be tensors or raw device addresses (ints)."""
+    ldw = W.shape[-1] if hasattr(W, "shape") else None
+    assert ldw is not None
+    p = L.gemm_params(A=A, W=W, bias=bias, residual=residual, rowmask=rowmask, alpha=alpha, out_f32=out_f32,
+                      out_act=out_act, lda=lda, ldw=ldw, ldr=ldr, ldo_f=ldo_f, ldo_a=ldo_a,
+                      a_bstride=a_bstride, w_bstride=w_bstride, r_bstride=r_bstride, rm_bstride=rm_bstride,
+                      of_bstride=of_bstride, oa_bstride=oa_bstride, row_off=row_off, row_lo=row_lo,
+                      row_hi=(row_hi if row_hi is not None else (1 << 40)), out_off=out_off,
+                      out_len=(out_len if out_len is not None else (1 << 62)), M=M, N=N, batch=batch,
+                      ntaps=ntaps, cin=cin, dil=dil, bias_mod=(bias_mod or N), alpha_mod=(alpha_mod or N),
+                      bias_per_row=int(bias_per_row), act=ACT[act], act2=ACT[act2], slope=slope)
+    L.gemm_win(p, dtype)
+
+
+def linear(x, Wp, K, *, dtype, bias=None, act="none", act2="none", residual=None, rowmask=None, out_f32=None,
+           out_act=None):
+    """x: act tensor [..., K] (contiguous rows); Wp packed [N, Kpad]. Outputs are [..., N] tensors."""
+    N = Wp.shape[0]
+    M = x.numel() // x.shape[-1]
+    gemm(x, Wp, M, N, dtype=dtype, lda=x.shape[-1], cin=K, bias=bias, act=act, act2=act2,
+         residual=residual, ldr=N, rowmask=rowmask, out_f32=out_f32, ldo_f=N, out_act=out_act, ldo_a=N)
+
+
+def conv1d(x, Wp, *, T, Cin, k, dtype, dil=1, pad_left=0, batch=1, bias=None, act="none", slope=0.1, residual=None,
+           rowmask=None, alpha=None, out_f32=None, out_act=None, T_out=None, act2="none"):
+    """Stride-1 Conv1d over time-major x [B, T, Cin] -> [B, T_out, Cout]; zero padding is virtual."""
+    Cout = Wp.shape[0]
+    T_out = T if T_out is None else T_out
+    gemm(x, Wp, T_out, Cout, dtype=dtype, lda=Cin, cin=Cin, ntaps=k, dil=dil, row_off=-pad_left, row_lo=0, row_hi=T,
+         batch=batch, a_bstride=T * Cin, bias=bias, act=act, act2=act2, slope=slope,
+         residual=residual, ldr=Cout, r_bstride=T_out * Cout, rowmask=rowmask, rm_bstride=T_out,
+         alpha=alpha, out_f32=out_f32, ldo_f=Cout, of_bstride=T_out * Cout,
+         out_act=out_act, ldo_a=Cout, oa_bstride=T_out * Cout)
+
+
+def convtranspose1d(x, Wp, *, T, Cin, Cout, stride, dtype, batch=1, bias=None, alpha=None, out_f32=None, out_act=None):
+    """ConvTranspose1d(kernel 2s, stride s, padding ceil(s/2), output_padding s%2): [B,T,Cin] -> [B,T*s,Cout]."""
+    s = stride
+    pad = math.ceil(s / 2)
+    gemm(x, Wp, T + 1, s * Cout, dtype=dtype, lda=Cin, cin=Cin, ntaps=2, dil=1, row_off=-1, row_lo=0, row_hi=T,
+         batch=batch, a_bstride=T * Cin, bias=bias, bias_mod=Cout, alpha=alpha, alpha_mod=Cout,
+         out_f32=out_f32, ldo_f=s * Cout, of_bstride=T * s * Cout, out_act=out_act, ldo_a=s * Cout,
+         oa_bstride=T * s * Cout, out_off=-pad * Cout, out_len=T * s * Cout)
+
+
+# ----------------------------------------------------------------------------- row-wise / elementwise
+def rownorm(x, gamma, beta, eps, *, rows, C_, batch=1, x_bstride=None, rms=False, act="none", rowmask=None,
+            addvec=None, out_f32=None, out_act=None, dtype=F32, ldx=None):
+    ldx = C_ if ldx is None else ldx
+    xb = rows * ldx if x_bstride is None else x_bstride
+    check(load().mmx_rownorm(_p(x), i64(ldx), i64(xb), rows, C_, batch, _p(gamma), _p(beta), C.c_float(eps), int(rms),
+                             ACT[act], _p(rowmask), i64(rows), _p(addvec), i64(C_),
+                             _p(out_f32), i64(C_), i64(rows * C_), _p(out_act), i64(C_), i64(rows * C_),
+                             dtype, stream()), "mmx_rownorm")
+
+
+def gather_rows(ids, table, *, scale=1.0, rowmask=None, out_f32=None, out_act=None, dtype=F32):
+    n, C_ = ids.numel(), table.shape[1]
+    check(load().mmx_gather_rows(_p(ids), n, _p(table), C_, C.c_float(scale), _p(rowmask), _p(out_f32), i64(C_),
+                                 _p(out_act), i64(C_), dtype, stream()), "mmx_gather_rows")
+
+
+def copy2d(src, src_dt, ibs, irs, ics, dst, dst_dt, obs, ors, ocs, rows, cols, batch=1, rep=1):
+    check(load().mmx_copy2d(_p(src), src_dt, i64(ibs), i64(irs), i64(ics), rep, _p(dst), dst_dt, i64(obs), i64(ors),
+                            i64(ocs), rows, cols, batch, stream()), "mmx_copy2d")
+
+
+def est_pack(x, mu, spks, cond, h, *, B, T, dtype):
+    check(load().mmx_est_pack(_p(x), _p(mu), _p(spks), _p(cond), B, T, 80, _p(h), i64(h.shape[-1]), dtype, stream()),
+          "mmx_est_pack")
+
+
+def sinusoidal_emb(t, out, *, dim, dtype, scale=1000.0):
+    check(load().mmx_sinusoidal_emb(_p(t), t.numel(), dim, C.c_float(scale), _p(out), dtype, stream()),
+          "mmx_sinusoidal_emb")
+
+
+def cfg_euler(x, d_cond, d_uncond, cfg, dt, n):
+    check(load().mmx_cfg_euler(_p(x), _p(d_cond), _p(d_uncond), C.c_float(cfg), C.c_float(dt), i64(n), stream()),
+          "mmx_cfg_euler")
+
+
+def conv_cout1_tanh(act, w, bias, out, *, T, C_, k, batch, dtype, slope=0.1, use_tanh=True):
+    check(load().mmx_conv_cout1_tanh(_p(act), i64(T * C_), T, C_, k, _p(w), _p(bias), C.c_float(slope), int(use_tanh),
+                                     _p(out), i64(T), batch, dtype, stream()), "mmx_conv_cout1_tanh")
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_dense(q, k, v, out, *, B, H, Tq, Tk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, dtype,
+               keymask=None, chunk=0, pos=None, ldp=0, pos_u=None, pos_v=None):
+    check(load().mmx_attn_dense(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(v), i64(ldv), i64(v_bs),
+                                _p(out), i64(ldo), i64(o_bs), B, H, 64, Tq, Tk, C.c_float(scale), _p(keymask),
+                                i64(Tk), chunk, _p(pos), i64(ldp), _p(pos_u), _p(pos_v), dtype, stream()),
+          "mmx_attn_dense")
+
+
+def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, keymask=None,
+                    chunk=0):
+    check(load().mmx_attn_flash_bf16(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(vt), i64(ldvt),
+                                     i64(vt_bs), _p(out), i64(ldo), i64(o_bs), B, H, T, C.c_float(scale),
+                                     _p(keymask), i64(T), chunk, stream()), "mmx_attn_flash_bf16")
+
+
+# ----------------------------------------------------------------------------- LM decode
+def pack_skinny(w, *, dtype, kscale=None, interleave_half=0):
+    """w: [N, K] tensor in the compute dtype -> MFMA-fragment-ordered copy (see csrc/llm.hip)."""
+    N, K = w.shape
+    KB = 32 if dtype == BF16 else 16
+    tiles = (N + 15) // 16
+    wp = torch.empty(tiles * (K // KB) * 64 * (KB // 4), dtype=L.TORCH_DT[dtype], device=w.device)
+    check(load().mmx_pack_skinny(_p(w), i64(w.stride(0)), N, K, _p(kscale), interleave_half, _p(wp), dtype, stream()),
+          "mmx_pack_skinny")
+    return wp
+
+
+def skinny_gemm(x, wp, *, B, K, N, dtype, bias=None, rs=False, eps=1e-6, epi=0, out_f32=None, out_act=None,
+                ldx=None, ldo_f=None, ldo_a=None):
+    xdt = L.dt_of(x)
+    check(load().mmx_skinny_gemm(_p(x), xdt, i64(ldx if ldx is not None else K), B, K, N, _p(wp), _p(bias), int(rs),
+                                 C.c_float(eps), epi, _p(out_f32), i64(ldo_f if ldo_f is not None else N),
+                                 _p(out_act), i64(ldo_a if ldo_a is not None else N), dtype, stream()),
+          "mmx_skinny_gemm")
+
+
+def rope_kv_store(qkv, inv_freq, pos, q_out, kc, vc, block_table, *, B, rows, Hq, Hkv, page, dtype):
+    ld = (Hq + 2 * Hkv) * 64
+    check(load().mmx_rope_kv_store(_p(qkv), i64(ld), i64(rows * ld), B, rows, Hq, Hkv, 64, _p(inv_freq), _p(pos),
+                                   _p(q_out), i64(Hq * 64), i64(rows * Hq * 64), _p(kc), _p(vc), _p(block_table),
+                                   block_table.shape[1], page, dtype, stream()), "mmx_rope_kv_store")
+
+
+def paged_attn(q, pos, kc, vc, block_table, out, *, B, rows, Hq, Hkv, page, dtype):
+    check(load().mmx_paged_attn(_p(q), i64(Hq * 64), i64(rows * Hq * 64), B, rows, Hq, Hkv, 64, C.c_float(0.125),
+                                _p(pos), _p(kc), _p(vc), _p(block_table), block_table.shape[1], page, _p(out),
+                                i64(Hq * 64), i64(rows * Hq * 64), dtype, stream()), "mmx_paged_attn")
+
+
+def swiglu(gu, out, *, rows, I, dtype):
+    check(load().mmx_swiglu(_p(gu), i64(2 * I), rows, I, _p(out), i64(I), dtype, stream()), "mmx_swiglu")
+
+
+def sample_step(logits, state, out_tokens, speech_emb, next_x, *, V, B, eos_id, seed, top_k=25, top_p=0.8,
+                win_size=10, tau_r=0.1, sampled=None, forced=None, logp_out=None):
+    check(load().mmx_sample_step(_p(logits), i64(logits.shape[-1]), V, B, eos_id, top_k, C.c_float(top_p), win_size,
+                                 C.c_float(tau_r), C.c_uint64(seed), _p(state), _p(out_tokens), out_tokens.shape[1],
+                                 _p(sampled), _p(forced), _p(speech_emb), speech_emb.shape[1], _p(next_x),
+                                 i64(next_x.shape[-1]), _p(logp_out), stream()), "mmx_sample_step")

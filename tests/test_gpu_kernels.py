@@ -1,0 +1,323 @@
+"""Op-level parity tests of the HIP kernels (through the C ABI) against plain torch fp32 math.
+Tolerances: fp32 build ~1e-4 relative (exact-fp32 MFMA, different summation order); bf16 build is
+bounded by bf16 operand rounding (2^-8 relative per operand) with fp32 accumulation."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from mmx import _lib, ops
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    _lib.load()
+    return _lib, ops
+
+
+def rel_err(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+DT = [0, 1]   # F32, BF16
+TOL = {0: 2e-5, 1: 2e-2}
+
+
+def cast(x, dt):
+    return x.to(torch.bfloat16 if dt == 1 else torch.float32)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(1, 16, 32), (37, 80, 96), (500, 256, 320), (130, 1536, 256), (1000, 48, 336), (64, 64, 4864)])
+def test_gemm_plain(env, dt, M, N, K):
+    L, ops = env
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = torch.randn(N, K, generator=g).cuda() / math.sqrt(K)
+    b = torch.randn(N, generator=g).cuda()
+    xa, wp = cast(x, dt), ops.pack_linear(w, dt)
+    out = torch.zeros(M, N, device="cuda")
+    outa = torch.zeros(M, N, device="cuda", dtype=xa.dtype)
+    ops.linear(xa, wp, K, dtype=dt, bias=b, act="gelu", out_f32=out, out_act=outa)
+    ref = F.gelu(F.linear(xa.float(), wp[:, :K].float(), b))
+    assert rel_err(out, ref) < TOL[dt]
+    assert rel_err(outa, ref) < (1e-2 if dt else TOL[dt])
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_epilogue_residual_mask_snake(env, dt):
+    L, ops = env
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 70, 96, 64
+    x = torch.randn(M, K, generator=g).cuda()
+    w = torch.randn(N, K, generator=g).cuda() / 8
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    mask = (torch.rand(M, generator=g) > 0.3).float().cuda()
+    alpha = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    xa, wp = cast(x, dt), ops.pack_linear(w, dt)
+    out = torch.zeros(M, N, device="cuda")
+    outa = torch.zeros(M, N, device="cuda", dtype=xa.dtype)
+    ops.gemm(xa, wp, M, N, dtype=dt, lda=K, cin=K, bias=b, act="lrelu", slope=0.1, residual=res, ldr=N, rowmask=mask,
+             alpha=alpha, out_f32=out, ldo_f=N, out_act=outa, ldo_a=N)
+    v = (F.leaky_relu(F.linear(xa.float(), wp[:, :K].float(), b), 0.1) + res) * mask[:, None]
+    assert rel_err(out, v) < TOL[dt]
+    sn = v + (alpha + 1e-9).reciprocal() * torch.sin(alpha * v) ** 2
+    assert rel_err(outa, sn) < (1e-2 if dt else 1e-4)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Cin,Cout,k,dil,T", [(80, 1536, 7, 1, 50), (48, 48, 7, 9, 700), (96, 96, 7, 3, 333), (192, 192, 1, 1, 100),
+                                              (320, 256, 3, 1, 64)])
+def test_conv1d(env, dt, Cin, Cout, k, dil, T):
+    L, ops = env
+    g = torch.Generator().manual_seed(Cin + k)
+    B = 2
+    x = torch.randn(B, Cin, T, generator=g).cuda()
+    w = torch.randn(Cout, Cin, k, generator=g).cuda() / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g).cuda()
+    xt = cast(x.transpose(1, 2).contiguous(), dt)
+    wp = ops.pack_conv1d(w, dt)
+    pad = (k - 1) * dil // 2 if k != 3 else 2              # k3 case = causal (left pad 2)
+    out = torch.zeros(B, T, Cout, device="cuda")
+    ops.conv1d(xt, wp, T=T, Cin=Cin, k=k, dil=dil, pad_left=pad, dtype=dt, batch=B, bias=b, out_f32=out)
+    wq = wp[:, :k * Cin].float().reshape(Cout, k, Cin).permute(0, 2, 1)
+    xin = xt.float().transpose(1, 2)
+    if k == 3:
+        ref = F.conv1d(F.pad(xin, (2, 0)), wq, b)
+    else:
+        ref = F.conv1d(xin, wq, b, dilation=dil, padding=pad)
+    assert rel_err(out, ref.transpose(1, 2)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("Cin,Cout,s,T", [(1536, 768, 5, 8), (96, 48, 2, 40), (192, 96, 3, 33), (384, 192, 4, 17)])
+def test_convtranspose1d(env, dt, Cin, Cout, s, T):
+    L, ops = env
+    g = torch.Generator().manual_seed(Cin + s)
+    B = 2
+    x = torch.randn(B, Cin, T, generator=g).cuda()
+    w = torch.randn(Cin, Cout, 2 * s, generator=g).cuda() / math.sqrt(Cin * 2)
+    b = torch.randn(Cout, generator=g).cuda()
+    xt = cast(x.transpose(1, 2).contiguous(), dt)
+    wq = cast(w, dt).float()
+    wp = ops.pack_convtranspose1d(w, s, dt)
+    out = torch.full((B, T * s, Cout), float("nan"), device="cuda")
+    ops.convtranspose1d(xt, wp, T=T, Cin=Cin, Cout=Cout, stride=s, dtype=dt, batch=B, bias=b, out_f32=out)
+    ref = F.conv_transpose1d(xt.float().transpose(1, 2), wq, b, stride=s, padding=math.ceil(s / 2),
+                             output_padding=s % 2)
+    assert ref.shape[-1] == T * s
+    assert not torch.isnan(out).any()
+    assert rel_err(out, ref.transpose(1, 2)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C,rms", [(256, False), (512, False), (896, True), (80, False)])
+def test_rownorm(env, dt, C, rms):
+    L, ops = env
+    g = torch.Generator().manual_seed(C)
+    B, T = 2, 37
+    x = (torch.randn(B, T, C, generator=g) * 2 + 0.5).cuda()
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    add = torch.randn(B, C, generator=g).cuda()
+    mask = (torch.rand(B, T, generator=g) > 0.2).float().cuda()
+    outf = torch.zeros(B, T, C, device="cuda")
+    outa = torch.zeros(B, T, C, device="cuda", dtype=torch.bfloat16 if dt else torch.float32)
+    ops.rownorm(x, gamma, None if rms else beta, 1e-5, rows=T, C_=C, batch=B, rms=rms, act="none" if rms else "mish",
+                rowmask=mask, addvec=add, out_f32=outf, out_act=outa, dtype=dt)
+    if rms:
+        y = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
+    else:
+        y = F.mish(F.layer_norm(x, (C,), gamma, beta, 1e-5))
+    y = (y * mask[..., None] + add[:, None, :]) * mask[..., None]
+    assert rel_err(outf, y) < 1e-5
+    assert rel_err(outa, y) < (1e-2 if dt else 1e-5)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("T,chunk,relpos", [(50, 0, False), (130, 50, False), (77, 0, True), (100, 50, True)])
+def test_attn_dense(env, dt, T, chunk, relpos):
+    from oracle import flow as OF
+    L, ops = env
+    g = torch.Generator().manual_seed(T)
+    B, H, D = 2, 8, 64
+    q, k, v = (cast(torch.randn(B, T, H * D, generator=g).cuda(), dt) for _ in range(3))
+    km = torch.ones(B, T)
+    km[1, T - 9:] = 0
+    out = torch.zeros(B, T, H * D, device="cuda", dtype=q.dtype)
+    pos = pu = pv = None
+    if relpos:
+        pos = cast(torch.randn(2 * T - 1, H * D, generator=g).cuda(), dt)
+        pu, pv = torch.randn(H, D, generator=g).cuda() * 0.2, torch.randn(H, D, generator=g).cuda() * 0.2
+    ops.attn_dense(q, k, v, out, B=B, H=H, Tq=T, Tk=T, ldq=H * D, ldk=H * D, ldv=H * D, ldo=H * D, q_bs=T * H * D,
+                   k_bs=T * H * D, v_bs=T * H * D, o_bs=T * H * D, scale=D ** -0.5, dtype=dt, keymask=km.cuda(),
+                   chunk=chunk, pos=pos, ldp=H * D, pos_u=pu, pos_v=pv)
+    # reference
+    qh = q.float().cpu().view(B, T, H, D)
+    kh = k.float().cpu().view(B, T, H, D).transpose(1, 2)
+    vh = v.float().cpu().view(B, T, H, D).transpose(1, 2)
+    if relpos:
+        ph = pos.float().cpu().view(1, 2 * T - 1, H, D).transpose(1, 2)
+        ac = (qh + pu.cpu()).transpose(1, 2) @ kh.transpose(-2, -1)
+        bd = OF.rel_shift((qh + pv.cpu()).transpose(1, 2) @ ph.transpose(-2, -1))
+        s = (ac + bd) * D ** -0.5
+    else:
+        s = (qh.transpose(1, 2) @ kh.transpose(-2, -1)) * D ** -0.5
+    vis = km.bool()[:, None, :].expand(B, T, T).clone()
+    if chunk:
+        vis = vis & OF.subsequent_chunk_mask(T, chunk)[None]
+    s = s.masked_fill(~vis[:, None], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, H * D)
+    assert rel_err(out.cpu(), ref) < (2e-2 if dt else 2e-5)
+
+
+@pytest.mark.parametrize("T,chunk", [(64, 0), (500, 0), (137, 50), (1000, 0)])
+def test_attn_flash_bf16(env, T, chunk):
+    from oracle import flow as OF
+    L, ops = env
+    g = torch.Generator().manual_seed(T + 1)
+    B, H, D = 2, 8, 64
+    q, k, v = (torch.randn(B, T, H * D, generator=g).cuda().bfloat16() for _ in range(3))
+    Tp = ops.round_up(T, 8)
+    vt = torch.zeros(B, H * D, Tp, device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :T] = v.transpose(1, 2)
+    km = torch.ones(B, T)
+    km[1, T - 9:] = 0
+    out = torch.zeros(B, T, H * D, device="cuda", dtype=torch.bfloat16)
+    ops.attn_flash_bf16(q, k, vt, out, B=B, H=H, T=T, ldq=H * D, ldk=H * D, ldvt=Tp, ldo=H * D, q_bs=T * H * D,
+                        k_bs=T * H * D, vt_bs=H * D * Tp, o_bs=T * H * D, scale=D ** -0.5, keymask=km.cuda(), chunk=chunk)
+    qh, kh, vh = (t.float().cpu().view(B, T, H, D).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-2, -1)) * D ** -0.5
+    vis = km.bool()[:, None, :].expand(B, T, T).clone()
+    if chunk:
+        vis = vis & OF.subsequent_chunk_mask(T, chunk)[None]
+    s = s.masked_fill(~vis[:, None], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, H * D)
+    assert rel_err(out.cpu(), ref) < 2e-2
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,K,N,epi,rs", [(1, 896, 1152, 0, True), (3, 896, 896, 2, False), (17, 4864, 896, 2, False),
+                                          (1, 896, 4864, 1, True), (33, 896, 4864, 1, True), (2, 896, 6564, 0, True)])
+def test_skinny_gemm(env, dt, B, K, N, epi, rs):
+    L, ops = env
+    g = torch.Generator().manual_seed(B * 31 + N)
+    x = torch.randn(B, K, generator=g).cuda() * 3
+    eps = 1e-6
+    if epi == 1:
+        w = torch.randn(2 * N, K, generator=g).cuda() / math.sqrt(K)
+    else:
+        w = torch.randn(N, K, generator=g).cuda() / math.sqrt(K)
+    ks = (1 + 0.1 * torch.randn(K, generator=g)).cuda() if rs else None
+    bias = torch.randn(N, generator=g).cuda() if epi == 0 else None
+    wc = cast(w, dt).contiguous()
+    wp = ops.pack_skinny(wc, dtype=dt, kscale=ks, interleave_half=(N if epi == 1 else 0))
+    xin = x if (epi != 2) else cast(x, dt)                  # o_proj / down take the compute-dtype activation
+    weff = cast(wc.float() * (ks if rs else 1.0), dt).float()
+    xe = cast(xin, dt).float()
+    acc = xe @ weff.t()
+    if rs:
+        acc = acc * torch.rsqrt(xin.float().pow(2).mean(-1, keepdim=True) + eps)
+    if epi == 0:
+        out = torch.zeros(B, N, device="cuda")
+        ops.skinny_gemm(xin, wp, B=B, K=K, N=N, dtype=dt, bias=bias, rs=rs, eps=eps, epi=0, out_f32=out)
+        ref = acc + bias
+    elif epi == 1:
+        out = torch.zeros(B, N, device="cuda", dtype=torch.bfloat16 if dt else torch.float32)
+        ops.skinny_gemm(xin, wp, B=B, K=K, N=N, dtype=dt, rs=rs, eps=eps, epi=1, out_act=out)
+        ref = F.silu(acc[:, :N]) * acc[:, N:]
+    else:
+        res = torch.randn(B, N, generator=g).cuda()
+        out = res.clone()
+        ops.skinny_gemm(xin, wp, B=B, K=K, N=N, dtype=dt, epi=2, out_f32=out)
+        ref = res + acc
+    assert rel_err(out, ref) < (1.5e-2 if dt else 3e-5)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_rope_kv_paged_attention_matches_oracle(env, dt):
+    """prefill of 11 tokens + 3 decode steps through rope_kv_store / paged_attn vs the oracle's Qwen2 attention."""
+    from oracle import llm as OL
+    L, ops = env
+    g = torch.Generator().manual_seed(5)
+    Hq, Hkv, D, page = 14, 2, 64, 16
+    B = 2
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))).cuda()
+    npages, maxp = 16, 4
+    tdt = torch.bfloat16 if dt else torch.float32
+    kc = torch.zeros(npages, Hkv, page, D, device="cuda", dtype=tdt)
+    vc = torch.zeros_like(kc)
+    bt = torch.tensor([[3, 7, 1, 0], [9, 2, 5, 4]], dtype=torch.int32).cuda()
+    lens = [11, 6]
+    hist = [[], []]
+    for step, rows in enumerate([None, 1, 1, 1]):
+        for b in range(B):
+            r = lens[b] if rows is None else 1
+            qkv = torch.randn(1, r, (Hq + 2 * Hkv) * D, generator=g)
+            hist[b].append(qkv)
+        pos = torch.tensor([sum(x.shape[1] for x in hist[b][:-1]) for b in range(B)], dtype=torch.int32).cuda()
+        for b in range(B):   # variable rows per sequence in prefill: one call per sequence
+            qkv = hist[b][-1].cuda().contiguous()
+            r = qkv.shape[1]
+            qo = torch.zeros(1, r, Hq * D, device="cuda", dtype=tdt)
+            ops.rope_kv_store(qkv, inv, pos[b:b + 1], qo, kc, vc, bt[b:b + 1], B=1, rows=r, Hq=Hq, Hkv=Hkv, page=page, dtype=dt)
+            out = torch.zeros(1, r, Hq * D, device="cuda", dtype=tdt)
+            ops.paged_attn(qo, pos[b:b + 1], kc, vc, bt[b:b + 1], out, B=1, rows=r, Hq=Hq, Hkv=Hkv, page=page, dtype=dt)
+            # oracle
+            allq = torch.cat(hist[b], dim=1)
+            n = allq.shape[1]
+            qq = allq[..., :Hq * D].view(1, n, Hq, D).transpose(1, 2)
+            kk = allq[..., Hq * D:(Hq + Hkv) * D].view(1, n, Hkv, D).transpose(1, 2)
+            vv = allq[..., (Hq + Hkv) * D:].view(1, n, Hkv, D).transpose(1, 2)
+            cos, sin = OL.rope_cos_sin(torch.arange(n), D, 1e6)
+            qq = qq * cos + OL.rotate_half(qq) * sin
+            kk = kk * cos + OL.rotate_half(kk) * sin
+            kr, vr = kk.repeat_interleave(Hq // Hkv, 1), vv.repeat_interleave(Hq // Hkv, 1)
+            s = (qq @ kr.transpose(-2, -1)) * D ** -0.5
+            s = s.masked_fill(~torch.tril(torch.ones(n, n, dtype=torch.bool)), float("-inf"))
+            ref = (torch.softmax(s, -1) @ vr).transpose(1, 2).reshape(1, n, Hq * D)[:, n - r:]
+            assert rel_err(out.cpu(), ref) < (2e-2 if dt else 2e-5), (step, b)
+
+
+def test_sampler_matches_oracle(env):
+    """Device sampler (log_softmax + RAS + EOS re-draw + bookkeeping) vs oracle.llm.sampling_ids_e on the same
+    Philox noise: ids must be IDENTICAL."""
+    from oracle import llm as OL
+    from oracle import weights as W
+    L, ops = env
+    cases = W.sampler_cases(64)
+    V, E, eos, seed = 6564, 896, 6561, 1234
+    emb = torch.randn(V, E).cuda()
+    mism = 0
+    for s, (logp, hist) in enumerate(cases):
+        logits = (logp + 3.7).unsqueeze(0)                   # any shift: log_softmax removes it
+        if s % 5 == 0:
+            logits[0, eos] = logits.max() + 2.0              # make EOS dominant -> exercises the re-draw loop
+        step = s
+        min_len = step + 1 if s % 2 == 0 else 0              # ignore_eos on even cases
+        state = torch.tensor([[40, step, len(hist), 0, min_len, 999, 3, 0]], dtype=torch.int32).cuda()
+        out_tokens = torch.zeros(1, 64, dtype=torch.int32)
+        out_tokens[0, :len(hist)] = torch.tensor(hist, dtype=torch.int32)
+        out_tokens = out_tokens.cuda()
+        sampled = torch.full((1, 64), -1, dtype=torch.int32).cuda()
+        nx = torch.zeros(1, E).cuda()
+        lp = torch.zeros(1, V).cuda()
+        ops.sample_step(logits.cuda().contiguous(), state, out_tokens, emb, nx, V=V, B=1, eos_id=eos, seed=seed,
+                        sampled=sampled, logp_out=lp)
+        got = int(sampled[0, step])
+        lpo = logits[0].log_softmax(-1)
+        assert (lp[0].cpu() - lpo).abs().max() < 1e-4
+        want = OL.sampling_ids_e(lpo, hist, lambda k: OL.philox_noise(seed, 3, step, k), ignore_eos=step < min_len, eos=eos)
+        mism += got != want
+        st = state.cpu()[0].tolist()
+        if want == eos:
+            assert st[3] == 1
+        elif want < eos:
+            assert st[2] == len(hist) + 1 and int(out_tokens[0, len(hist)]) == want
+            assert torch.equal(nx[0], emb[want])
+            assert st[0] == 41 and st[1] == step + 1
+    assert mism == 0, f"{mism} sampled ids differ from the oracle"
