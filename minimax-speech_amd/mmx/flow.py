@@ -1,0 +1,438 @@
+"""CosyVoice2 causal flow-matching decoder engine (FSQ tokens -> DAC-VAE latents) on libmmx_hip kernels.
+
+Reference (speech/): cosyvoice/flow/flow.py:437-511 (inference), transformer/upsample_encoder.py:243-316 (encoder),
+flow/flow_matching.py:74-126,323-348 (CFM Euler + CFG), flow/decoder.py:405-496 (estimator),
+matcha/models/components/{decoder.py:14-117, transformer.py:243-316}.
+
+Everything is time-major [B, T, C].  fp32 residual streams, compute-dtype GEMM inputs.  Each Linear / causal
+Conv1d is one windowed-GEMM launch with bias / activation / residual / mask fused; the estimator's V
+projection is computed directly transposed (V^T = W_v X^T, same kernel with operand roles swapped) so the
+MFMA flash-attention kernel reads K row-major and V^T row-major without any transpose pass.
+A whole 10-step Euler solve (about 5 000 launches) is recorded once per shape into a hipGraph.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import BF16, F32, TORCH_DT
+
+
+def espnet_rel_pe(T: int, d: int) -> torch.Tensor:
+    """embedding.py:233-253 table for relative positions T-1 ... -(T-1): [2T-1, d] fp32 (host, cached)."""
+    pos = torch.arange(T - 1, -T, -1, dtype=torch.float32)[:, None]
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(2 * T - 1, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class Graphed:
+    """Runs `fn` eagerly once (warm-up), then records it into a hipGraph and replays it."""
+
+    def __init__(self, fn, enabled=True):
+        self.fn, self.enabled, self.graph, self.calls = fn, enabled, None, 0
+
+    def __call__(self):
+        if not self.enabled:
+            return self.fn()
+        if self.graph is None:
+            self.calls += 1
+            if self.calls == 1:
+                return self.fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.fn()
+            self.graph = g
+        self.graph.replay()
+
+
+class FlowEngine:
+    def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", n_timesteps=10, cfg_rate=0.7,
+                 enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True):
+        self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
+        self.enc_chunk, self.est_chunk = enc_chunk, est_chunk
+        self.use_graphs = use_graphs
+        dt = dtype
+        f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
+        lin = lambda k: ops.pack_linear(f(k), dt)
+        cv = lambda k: ops.pack_conv1d(f(k), dt)
+        self.emb_table = f("input_embedding.weight")
+        self.spk_w, self.spk_b = lin("spk_embed_affine_layer.weight"), f("spk_embed_affine_layer.bias")
+        self.spk_dim = sd["spk_embed_affine_layer.weight"].shape[1]
+        self.spk_gamma = torch.full((self.spk_dim,), 1.0 / math.sqrt(self.spk_dim), device=self.dev)
+        e = "encoder"
+        xs = math.sqrt(512.0)
+
+        def embed(p):
+            return dict(w=lin(p + ".out.0.weight"), b=f(p + ".out.0.bias"), g=f(p + ".out.1.weight") * xs,
+                        beta=f(p + ".out.1.bias") * xs)
+
+        def conf_layer(p):
+            a = p + ".self_attn"
+            return dict(
+                n1g=f(p + ".norm_mha.weight"), n1b=f(p + ".norm_mha.bias"),
+                wqkv=ops.pack_linear(torch.cat([f(a + ".linear_q.weight"), f(a + ".linear_k.weight"), f(a + ".linear_v.weight")], 0), dt),
+                bqkv=torch.cat([f(a + ".linear_q.bias"), f(a + ".linear_k.bias"), f(a + ".linear_v.bias")], 0).contiguous(),
+                wpos=lin(a + ".linear_pos.weight"), pu=f(a + ".pos_bias_u"), pv=f(a + ".pos_bias_v"),
+                wo=lin(a + ".linear_out.weight"), bo=f(a + ".linear_out.bias"),
+                n2g=f(p + ".norm_ff.weight"), n2b=f(p + ".norm_ff.bias"),
+                w1=lin(p + ".feed_forward.w_1.weight"), b1=f(p + ".feed_forward.w_1.bias"),
+                w2=lin(p + ".feed_forward.w_2.weight"), b2=f(p + ".feed_forward.w_2.bias"))
+
+        self.enc = dict(embed=embed(e + ".embed"), up_embed=embed(e + ".up_embed"),
+                        pl_w1=cv(e + ".pre_lookahead_layer.conv1.weight"), pl_b1=f(e + ".pre_lookahead_layer.conv1.bias"),
+                        pl_w2=cv(e + ".pre_lookahead_layer.conv2.weight"), pl_b2=f(e + ".pre_lookahead_layer.conv2.bias"),
+                        layers=[conf_layer(f"{e}.encoders.{i}") for i in range(6)],
+                        up_w=cv(e + ".up_layer.conv.weight"), up_b=f(e + ".up_layer.conv.bias"),
+                        up_layers=[conf_layer(f"{e}.up_encoders.{i}") for i in range(4)],
+                        ang=f(e + ".after_norm.weight"), anb=f(e + ".after_norm.bias"),
+                        wproj=lin("encoder_proj.weight"), bproj=f("encoder_proj.bias"))
+        # ------------------------------------------------------------------ estimator
+        q = "decoder.estimator"
+        self.tdim = sd[q + ".time_mlp.linear_1.weight"].shape[1]             # 320
+        self.t_w1, self.t_b1 = lin(q + ".time_mlp.linear_1.weight"), f(q + ".time_mlp.linear_1.bias")
+        self.t_w2, self.t_b2 = lin(q + ".time_mlp.linear_2.weight"), f(q + ".time_mlp.linear_2.bias")
+
+        def tblock(p):
+            a = p + ".attn1"
+            d = dict(n1g=f(p + ".norm1.weight"), n1b=f(p + ".norm1.bias"),
+                     wo=lin(a + ".to_out.0.weight"), bo=f(a + ".to_out.0.bias"),
+                     n3g=f(p + ".norm3.weight"), n3b=f(p + ".norm3.bias"),
+                     w1=lin(p + ".ff.net.0.proj.weight"), b1=f(p + ".ff.net.0.proj.bias"),
+                     w2=lin(p + ".ff.net.2.weight"), b2=f(p + ".ff.net.2.bias"))
+            wq, wk, wv = f(a + ".to_q.weight"), f(a + ".to_k.weight"), f(a + ".to_v.weight")
+            if dt == BF16:
+                d["wqk"] = ops.pack_linear(torch.cat([wq, wk], 0), dt)       # [1024, 256]
+                d["wv"] = ops.pack_linear(wv, dt)                            # A operand of the V^T GEMM
+            else:
+                d["wqkv"] = ops.pack_linear(torch.cat([wq, wk, wv], 0), dt)
+            return d
+
+        self.resnets, mlp_w, mlp_b = [], [], []
+
+        def resnet(p):
+            idx = len(self.resnets)
+            r = dict(idx=idx, cin=sd[p + ".block1.block.0.weight"].shape[1],
+                     w1=cv(p + ".block1.block.0.weight"), b1=f(p + ".block1.block.0.bias"),
+                     g1=f(p + ".block1.block.2.weight"), be1=f(p + ".block1.block.2.bias"),
+                     w2=cv(p + ".block2.block.0.weight"), b2=f(p + ".block2.block.0.bias"),
+                     g2=f(p + ".block2.block.2.weight"), be2=f(p + ".block2.block.2.bias"),
+                     wr=cv(p + ".res_conv.weight"), br=f(p + ".res_conv.bias"))
+            mlp_w.append(f(p + ".mlp.1.weight"))
+            mlp_b.append(f(p + ".mlp.1.bias"))
+            self.resnets.append(r)
+            return r
+
+        def stage(p):
+            return dict(res=resnet(p + ".0"), blocks=[tblock(f"{p}.1.{j}") for j in range(4)])
+
+        self.n_mid = len({k.split(".")[3] for k in sd if k.startswith(q + ".mid_blocks.")})
+        self.down = stage(q + ".down_blocks.0")
+        self.down_w, self.down_b = cv(q + ".down_blocks.0.2.weight"), f(q + ".down_blocks.0.2.bias")
+        self.mid = [stage(f"{q}.mid_blocks.{i}") for i in range(self.n_mid)]
+        self.up = stage(q + ".up_blocks.0")
+        self.up_w, self.up_b = cv(q + ".up_blocks.0.2.weight"), f(q + ".up_blocks.0.2.bias")
+        self.fin_w, self.fin_b = cv(q + ".final_block.block.0.weight"), f(q + ".final_block.block.0.bias")
+        self.fin_g, self.fin_be = f(q + ".final_block.block.2.weight"), f(q + ".final_block.block.2.bias")
+        self.proj_w, self.proj_b = cv(q + ".final_proj.weight"), f(q + ".final_proj.bias")
+        self.mlp_w = ops.pack_linear(torch.cat(mlp_w, 0), dt)                # [14*256, 1024]
+        self.mlp_b = torch.cat(mlp_b, 0).contiguous()
+        self.C = 256
+        # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
+        g = torch.Generator().manual_seed(0)
+        self.rand_noise = torch.randn([1, 80, 50 * 300], generator=g)
+        self._pe, self._plans = {}, {}
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, *shape, f32=False):
+        return torch.empty(*shape, dtype=torch.float32 if f32 else self.tdt, device=self.dev)
+
+    def _pos(self, T):
+        if T not in self._pe:
+            self._pe[T] = espnet_rel_pe(T, 512).to(self.dev, self.tdt)
+        return self._pe[T]
+
+    # ------------------------------------------------------------------ encoder
+    def _conformer(self, lw, x, T, pos_act, chunk):
+        dt = self.dtype
+        hn = self._new(T, 512)
+        ops.rownorm(x, lw["n1g"], lw["n1b"], 1e-12, rows=T, C_=512, out_act=hn, dtype=dt)
+        qkv = self._new(T, 1536)
+        ops.linear(hn, lw["wqkv"], 512, dtype=dt, bias=lw["bqkv"], out_act=qkv)
+        p = self._new(2 * T - 1, 512)
+        ops.linear(pos_act, lw["wpos"], 512, dtype=dt, out_act=p)
+        ao = self._new(T, 512)
+        ops.attn_dense(qkv, qkv[:, 512:], qkv[:, 1024:], ao, B=1, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                       q_bs=0, k_bs=0, v_bs=0, o_bs=0, scale=0.125, dtype=dt, chunk=chunk, pos=p, ldp=512,
+                       pos_u=lw["pu"], pos_v=lw["pv"])
+        x2 = self._new(T, 512, f32=True)
+        ops.linear(ao, lw["wo"], 512, dtype=dt, bias=lw["bo"], residual=x, out_f32=x2)
+        ops.rownorm(x2, lw["n2g"], lw["n2b"], 1e-12, rows=T, C_=512, out_act=hn, dtype=dt)
+        ff = self._new(T, 2048)
+        ops.linear(hn, lw["w1"], 512, dtype=dt, bias=lw["b1"], act="silu", out_act=ff)
+        x3 = self._new(T, 512, f32=True)
+        ops.linear(ff, lw["w2"], 2048, dtype=dt, bias=lw["b2"], residual=x2, out_f32=x3)
+        return x3
+
+    def _embed(self, ew, a, T):
+        """LinearNoSubsampling + LayerNorm (eps 1e-5) * sqrt(512): act [T,512] -> fp32 [T,512] and act copy."""
+        dt = self.dtype
+        tmp = self._new(T, 512, f32=True)
+        ops.linear(a, ew["w"], 512, dtype=dt, bias=ew["b"], out_f32=tmp)
+        x = self._new(T, 512, f32=True)
+        xa = self._new(T, 512)
+        ops.rownorm(tmp, ew["g"], ew["beta"], 1e-5, rows=T, C_=512, out_f32=x, out_act=xa, dtype=dt)
+        return x, xa
+
+    def encode(self, ids: torch.Tensor, finalize: bool, streaming: bool) -> torch.Tensor:
+        """ids [L] int64 (prompt + tokens). Returns mu fp32 time-major [2*T, 80], T = L (finalize) or L - 3."""
+        dt, E = self.dtype, self.enc
+        Lt = ids.numel()
+        a0 = self._new(Lt, 512)
+        ops.gather_rows(ids, self.emb_table, out_act=a0, dtype=dt)
+        x_all, xa_all = self._embed(E["embed"], a0, Lt)
+        T = Lt if finalize else Lt - self.L
+        rows_in = Lt                                    # look-ahead context rows follow the T rows contiguously
+        # PreLookaheadLayer: conv k4 over [x ; context|zeros] -> leaky_relu(0.01) -> causal conv k3 -> + x
+        h1 = self._new(T, 512)
+        ops.gemm(xa_all, E["pl_w1"], T, 512, dtype=dt, lda=512, cin=512, ntaps=4, row_off=0, row_lo=0, row_hi=rows_in,
+                 bias=E["pl_b1"], act="lrelu", slope=0.01, out_act=h1, ldo_a=512)
+        x = self._new(T, 512, f32=True)
+        ops.conv1d(h1, E["pl_w2"], T=T, Cin=512, k=3, pad_left=2, dtype=dt, bias=E["pl_b2"], residual=x_all, out_f32=x)
+        pos = self._pos(T)
+        chunk = self.enc_chunk if streaming else 0
+        for lw in E["layers"]:
+            x = self._conformer(lw, x, T, pos, chunk)
+        # Upsample1D: nearest x2, left pad 4, conv k5
+        T2 = 2 * T
+        up = self._new(T2, 512)
+        ops.copy2d(x, F32, 0, 512, 1, up, dt, 0, 512, 1, rows=T2, cols=512, rep=2)
+        c5 = self._new(T2, 512)
+        ops.conv1d(up, E["up_w"], T=T2, Cin=512, k=5, pad_left=4, dtype=dt, bias=E["up_b"], out_act=c5)
+        x, _ = self._embed(E["up_embed"], c5, T2)
+        pos = self._pos(T2)
+        for lw in E["up_layers"]:
+            x = self._conformer(lw, x, T2, pos, 2 * chunk)
+        hn = self._new(T2, 512)
+        ops.rownorm(x, E["ang"], E["anb"], 1e-5, rows=T2, C_=512, out_act=hn, dtype=dt)
+        mu = self._new(T2, 80, f32=True)
+        ops.linear(hn, E["wproj"], 512, dtype=dt, bias=E["bproj"], out_f32=mu)
+        return mu
+
+    # ------------------------------------------------------------------ estimator
+    def _resnet(self, r, a_in, lda, B, T, tv, mask, out_x):
+        """CausalResnetBlock1D; a_in: act [B,T,lda] holding x*mask; writes fp32 out_x [B,T,256]."""
+        dt, C = self.dtype, self.C
+        cin = r["cin"]
+        c1 = self._new(B, T, C, f32=True)
+        kw = dict(dtype=dt, lda=lda, cin=cin, ntaps=3, row_off=-2, row_lo=0, row_hi=T, batch=B, a_bstride=T * lda)
+        ops.gemm(a_in, r["w1"], T, C, bias=r["b1"], out_f32=c1, ldo_f=C, of_bstride=T * C, **kw)
+        h1 = self._new(B, T, C)
+        ops.rownorm(c1, r["g1"], r["be1"], 1e-5, rows=T, C_=C, batch=B, act="mish", rowmask=mask,
+                    addvec=tv[:, r["idx"] * C:], av_bstride=tv.shape[1], out_act=h1, dtype=dt)
+        ops.conv1d(h1, r["w2"], T=T, Cin=C, k=3, pad_left=2, dtype=dt, batch=B, bias=r["b2"], out_f32=c1)
+        h2 = self._new(B, T, C, f32=True)
+        ops.rownorm(c1, r["g2"], r["be2"], 1e-5, rows=T, C_=C, batch=B, act="mish", rowmask=mask, out_f32=h2, dtype=dt)
+        ops.gemm(a_in, r["wr"], T, C, dtype=dt, lda=lda, cin=cin, ntaps=1, row_lo=0, row_hi=T, batch=B, a_bstride=T * lda,
+                 bias=r["br"], residual=h2, ldr=C, r_bstride=T * C, out_f32=out_x, ldo_f=C, of_bstride=T * C)
+
+    def _tblock(self, w, x, B, T, mask, chunk, act_out=None, act_ld=0):
+        """BasicTransformerBlock on fp32 x [B,T,256] (in place); optional compute-dtype copy of the result
+        (x*mask) into act_out with row stride act_ld."""
+        dt, C = self.dtype, self.C
+        hn = self._new(B, T, C)
+        ops.rownorm(x, w["n1g"], w["n1b"], 1e-5, rows=T, C_=C, batch=B, out_act=hn, dtype=dt)
+        ao = self._new(B, T, 512)
+        if dt == BF16:
+            qk = self._new(B, T, 1024)
+            ops.gemm(hn, w["wqk"], T, 1024, dtype=dt, lda=C, cin=C, batch=B, a_bstride=T * C, out_act=qk, ldo_a=1024,
+                     oa_bstride=T * 1024)
+            Tp = ops.round_up(T, 8)
+            vt = self._vt_buf(B, Tp)
+            # V^T[b] = W_v (512x256) . X_b^T : A = weights, "W" operand = activations (batch stride on W)
+            ops.gemm(w["wv"], hn, 512, T, dtype=dt, lda=w["wv"].shape[1], cin=C, batch=B, a_bstride=0, w_bstride=T * C,
+                     out_act=vt, ldo_a=Tp, oa_bstride=512 * Tp)
+            ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512,
+                                q_bs=T * 1024, k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, keymask=mask,
+                                chunk=chunk)
+        else:
+            qkv = self._new(B, T, 1536)
+            ops.gemm(hn, w["wqkv"], T, 1536, dtype=dt, lda=C, cin=C, batch=B, a_bstride=T * C, out_act=qkv, ldo_a=1536,
+                     oa_bstride=T * 1536)
+            ops.attn_dense(qkv, qkv[:, :, 512:], qkv[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536,
+                           ldo=512, q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt,
+                           keymask=mask, chunk=chunk)
+        ops.gemm(ao, w["wo"], T, C, dtype=dt, lda=512, cin=512, batch=B, a_bstride=T * 512, bias=w["bo"], residual=x,
+                 ldr=C, r_bstride=T * C, out_f32=x, ldo_f=C, of_bstride=T * C)
+        ops.rownorm(x, w["n3g"], w["n3b"], 1e-5, rows=T, C_=C, batch=B, out_act=hn, dtype=dt)
+        ff = self._new(B, T, 1024)
+        ops.gemm(hn, w["w1"], T, 1024, dtype=dt, lda=C, cin=C, batch=B, a_bstride=T * C, bias=w["b1"], act="gelu",
+                 out_act=ff, ldo_a=1024, oa_bstride=T * 1024)
+        ops.gemm(ff, w["w2"], T, C, dtype=dt, lda=1024, cin=1024, batch=B, a_bstride=T * 1024, bias=w["b2"], residual=x,
+                 ldr=C, r_bstride=T * C, out_f32=x, ldo_f=C, of_bstride=T * C,
+                 rowmask=(mask if act_out is not None else None), rm_bstride=T,
+                 out_act=act_out, ldo_a=act_ld, oa_bstride=T * act_ld)
+
+    def _vt_buf(self, B, Tp):
+        key = ("vt", B, Tp)
+        if key not in self._plans:
+            self._plans[key] = torch.zeros(B, 512, Tp, dtype=self.tdt, device=self.dev)   # pad columns stay zero
+        return self._plans[key]
+
+    def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None):
+        """All inputs fp32 time-major device tensors: x [*,T,80] (batch stride x_bstride), mu/cond [B,T,80],
+        spks [B,80], t [B]; mask fp32 [B,T] or None.  Returns fp32 [B,T,80]."""
+        dt, C = self.dtype, self.C
+        chunk = self.est_chunk if streaming else 0
+        te = self._new(B, self.tdim)
+        ops.sinusoidal_emb(t, te, dim=self.tdim, dtype=dt)
+        t1 = self._new(B, 1024)
+        ops.linear(te, self.t_w1, self.tdim, dtype=dt, bias=self.t_b1, act="silu", out_act=t1)
+        t2 = self._new(B, 1024)
+        ops.linear(t1, self.t_w2, 1024, dtype=dt, bias=self.t_b2, act2="mish", out_act=t2)       # mish(time_mlp(t))
+        tv = self._new(B, self.mlp_w.shape[0], f32=True)
+        ops.linear(t2, self.mlp_w, 1024, dtype=dt, bias=self.mlp_b, out_f32=tv)                  # all 14 resnet mlps
+        h0 = self._new(B, T, 320)
+        ops.est_pack(x, mu, spks, cond, h0, B=B, T=T, dtype=dt, x_bstride=x_bstride)
+        xs = self._new(B, T, C, f32=True)
+        cat = self._new(B, T, 2 * C)                     # [mid output | skip] for the up block
+        # down block: resnet + 4 transformer blocks; the last block drops its activation copy into cat[:, :, C:]
+        self._resnet(self.down["res"], h0, 320, B, T, tv, mask, xs)
+        for j, w in enumerate(self.down["blocks"]):
+            last = j == 3
+            self._tblock(w, xs, B, T, mask, chunk, act_out=(cat[:, :, C:] if last else None), act_ld=2 * C)
+        a = self._new(B, T, C)
+        ops.gemm(cat[:, :, C:], self.down_w, T, C, dtype=dt, lda=2 * C, cin=C, ntaps=3, row_off=-2, row_lo=0, row_hi=T,
+                 batch=B, a_bstride=T * 2 * C, bias=self.down_b, rowmask=mask, rm_bstride=T, out_act=a, ldo_a=C,
+                 oa_bstride=T * C)
+        lda = C
+        for i, st in enumerate(self.mid):
+            self._resnet(st["res"], a, lda, B, T, tv, mask, xs)
+            lastst = i == len(self.mid) - 1
+            for j, w in enumerate(st["blocks"]):
+                last = j == 3
+                if last and lastst:
+                    self._tblock(w, xs, B, T, mask, chunk, act_out=cat, act_ld=2 * C)
+                elif last:
+                    self._tblock(w, xs, B, T, mask, chunk, act_out=a, act_ld=C)
+                else:
+                    self._tblock(w, xs, B, T, mask, chunk)
+        self._resnet(self.up["res"], cat, 2 * C, B, T, tv, mask, xs)
+        for j, w in enumerate(self.up["blocks"]):
+            self._tblock(w, xs, B, T, mask, chunk, act_out=(a if j == 3 else None), act_ld=C)
+        a2 = self._new(B, T, C)
+        ops.conv1d(a, self.up_w, T=T, Cin=C, k=3, pad_left=2, dtype=dt, batch=B, bias=self.up_b, rowmask=mask, out_act=a2)
+        c1 = self._new(B, T, C, f32=True)
+        ops.conv1d(a2, self.fin_w, T=T, Cin=C, k=3, pad_left=2, dtype=dt, batch=B, bias=self.fin_b, out_f32=c1)
+        ops.rownorm(c1, self.fin_g, self.fin_be, 1e-5, rows=T, C_=C, batch=B, act="mish", rowmask=mask, out_act=a, dtype=dt)
+        if out is None:
+            out = self._new(B, T, 80, f32=True)
+        ops.conv1d(a, self.proj_w, T=T, Cin=C, k=1, dtype=dt, batch=B, bias=self.proj_b, rowmask=mask, out_f32=out)
+        return out
+
+    @torch.no_grad()
+    def estimator_channels_first(self, x, mask, mu, t, spks, cond, streaming=False):
+        """The reference's estimator seam (flow_matching.py:128-131; ONNX names x, mask, mu, t, spks, cond):
+        x/mu/cond [B,80,T], mask [B,1,T], t [B], spks [B,80] fp32 -> [B,80,T] fp32 (a fresh tensor)."""
+        B, _, T = x.shape
+        tm = lambda a: self._to_time_major(a.to(self.dev, torch.float32).contiguous(), B, T)
+        m = mask.to(self.dev, torch.float32).reshape(B, T).contiguous()
+        d = self.estimator(tm(x), T * 80, tm(mu), spks.to(self.dev, torch.float32).contiguous(), tm(cond),
+                           t.to(self.dev, torch.float32).contiguous(), B, T, m, streaming)
+        out = torch.empty(B, 80, T, dtype=torch.float32, device=self.dev)
+        ops.copy2d(d, F32, T * 80, 80, 1, out, F32, 80 * T, 1, T, rows=T, cols=80, batch=B)
+        return out
+
+    def _to_time_major(self, a, B, T):
+        o = torch.empty(B, T, 80, dtype=torch.float32, device=self.dev)
+        ops.copy2d(a, F32, 80 * T, 1, T, o, F32, T * 80, 80, 1, rows=T, cols=80, batch=B)
+        return o
+
+    # ------------------------------------------------------------------ CFM solve
+    def t_schedule(self):
+        """flow_matching.py:345-348 + :90,121-124 replicated in fp32 on the host: (t per step, dt per step)."""
+        n = self.n_timesteps
+        ts = torch.linspace(0, 1, n + 1, dtype=torch.float32)
+        ts = 1 - torch.cos(ts * 0.5 * torch.pi)
+        t, dt = ts[0:1].clone(), ts[1] - ts[0]
+        tt, dd = [], []
+        for step in range(1, n + 1):
+            tt.append(float(t))
+            dd.append(float(dt))
+            t = t + dt
+            if step < n:
+                dt = ts[step + 1] - t
+        return tt, dd
+
+    class _Plan:
+        pass
+
+    def _cfm_plan(self, T, streaming):
+        key = ("cfm", T, bool(streaming))
+        if key in self._plans:
+            return self._plans[key]
+        P = FlowEngine._Plan()
+        P.x = self._new(T, 80, f32=True)                # the ODE state (shared by the CFG pair)
+        P.mu = torch.zeros(2, T, 80, device=self.dev)   # row 1 stays zero: the unconditional branch
+        P.spks = torch.zeros(2, 80, device=self.dev)
+        P.cond = torch.zeros(2, T, 80, device=self.dev)
+        P.d = self._new(2, T, 80, f32=True)
+        tt, dd = self.t_schedule()
+        P.t_all = torch.tensor([[v, v] for v in tt], dtype=torch.float32, device=self.dev)
+        P.z = self.rand_noise[0, :, :T].t().contiguous().to(self.dev)      # [T,80]
+
+        def run():
+            P.x.copy_(P.z)
+            for s in range(self.n_timesteps):
+                self.estimator(P.x, 0, P.mu, P.spks, P.cond, P.t_all[s], 2, T, None, streaming, out=P.d)
+                ops.cfg_euler(P.x, P.d[0], P.d[1], self.cfg, dd[s], T * 80)
+
+        P.run = Graphed(run, self.use_graphs)
+        self._plans[key] = P
+        return P
+
+    def cfm(self, mu, spks, cond, streaming=False) -> torch.Tensor:
+        """mu, cond fp32 [T,80] time-major; spks fp32 [80] -> x fp32 [T,80] (owned by the plan: copy if kept)."""
+        T = mu.shape[0]
+        P = self._cfm_plan(T, streaming)
+        P.mu[0].copy_(mu)
+        P.spks[0].copy_(spks.reshape(-1))
+        P.cond[0].copy_(cond)
+        P.run()
+        return P.x
+
+    # ------------------------------------------------------------------ flow.inference
+    @torch.no_grad()
+    def inference_time_major(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):
+        """token [1,Lt], prompt_token [1,Lp] ints; prompt_feat [1,Tp,80]; embedding [1,192] (device tensors).
+        Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped)."""
+        dt = self.dtype
+        emb = embedding.to(self.dev, torch.float32).contiguous()
+        en = self._new(1, self.spk_dim)
+        # F.normalize(embedding, dim=1) == rmsnorm with gamma 1/sqrt(d) and eps -> 0
+        ops.rownorm(emb, self.spk_gamma, None, 1e-30, rows=1, C_=self.spk_dim, rms=True, out_act=en, dtype=dt)
+        spks = self._new(1, 80, f32=True)
+        ops.linear(en, self.spk_w, self.spk_dim, dtype=dt, bias=self.spk_b, out_f32=spks)
+        ids = torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).to(self.dev, torch.int64)
+        mu = self.encode(ids, finalize, streaming)
+        T = mu.shape[0]
+        mel_len1 = prompt_feat.shape[1]
+        cond = torch.zeros(T, 80, device=self.dev)
+        if mel_len1:
+            cond[:mel_len1].copy_(prompt_feat[0].to(self.dev, torch.float32))
+        x = self.cfm(mu, spks, cond, streaming)
+        return x[mel_len1:]
+
+    @torch.no_grad()
+    def inference(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):
+        """Reference layout: returns feat [1, 80, T2] fp32 (flow.py:509-511)."""
+        x = self.inference_time_major(token, prompt_token, prompt_feat, embedding, streaming, finalize)
+        T2 = x.shape[0]
+        out = torch.empty(1, 80, T2, dtype=torch.float32, device=self.dev)
+        ops.copy2d(x, F32, 0, 80, 1, out, F32, 0, 1, T2, rows=T2, cols=80)
+        return out

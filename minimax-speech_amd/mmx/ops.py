@@ -101,11 +101,11 @@ def convtranspose1d(x, Wp, *, T, Cin, Cout, stride, dtype, batch=1, bias=None, a
 
 # ----------------------------------------------------------------------------- row-wise / elementwise
 def rownorm(x, gamma, beta, eps, *, rows, C_, batch=1, x_bstride=None, rms=False, act="none", rowmask=None,
-            addvec=None, out_f32=None, out_act=None, dtype=F32, ldx=None):
+            addvec=None, av_bstride=None, out_f32=None, out_act=None, dtype=F32, ldx=None):
     ldx = C_ if ldx is None else ldx
     xb = rows * ldx if x_bstride is None else x_bstride
     check(load().mmx_rownorm(_p(x), i64(ldx), i64(xb), rows, C_, batch, _p(gamma), _p(beta), C.c_float(eps), int(rms),
-                             ACT[act], _p(rowmask), i64(rows), _p(addvec), i64(C_),
+                             ACT[act], _p(rowmask), i64(rows), _p(addvec), i64(C_ if av_bstride is None else av_bstride),
                              _p(out_f32), i64(C_), i64(rows * C_), _p(out_act), i64(C_), i64(rows * C_),
                              dtype, stream()), "mmx_rownorm")
 
@@ -121,8 +121,8 @@ def copy2d(src, src_dt, ibs, irs, ics, dst, dst_dt, obs, ors, ocs, rows, cols, b
                             i64(ocs), rows, cols, batch, stream()), "mmx_copy2d")
 
 
-def est_pack(x, mu, spks, cond, h, *, B, T, dtype):
-    check(load().mmx_est_pack(_p(x), _p(mu), _p(spks), _p(cond), B, T, 80, _p(h), i64(h.shape[-1]), dtype, stream()),
+def est_pack(x, mu, spks, cond, h, *, B, T, dtype, x_bstride=None):
+    check(load().mmx_est_pack(_p(x), i64(T * 80 if x_bstride is None else x_bstride), _p(mu), _p(spks), _p(cond), B, T, 80, _p(h), i64(h.shape[-1]), dtype, stream()),
           "mmx_est_pack")
 
 
