@@ -173,7 +173,8 @@ int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* out, int64_
 
 /* Sampler = log_softmax + ras_sampling + sampling_ids + the loop bookkeeping of inference_wrapper
  * (llm.py:259-274,751-760; utils/common.py:111-139), one workgroup per sequence, all state on device:
- *   state[b] = {pos, step, n_out, finished, min_len, max_len, seq_id, _}  (int32 x 8)
+ *   state[field * B + b], fields {0 pos, 1 step, 2 n_out, 3 finished, 4 min_len, 5 max_len, 6 seq_id, 7 error}
+ *   (int32, field-major so that &state[0] is the pos[] array the attention kernels read)
  * Draws follow oracle/philox.py (Philox4x32-10 keyed by seed; exponential race == torch.multinomial).
  * On an accepted token: appended to out_tokens[b][n_out++], next_x[b][:] = speech_emb[token][:].
  * EOS (== eos_id) sets finished; ids > eos_id leave next_x unchanged (llm.py:755-756).

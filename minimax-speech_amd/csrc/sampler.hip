@@ -83,8 +83,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     __shared__ int cand_i[SAMP_MAXK];
     __shared__ int sh_n, sh_top;
     const int b = blockIdx.x, tid = threadIdx.x;
-    int32_t* st = state + b * 8;
-    const int pos = st[0], step = st[1], n_out = st[2], finished = st[3], min_len = st[4], seq = st[6];
+    const int nb = gridDim.x;                          // state is field-major: state[field * B + b]
+    int32_t* st = state + b;
+#define ST(f) st[(f) * nb]
+    const int pos = ST(0), step = ST(1), n_out = ST(2), finished = ST(3), min_len = ST(4), seq = ST(6);
     if (finished) return;                              // uniform per block
     const float* lg = logits + (long)b * ldl;
 
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
             top = r.i;
         }
         if (!ignore_eos || top != eos_id) break;
-        if (trial >= 100) { if (tid == 0) st[7] = 1; break; }    // llm.py:271-273 raises here; flag + accept
+        if (trial >= 100) { if (tid == 0) ST(7) = 1; break; }    // llm.py:271-273 raises here; flag + accept
     }
     if (tid == 0) {
         if (sampled) sampled[(long)b * max_out + step] = top;
@@ -178,14 +180,15 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     __syncthreads();
     top = sh_top;
     if (top == eos_id) {
-        if (tid == 0) { st[3] = 1; st[1] = step + 1; }
+        if (tid == 0) { ST(3) = 1; ST(1) = step + 1; }
         return;
     }
     if (top < eos_id) {
         for (int c = tid; c < E; c += SAMP_THREADS) next_x[(long)b * ldx + c] = speech_emb[(long)top * E + c];
-        if (tid == 0) { out_tokens[(long)b * max_out + n_out] = top; st[2] = n_out + 1; }
+        if (tid == 0) { out_tokens[(long)b * max_out + n_out] = top; ST(2) = n_out + 1; }
     }
-    if (tid == 0) { st[0] = pos + 1; st[1] = step + 1; }
+    if (tid == 0) { ST(0) = pos + 1; ST(1) = step + 1; }
+#undef ST
 }
 
 extern "C" int mmx_sample_step(const float* logits, int64_t ldl, int V, int B, int eos_id, int top_k, float top_p,

@@ -1,0 +1,187 @@
+"""Autoregressive speech-token LM engine (Qwen2-0.5B-shaped backbone + CosyVoice2 heads) on libmmx_hip kernels.
+
+Reference (speech/): cosyvoice/llm/llm.py:676-711 (Qwen2LM.inference), :745-760 (inference_wrapper AR loop),
+:359-371 (forward_one_step -> HF Qwen2ForCausalLM hidden_states[-1]), :259-274 (sampling_ids),
+cosyvoice/utils/common.py:111-139 (ras/nucleus/random sampling).
+
+One decode step for a batch of B sequences is 6 launches per layer (RMSNorm-folded QKV projection, RoPE + paged KV
+append, paged GQA attention, o_proj + residual, RMSNorm-folded gate/up + SwiGLU, down + residual) + logits + the
+device-resident sampler; it is recorded once into a hipGraph and replayed per token, with all loop state
+(positions, step counters, token history, next input embedding, finished flags) on the device — the host only
+polls `finished` every few steps (the reference syncs on .item() every token, llm.py:752).
+Attention is full causal over the KV cache (SURVEY.md §7 "version-drift trap").
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from ._lib import BF16, F32, TORCH_DT
+from .flow import Graphed
+
+ST_POS, ST_STEP, ST_NOUT, ST_FIN, ST_MINLEN, ST_MAXLEN, ST_SEQ, ST_ERR = range(8)
+
+
+class LlmEngine:
+    def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
+                 heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
+                 prefix="llm.model.model"):
+        self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.Hq, self.Hkv, self.D, self.eps = heads, kv_heads, head_dim, eps
+        self.page, self.use_graphs = page, use_graphs
+        self.eos = speech_token_size
+        self.V = speech_token_size + 3
+        dt = dtype
+        f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
+        c = lambda t: t.to(self.tdt).contiguous()
+        self.n_layers = len({k.split(".")[4] for k in sd if k.startswith(prefix + ".layers.")})
+        self.H = sd[prefix + ".norm.weight"].shape[0]
+        self.I = sd[prefix + ".layers.0.mlp.gate_proj.weight"].shape[0]
+        self.layers = []
+        for l in range(self.n_layers):
+            p = f"{prefix}.layers.{l}"
+            a = p + ".self_attn"
+            wqkv = torch.cat([f(a + ".q_proj.weight"), f(a + ".k_proj.weight"), f(a + ".v_proj.weight")], 0)
+            bqkv = torch.cat([f(a + ".q_proj.bias"), f(a + ".k_proj.bias"), f(a + ".v_proj.bias")], 0).contiguous()
+            wgu = torch.cat([f(p + ".mlp.gate_proj.weight"), f(p + ".mlp.up_proj.weight")], 0)
+            self.layers.append(dict(
+                wqkv=ops.pack_skinny(c(wqkv), dtype=dt, kscale=f(p + ".input_layernorm.weight")), bqkv=bqkv,
+                wo=ops.pack_skinny(c(f(a + ".o_proj.weight")), dtype=dt),
+                wgu=ops.pack_skinny(c(wgu), dtype=dt, kscale=f(p + ".post_attention_layernorm.weight"), interleave_half=self.I),
+                wdown=ops.pack_skinny(c(f(p + ".mlp.down_proj.weight")), dtype=dt)))
+            del wqkv, wgu
+        self.wdec = ops.pack_skinny(c(f("llm_decoder.weight")), dtype=dt, kscale=f(prefix + ".norm.weight"))
+        self.bdec = f("llm_decoder.bias")
+        self.embed_tokens = f(prefix + ".embed_tokens.weight")
+        self.speech_emb = f("speech_embedding.weight")
+        self.llm_emb = f("llm_embedding.weight")
+        # HF Qwen2RotaryEmbedding inv_freq (modeling_qwen2.py: 1 / theta^(arange(0,d,2)/d)), computed like HF in fp32
+        self.inv_freq = (1.0 / (rope_theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))).to(self.dev)
+        # paged KV cache: [layers][pages][Hkv][page][D]; sequence b owns table row b (static allocation for now)
+        self.B = max_batch
+        self.max_pages = (max_ctx + page - 1) // page
+        npages = self.B * self.max_pages
+        self.kc = torch.zeros(self.n_layers, npages, kv_heads, page, head_dim, dtype=self.tdt, device=self.dev)
+        self.vc = torch.zeros_like(self.kc)
+        self.block_table = torch.arange(npages, dtype=torch.int32, device=self.dev).reshape(self.B, self.max_pages).contiguous()
+        self.max_out = max_ctx
+        B = self.B
+        self.state = torch.zeros(8, B, dtype=torch.int32, device=self.dev)
+        self.out_tokens = torch.zeros(B, self.max_out, dtype=torch.int32, device=self.dev)
+        self.sampled = torch.full((B, self.max_out), -1, dtype=torch.int32, device=self.dev)
+        self.forced, self._forced_buf = None, None
+        self.x_in = torch.zeros(B, self.H, device=self.dev)         # next input embedding (written by the sampler)
+        self.h = torch.zeros(B, self.H, device=self.dev)            # residual stream of the step
+        self.logits = torch.zeros(B, self.V, device=self.dev)
+        self.logp = torch.zeros(B, self.V, device=self.dev)
+        self.want_logp = False
+        self.seed = 0
+        self._decode = None
+
+    # ------------------------------------------------------------------ one transformer pass over `rows` tokens/seq
+    def _layers(self, h, B, rows, pos, block_table):
+        """h fp32 [B*rows, H] residual stream (in place). pos int32 [B] device, block_table [B, max_pages]."""
+        dt, H, I = self.dtype, self.H, self.I
+        n = B * rows
+        assert n <= 64
+        qkv = torch.empty(n, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
+        q = torch.empty(n, self.Hq * self.D, dtype=self.tdt, device=self.dev)
+        att = torch.empty(n, self.Hq * self.D, dtype=self.tdt, device=self.dev)
+        act = torch.empty(n, I, dtype=self.tdt, device=self.dev)
+        for l, w in enumerate(self.layers):
+            ops.skinny_gemm(h, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True, eps=self.eps,
+                            epi=0, out_f32=qkv)
+            ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=rows,
+                              Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
+            ops.paged_attn(q, pos, self.kc[l], self.vc[l], block_table, att, B=B, rows=rows, Hq=self.Hq, Hkv=self.Hkv,
+                           page=self.page, dtype=dt)
+            ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h)
+            ops.skinny_gemm(h, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act)
+            ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h)
+
+    def _tail(self, B):
+        """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences."""
+        ops.skinny_gemm(self.h, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
+                        eps=self.eps, epi=0, out_f32=self.logits)
+        ops.sample_step(self.logits, self.state, self.out_tokens, self.speech_emb, self.x_in, V=self.V, B=B,
+                        eos_id=self.eos, seed=self.seed, sampled=self.sampled, forced=self.forced,
+                        logp_out=(self.logp if self.want_logp else None))
+
+    def _decode_step(self):
+        B = self.B
+        self.h.copy_(self.x_in)
+        self._layers(self.h, B, 1, self.state[ST_POS], self.block_table)
+        self._tail(B)
+
+    # ------------------------------------------------------------------ request setup
+    def build_lm_input(self, text, prompt_text, prompt_speech_token):
+        """llm.py:691-703: [sos | embed(prompt_text ++ text) | task_id | speech_emb(prompt_speech)] fp32 [L, H]."""
+        tok = torch.cat([prompt_text.reshape(-1), text.reshape(-1)]).to(self.dev, torch.int64)
+        L = 2 + tok.numel() + prompt_speech_token.numel()
+        x = torch.empty(L, self.H, device=self.dev)
+        x[0].copy_(self.llm_emb[0])
+        ops.gather_rows(tok, self.embed_tokens, out_f32=x[1:1 + tok.numel()], dtype=F32)
+        x[1 + tok.numel()].copy_(self.llm_emb[1])
+        if prompt_speech_token.numel():
+            ops.gather_rows(prompt_speech_token.reshape(-1).to(self.dev, torch.int64), self.speech_emb,
+                            out_f32=x[2 + tok.numel():], dtype=F32)
+        return x
+
+    def start(self, lm_inputs: List[torch.Tensor], min_lens: List[int], max_lens: List[int], seed=0, seq_ids=None,
+              forced: Optional[torch.Tensor] = None, want_logp=False):
+        """Prefills every sequence (prompt rows in chunks of <= 64 through the same kernels as decode) and samples
+        the first token of each.  After this, call step()/run()."""
+        B = self.B
+        assert len(lm_inputs) == B
+        self.seed, self.want_logp = int(seed), want_logp
+        if forced is not None:
+            if self._forced_buf is None:
+                self._forced_buf = torch.zeros(B, self.max_out, dtype=torch.int32, device=self.dev)
+            self._forced_buf[:, :forced.shape[1]].copy_(forced.to(torch.int32))
+            self.forced = self._forced_buf
+        else:
+            self.forced = None
+        st = torch.zeros(8, B, dtype=torch.int32)
+        for b in range(B):
+            st[ST_MINLEN, b], st[ST_MAXLEN, b] = min_lens[b], max_lens[b]
+            st[ST_SEQ, b] = b if seq_ids is None else seq_ids[b]
+        self.state.copy_(st)
+        self.sampled.fill_(-1)
+        for b, x in enumerate(lm_inputs):
+            L = x.shape[0]
+            assert L + max_lens[b] <= self.max_pages * self.page, "sequence exceeds the KV cache"
+            x = x.to(self.dev, torch.float32).contiguous()
+            for c0 in range(0, L, 64):
+                c1 = min(L, c0 + 64)
+                hc = x[c0:c1].clone()
+                pos = torch.tensor([c0], dtype=torch.int32, device=self.dev)
+                self._layers(hc, 1, c1 - c0, pos, self.block_table[b:b + 1])
+            self.h[b].copy_(hc[-1])
+            self.state[ST_POS, b] = L - 1                # the sampler's +1 makes it L (= rows in the cache)
+        self._tail(B)
+        if self._decode is None:
+            self._decode = Graphed(self._decode_step, self.use_graphs)
+        elif self._graph_key != (self.forced is None, want_logp, self.seed):
+            self._decode = Graphed(self._decode_step, self.use_graphs)      # baked arguments changed: re-record
+        self._graph_key = (self.forced is None, want_logp, self.seed)
+
+    def step(self):
+        self._decode()
+
+    def run(self, max_steps: int, poll_every: int = 8) -> List[List[int]]:
+        """Decode until every sequence finished or max_steps tokens were tried; returns accepted tokens per sequence."""
+        done = 1                                          # start() already sampled step 0
+        while done < max_steps:
+            n = min(poll_every, max_steps - done)
+            for _ in range(n):
+                self._decode()
+            done += n
+            if bool(self.state[ST_FIN].all().item()):
+                break
+        return self.tokens()
+
+    def tokens(self) -> List[List[int]]:
+        n = self.state[ST_NOUT].tolist()
+        t = self.out_tokens.cpu()
+        return [t[b, :n[b]].tolist() for b in range(self.B)]

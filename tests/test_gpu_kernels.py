@@ -299,7 +299,7 @@ def test_sampler_matches_oracle(env):
             logits[0, eos] = logits.max() + 2.0              # make EOS dominant -> exercises the re-draw loop
         step = s
         min_len = step + 1 if s % 2 == 0 else 0              # ignore_eos on even cases
-        state = torch.tensor([[40, step, len(hist), 0, min_len, 999, 3, 0]], dtype=torch.int32).cuda()
+        state = torch.tensor([40, step, len(hist), 0, min_len, 999, 3, 0], dtype=torch.int32).cuda()   # field-major, B = 1
         out_tokens = torch.zeros(1, 64, dtype=torch.int32)
         out_tokens[0, :len(hist)] = torch.tensor(hist, dtype=torch.int32)
         out_tokens = out_tokens.cuda()
@@ -313,7 +313,7 @@ def test_sampler_matches_oracle(env):
         assert (lp[0].cpu() - lpo).abs().max() < 1e-4
         want = OL.sampling_ids_e(lpo, hist, lambda k: OL.philox_noise(seed, 3, step, k), ignore_eos=step < min_len, eos=eos)
         mism += got != want
-        st = state.cpu()[0].tolist()
+        st = state.cpu().tolist()
         if want == eos:
             assert st[3] == 1
         elif want < eos:
