@@ -1,0 +1,180 @@
+"""bench.py — headline benchmark of the TTS hot path (BASELINE.json metric: 24 kHz audio-seconds per wall-second
+per node, + RTF), CosyVoice2-0.5B-shaped models, random-init weights, synthetic inputs.
+
+One "step" = one full pass of the path over the rank's batch: AR LM decode (text ids -> FSQ tokens), flow-matching
+decoder (tokens -> latents, 10 Euler steps, CFG), DAC-VAE decoder (latents -> 24 kHz waveform) and, for N > 1, the
+RCCL all-gather of the generated audio.  Inputs are resident on the device before the timed region.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "minimax-speech_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_weights(seed=0):
+    from mmx import shapes, synth
+    return (synth.synth_state_dict(shapes.llm_manifest(), seed), synth.synth_state_dict(shapes.flow_manifest(), seed),
+            synth.synth_state_dict(shapes.dac_decoder_manifest(80), seed))
+
+
+def measure_dominant_kernel(eng, iters=200):
+    """Roofline of the dominant kernel of the step: the weight-streaming skinny GEMM of the LM decode
+    (gate/up projection + SwiGLU instance: the largest of the 4 per layer).  Timed live with HIP events on the
+    stream the kernel is launched on.  Algorithmic bytes per launch = its bf16 weight matrix (2 x 4864 x 896 x 2 B)
+    + the fp32 input row and the bf16 output row."""
+    from mmx import ops
+    llm = eng.llm
+    w = llm.layers[0]
+    B, H, I = llm.B, llm.H, llm.I
+    h = torch.randn(B, H, device=llm.dev)
+    act = torch.empty(B, I, dtype=llm.tdt, device=llm.dev)
+    esz = 2 if llm.dtype == 1 else 4
+    nbytes = 2 * I * H * esz + B * H * 4 + B * I * esz
+    # rotate over all layers' weights so the 256 MiB Infinity Cache cannot serve the stream
+    s = torch.cuda.current_stream()
+    for l in range(llm.n_layers):
+        ops.skinny_gemm(h, llm.layers[l]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps, epi=1, out_act=act)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for i in range(iters):
+        ops.skinny_gemm(h, llm.layers[i % llm.n_layers]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps,
+                        epi=1, out_act=act)
+    e1.record(s)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    achieved = nbytes / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "skinny_gemm_kernel (gate/up + SwiGLU, K=896, N=2x4864)", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
+
+
+def cpu_baseline():
+    """The CPU oracle (port of the reference algorithm, oracle/*.py) timed on this host's cores on a bounded
+    sample of the same workload: 16 LM decode steps (after a 50-row prefill), the flow on 25 tokens (50 frames,
+    10 Euler steps) and the DAC decoder on 50 frames; per-stage cost is scaled to a 10 s utterance."""
+    from oracle import dac as ODAC, flow as OFLOW, llm as OLLM
+    from mmx import shapes, synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    llm_sd, flow_sd, dac_sd = build_weights(0)
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        cfg = OLLM.QwenCfg()
+        x = OLLM.build_lm_input(llm_sd, torch.randint(0, 151936, (1, 48), generator=g), torch.zeros(1, 0, dtype=torch.long),
+                                torch.zeros(1, 0, dtype=torch.long))
+        y, cache = OLLM.qwen2_forward(llm_sd, cfg, x, None)
+        t0 = time.time()
+        for i in range(16):
+            y, cache = OLLM.qwen2_forward(llm_sd, cfg, llm_sd["speech_embedding.weight"][i].reshape(1, 1, -1), cache)
+            torch.nn.functional.linear(y[:, -1], llm_sd["llm_decoder.weight"], llm_sd["llm_decoder.bias"]).log_softmax(-1)
+        t_tok = (time.time() - t0) / 16
+        tok = torch.randint(0, 6561, (1, 25), generator=g)
+        t0 = time.time()
+        OFLOW.flow_inference(flow_sd, tok, torch.zeros(1, 0, dtype=torch.long), torch.zeros(1, 0, 80), torch.randn(1, 192, generator=g))
+        t_flow = time.time() - t0                              # 1 s of audio
+        t0 = time.time()
+        ODAC.decode(dac_sd, torch.randn(1, 80, 50, generator=g), [5, 4, 4, 3, 2])
+        t_dac = time.time() - t0                               # 1 s of audio
+    per_audio_s = 25 * t_tok + t_flow + t_dac
+    return {"value": round(1.0 / per_audio_s, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
+            "sample": "oracle: 16 LM decode steps + flow on 25 tokens (10 Euler steps) + DAC on 50 frames, scaled per audio-second",
+            "llm_s_per_token": round(t_tok, 4), "flow_s_per_audio_s": round(t_flow, 3), "dac_s_per_audio_s": round(t_dac, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from mmx.pipeline import TtsEngine, TOKEN_RATE, SAMPLE_RATE
+    dt = 1 if a.dtype == "bf16" else 0
+    llm_sd, flow_sd, dac_sd = build_weights(0)
+    eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=dt, device=f"cuda:{local}", max_batch=1, max_ctx=1024)
+    del llm_sd, flow_sd, dac_sd
+    # BASELINE config 3 / SURVEY §8d.3: 48 random text ids, no prompt, exactly 250 decode steps (a 10 s utterance)
+    g = torch.Generator().manual_seed(2 + rank)
+    text = torch.randint(0, 151936, (1, 48), generator=g).cuda()
+    emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).cuda()
+    NTOK = 250
+    max_samples = 2 * NTOK * eng.hop
+    gather_buf = torch.zeros(world, max_samples, device="cuda") if world > 1 else None
+    mine = torch.zeros(max_samples, device="cuda")
+
+    def step():
+        wav = eng.tts(text, emb, seed=rank, exact_steps=NTOK)
+        n = wav.shape[-1]
+        if world > 1:
+            mine.zero_()
+            mine[:n].copy_(wav.reshape(-1))
+            dist.all_gather_into_tensor(gather_buf, mine)
+        return n
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(a.steps):
+        samples += step()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        tot = torch.tensor([samples], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tot)
+        samples = float(tot.item())
+    audio_s = samples / SAMPLE_RATE
+    if rank == 0:
+        out = {"metric": "24 kHz audio-seconds generated per wall-second per node (CosyVoice2-0.5B-shaped LM + flow + DAC-VAE, end to end)",
+               "value": round(audio_s / el, 3), "unit": "audio_s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic text ids, random-init weights (deterministic synth init)",
+               "rtf": round(el / audio_s * world, 5),
+               "config": {"workload": "BASELINE config 3: one 10 s utterance per GPU per step (48 text ids, 250 AR decode steps, "
+                                      "flow 500 frames x 10 Euler steps with CFG, DAC 240000 samples)",
+                          "utterances_per_gpu": 1, "tokens": NTOK, "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
+        if world == 1:
+            out["roofline"] = measure_dominant_kernel(eng)
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,8 +37,9 @@ def test_teacher_forced_logp_vs_reference_golden(llm_sd, gold, dt, tol):
         eng.step()
         errs.append((eng.logp[0] - t("logp")[i + 1]).abs().max().item())
     assert max(errs) < tol, errs
-    # argmax agreement (bf16 may flip near-ties; report through the assertion message)
-    assert eng.tokens()[0] == gold["forced"].tolist()
+    print(f"dtype {dt}: max |dlogp| over 17 steps = {max(errs):.3e}")
+    # teacher forcing: the accepted history is the forced one (17th step reads the zero padding of `forced`)
+    assert eng.tokens()[0][:16] == gold["forced"].tolist()
 
 
 def test_free_running_token_ids_match_oracle_fp32(llm_sd):
