@@ -177,19 +177,30 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     }
     bf16_t* Pw = Ps + wave * 16 * LD;
 
-    for (int j0 = 0; j0 < kend; j0 += KT) {
-        __syncthreads();                               // previous tile fully consumed
+    // register-staged prefetch: the next K / V^T tile is loaded while the current one is multiplied
+    uint4 kreg[2], vreg[2];
+    auto load_tiles = [&](int j0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int id = tid + i * 256;                    // 512 chunks of 16 B per tile
             int r = id >> 3, c = (id & 7) * 8;
             int key = j0 + r;
-            uint4 kv = key < Tn ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(Ks + r * LD + c) = kv;
+            kreg[i] = key < Tn ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
             // V^T rows are d; columns j0 + c .. +7 (buffer is zero padded to a multiple of 8 columns)
-            uint4 vv = (j0 + c < Tn) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(Vs + r * LD + c) = vv;
+            vreg[i] = (j0 + c < Tn) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
         }
+    };
+    load_tiles(0);
+    for (int j0 = 0; j0 < kend; j0 += KT) {
+        __syncthreads();                               // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int id = tid + i * 256;
+            int r = id >> 3, c = (id & 7) * 8;
+            *reinterpret_cast<uint4*>(Ks + r * LD + c) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs + r * LD + c) = vreg[i];
+        }
+        if (j0 + KT < kend) load_tiles(j0 + KT);
         __syncthreads();
         // S = Q K^T  (4 key fragments of 16)
         float4_t s[4];

@@ -20,6 +20,7 @@
 // so no elementwise kernel ever round-trips HBM between two convs.
 #include "common.h"
 #include "gemm.h"
+#include <utility>
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
@@ -65,17 +66,21 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         a_tap[i] = k / p.cin;
         a_c[i] = k % p.cin;
     }
-    uint4 a_reg[A_CHUNKS], w_reg[W_CHUNKS];
+    // register-staged prefetch ring: STAGES k-tiles of global loads in flight per workgroup (these GEMMs are
+    // short-K and latency bound: M ~ 500-1000 rows, K = 256..1024), 2 LDS buffers, one barrier per k-tile
+    constexpr int STAGES = sizeof(T) == 2 ? 4 : 2;
+    uint4 a_reg[STAGES][A_CHUNKS], w_reg[STAGES][W_CHUNKS];
     const int K = p.ntaps * p.cin;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             int m = m0 + a_row[i];
             long srow = (long)m + (long)a_tap[i] * p.dil + p.row_off;
             bool ok = (m < p.M) && (a_tap[i] < p.ntaps) && (srow >= p.row_lo) && (srow < p.row_hi);
             if (!A_FULL) ok = ok && (tid + i * 256 < BM * CPR);
-            a_reg[i] = ok ? *reinterpret_cast<const uint4*>(A + srow * p.lda + a_c[i]) : make_uint4(0, 0, 0, 0);
+            a_reg[slot][i] = ok ? *reinterpret_cast<const uint4*>(A + srow * p.lda + a_c[i]) : make_uint4(0, 0, 0, 0);
             a_c[i] += BK;
             while (a_c[i] >= p.cin) { a_c[i] -= p.cin; a_tap[i]++; }
         }
@@ -84,22 +89,23 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
             int id = tid + i * 256;
             int r = id / CPR, kc = (id % CPR) * CH;
             int n = n0 + r;
-            w_reg[i] = (n < p.N && (W_FULL || id < BN * CPR)) ? *reinterpret_cast<const uint4*>(W + (long)n * p.ldw + kt * BK + kc)
+            w_reg[slot][i] = (n < p.N && (W_FULL || id < BN * CPR)) ? *reinterpret_cast<const uint4*>(W + (long)n * p.ldw + kt * BK + kc)
                                  : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tile = [&](int stage) {
+    auto store_tile = [&](int stage, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             int id = tid + i * 256;
             if (A_FULL || id < BM * CPR)
-                *reinterpret_cast<uint4*>(As + (stage * BM + id / CPR) * LR + (id % CPR) * CH) = a_reg[i];
+                *reinterpret_cast<uint4*>(As + (stage * BM + id / CPR) * LR + (id % CPR) * CH) = a_reg[slot][i];
         }
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
             int id = tid + i * 256;
             if (W_FULL || id < BN * CPR)
-                *reinterpret_cast<uint4*>(Ws + (stage * BN + id / CPR) * LR + (id % CPR) * CH) = w_reg[i];
+                *reinterpret_cast<uint4*>(Ws + (stage * BN + id / CPR) * LR + (id % CPR) * CH) = w_reg[slot][i];
         }
     };
 
@@ -110,12 +116,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         for (int j = 0; j < NF; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (K + BK - 1) / BK;                  // W is zero padded to nk*BK columns (ldw >= nk*BK)
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&](int st) {
         const T* as = As + (st * BM + wm * (BM / WM) + l16) * LR;
         const T* ws = Ws + (st * BN + wn * (BN / WN) + l16) * LR;
         if constexpr (sizeof(T) == 2) {
@@ -146,8 +147,24 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bfr[j][s], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) store_tile(st ^ 1);
-        __syncthreads();
+    };
+    auto for_each_slot = [&](auto&& fn) {
+        [&]<int... S>(std::integer_sequence<int, S...>) { (fn(std::integral_constant<int, S>{}), ...); }
+        (std::make_integer_sequence<int, STAGES>{});
+    };
+    // prologue: tiles 0 .. STAGES-1 in flight (load_tile advances the (tap, c) trackers in tile order)
+    for_each_slot([&](auto sc) { if (decltype(sc)::value < nk) load_tile(decltype(sc)::value, sc); });
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+        for_each_slot([&](auto sc) {
+            const int kt = kt0 + decltype(sc)::value;
+            if (kt < nk) {                             // uniform
+                // LDS[kt&1] was last read by compute(kt-2); every wave passed barrier(kt-1) after finishing it
+                store_tile(kt & 1, sc);
+                if (kt + STAGES < nk) load_tile(kt + STAGES, sc);
+                __syncthreads();
+                compute(kt & 1);
+            }
+        });
     }
 
     // ------------------------------------------------------------------ fused epilogue

@@ -50,9 +50,13 @@ extern "C" int mmx_pack_skinny(const void* w, int64_t ldw, int N, int K, const f
 }
 
 // ------------------------------------------------------------------------------------------ skinny GEMM
-// wave -> (output tile of 16 columns [x2 for SwiGLU], k slice); MT = row tiles of 16 (B <= 16*MT)
-template <typename T, typename TX, int MT, int EPI>
-__global__ void skinny_gemm_kernel(const TX* __restrict__ x, long ldx, int B, int K, int N,
+// wave -> (output tile of 16 columns [x2 for SwiGLU], k slice); MT = row tiles of 16 (B <= 16*MT).
+// The whole problem is latency bound (a projection is 1.6 - 17 MB, a single HBM round trip is ~1-2 us), so
+// bandwidth comes from bytes in flight: every wave issues ALL the weight loads of its k slice (<= KS k-blocks,
+// 1 KiB per wave-instruction) back to back into registers before the first MFMA, and the k split is chosen so
+// that a slice fits (skinny_launch_mt below).
+template <typename T, typename TX, int MT, int EPI, int KS>
+__global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__ x, long ldx, int B, int K, int N,
                                    const T* __restrict__ wp, const float* __restrict__ bias, int rs, float eps,
                                    float* __restrict__ outf, long ldo_f, T* __restrict__ outa, long ldo_a,
                                    int ksplit, int ntiles) {
@@ -60,6 +64,8 @@ __global__ void skinny_gemm_kernel(const TX* __restrict__ x, long ldx, int B, in
     constexpr int E = BF ? 8 : 4;
     constexpr int KB = E * 4;
     constexpr int NB = EPI == 1 ? 2 : 1;               // B fragments per wave
+    constexpr int XV = sizeof(TX) == 4 ? E / 4 : 1;    // 16-byte loads per A fragment
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);       // [waves][NB*MT*4 + MT] x 64 lanes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,56 +90,75 @@ __global__ void skinny_gemm_kernel(const TX* __restrict__ x, long ldx, int B, in
 
     if (active) {
         const T* wbase = wp + ((long)tile * NB * nkb) * 64 * E + (long)lane * E;
-#pragma unroll 4
-        for (int kb = kb0; kb < kb1; ++kb) {
-            // weight fragments: contiguous 1 KiB (bf16) per wave-instruction
-            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-            u32x4_t wf[NB];
+        for (int kc = kb0; kc < kb1; kc += KS) {
+            // (1) the whole weight slice in flight
+            u32x4_t wf[KS][NB];
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
-                wf[n] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wbase + ((long)n * nkb + kb) * 64 * E));
+            for (int i = 0; i < KS; ++i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int row = m * 16 + l16;
-                float xv[E];
-                if (row < B) {
-                    const TX* xp = x + (long)row * ldx + kb * KB + g * E;
+                for (int n = 0; n < NB; ++n)
+                    if (kc + i < kb1)
+                        wf[i][n] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wbase + ((long)n * nkb + kc + i) * 64 * E));
+            // (2) activations (L2 resident): for one row tile they are prefetched too
+            u32x4_t xr[MT == 1 ? KS : 1][XV];
+            if constexpr (MT == 1) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i)
+#pragma unroll
+                    for (int v = 0; v < XV; ++v)
+                        xr[i][v] = (kc + i < kb1 && l16 < B)
+                                       ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(x + (long)l16 * ldx + (kc + i) * KB + g * E) + v * 16)
+                                       : u32x4_t{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                if (kc + i >= kb1) continue;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float xv[E];
+                    u32x4_t raw[XV];
+                    if constexpr (MT == 1) {
+#pragma unroll
+                        for (int v = 0; v < XV; ++v) raw[v] = xr[i][v];
+                    } else {
+                        const int row = m * 16 + l16;
+#pragma unroll
+                        for (int v = 0; v < XV; ++v)
+                            raw[v] = row < B ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(x + (long)row * ldx + (kc + i) * KB + g * E) + v * 16)
+                                             : u32x4_t{0, 0, 0, 0};
+                    }
                     if constexpr (sizeof(TX) == 4) {
 #pragma unroll
-                        for (int e4 = 0; e4 < E / 4; ++e4) {
-                            float4 t4 = *reinterpret_cast<const float4*>(xp + e4 * 4);
-                            xv[e4 * 4 + 0] = t4.x; xv[e4 * 4 + 1] = t4.y; xv[e4 * 4 + 2] = t4.z; xv[e4 * 4 + 3] = t4.w;
+                        for (int e = 0; e < E; ++e) xv[e] = __uint_as_float(raw[e / 4][e % 4]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) xv[e] = __uint_as_float((raw[0][e / 2] >> ((e & 1) * 16)) << 16);
+                    }
+                    if (rs) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) ssq[m] += xv[e] * xv[e];
+                    }
+                    if constexpr (BF) {
+                        short8_t af;
+                        if constexpr (sizeof(TX) == 2) {
+                            af = *reinterpret_cast<const short8_t*>(&raw[0]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) af[e] = (short)f2bf(xv[e]);
+                        }
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) {
+                            short8_t bfr = *reinterpret_cast<const short8_t*>(&wf[i][n]);
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[n][m], 0, 0, 0);
                         }
                     } else {
-                        uint4 t4 = *reinterpret_cast<const uint4*>(xp);
-                        const bf16_t* hp = reinterpret_cast<const bf16_t*>(&t4);
 #pragma unroll
-                        for (int e = 0; e < E; ++e) xv[e] = bf2f(hp[e]);
-                    }
-                } else {
+                        for (int n = 0; n < NB; ++n) {
+                            float4_t bfr = *reinterpret_cast<const float4_t*>(&wf[i][n]);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) xv[e] = 0.f;
-                }
-                if (rs) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) ssq[m] += xv[e] * xv[e];
-                }
-                if constexpr (BF) {
-                    short8_t af;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) af[e] = (short)f2bf(xv[e]);
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) {
-                        short8_t bfr = *reinterpret_cast<const short8_t*>(&wf[n]);
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[n][m], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) {
-                        float4_t bfr = *reinterpret_cast<const float4_t*>(&wf[n]);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], bfr[s], acc[n][m], 0, 0, 0);
+                            for (int s2 = 0; s2 < 4; ++s2)
+                                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s2], bfr[s2], acc[n][m], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -210,18 +235,20 @@ template <typename T, typename TX, int EPI>
 static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, int rs,
                             float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s) {
     constexpr int KB = sizeof(T) == 2 ? 32 : 16;
+    constexpr int KS = 10;                             // k-blocks a wave keeps in flight (registers)
     const int ntiles = (N + 15) / 16;                  // for EPI==1, N is the activation width I
     const int nkb = K / KB;
-    // choose the k split so that ~>= 256 waves stream weights and each wave keeps >= 4 k blocks
+    // smallest power-of-two k split (<= 8 waves = 512 threads per workgroup, so a wave may use 256 VGPRs) whose
+    // slice fits KS blocks; a longer slice is walked in chunks of KS
     int ksplit = 1;
-    while (ksplit < 16 && (long)ntiles * ksplit < 512 && nkb / (ksplit * 2) >= 4) ksplit *= 2;
+    while (ksplit < 8 && (nkb + ksplit - 1) / ksplit > KS) ksplit *= 2;
     int waves = ksplit >= 4 ? ksplit : 4;
     int tpb = waves / ksplit;
     dim3 grid((ntiles + tpb - 1) / tpb), block(waves * 64);
     const int mt = (B + 15) / 16;
     constexpr int NB = EPI == 1 ? 2 : 1;
     size_t lds = ksplit > 1 ? (size_t)waves * (NB * mt * 4 + mt) * 64 * 4 : 0;
-#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
+#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, KS>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
         bias, rs, eps, outf, ldo_f, (T*)outa, ldo_a, ksplit, ntiles)
     switch (mt) {
         case 1: SK(1); break;
@@ -371,6 +398,140 @@ extern "C" int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, i
     dim3 grid(Hq, rows, B);
     if (dtype == MMX_BF16) hipLaunchKernelGGL(paged_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, ldq, q_bs, Hq, Hkv, scale, pos, (const bf16_t*)kc, (const bf16_t*)vc, block_table, max_pages, page, (bf16_t*)out, ldo, o_bs);
     else if (dtype == MMX_F32) hipLaunchKernelGGL(paged_attn_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, ldq, q_bs, Hq, Hkv, scale, pos, (const float*)kc, (const float*)vc, block_table, max_pages, page, (float*)out, ldo, o_bs);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ fused decode attention
+// One launch per layer for the single-token step: RoPE(q), RoPE(k_new), KV append and causal GQA attention.
+// Every (head, sequence) workgroup ropes the new key itself (so it does not wait for the cache write of the
+// one workgroup per kv head that appends it), reads the older keys/values from the paged cache with 16-byte
+// loads all in flight, and splits PV over 32 key groups x 8 channel chunks.
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float o[8]) {
+    if constexpr (sizeof(T) == 2) {
+        uint4 r = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(w[i] << 16);
+            o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    } else {
+        float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(
+    const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
+    const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc, const int32_t* __restrict__ block_table,
+    int max_pages, int page, float scale, T* __restrict__ out, long ldo) {
+    constexpr int D = 64, HALF = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);        // [D]
+    float* kn = qs + D;                                // [D] new key (rounded through T)
+    float* vn = kn + D;                                // [D] new value
+    float* red = vn + D;                               // [16]
+    float* part = red + 16;                            // [32][D]
+    float* S = part + 32 * D;                          // [ctx]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int group = Hq / Hkv, hk = h / group;
+    const int p = pos[b];
+    const int32_t* bt = block_table + (long)b * max_pages;
+    const float* src = qkv + (long)b * ldqkv;
+    if (tid < 2 * HALF) {
+        const int which = tid >> 5, d = tid & 31;      // 0: q head h, 1: k head hk
+        const float* x = src + (which == 0 ? h * D : (Hq + hk) * D);
+        const float ang = (float)p * inv_freq[d];
+        const float c = cosf(ang), s = sinf(ang);
+        const float y0 = x[d] * c - x[d + HALF] * s, y1 = x[d + HALF] * c + x[d] * s;
+        if (which == 0) { qs[d] = y0; qs[d + HALF] = y1; }
+        else { kn[d] = Cvt<T>::to_f(Cvt<T>::from_f(y0)); kn[d + HALF] = Cvt<T>::to_f(Cvt<T>::from_f(y1)); }
+    } else if (tid < 2 * HALF + D) {
+        const int d = tid - 2 * HALF;
+        vn[d] = Cvt<T>::to_f(Cvt<T>::from_f(src[(Hq + Hkv + hk) * D + d]));
+    }
+    __syncthreads();
+    if (h % group == 0 && tid < D) {                   // one workgroup per kv head appends to the cache
+        const long o = (((long)bt[p / page] * Hkv + hk) * page + p % page) * D + tid;
+        kc[o] = Cvt<T>::from_f(kn[tid]);
+        vc[o] = Cvt<T>::from_f(vn[tid]);
+    }
+    float mx = -INFINITY;
+    for (int j = tid; j <= p; j += 256) {
+        float s = 0.f;
+        if (j < p) {
+            const T* kp = kc + (((long)bt[j / page] * Hkv + hk) * page + j % page) * D;
+            float kv[8][8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) load8<T>(kp + c * 8, kv[c]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += qs[c * 8 + e] * kv[c][e];
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += qs[d] * kn[d];
+        }
+        s *= scale;
+        S[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int j = tid; j <= p; j += 256) {
+        float e = expf(S[j] - mx);
+        S[j] = e;
+        l += e;
+    }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+    // PV: thread -> (key group kg of 32, channel chunk dc of 8)
+    const int kg = tid >> 3, dc = tid & 7;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll 4
+    for (int j = kg; j <= p; j += 32) {
+        float v[8];
+        if (j < p) load8<T>(vc + (((long)bt[j / page] * Hkv + hk) * page + j % page) * D + dc * 8, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = vn[dc * 8 + e];
+        }
+        const float pj = S[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pj * v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[kg * D + dc * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < D) {
+        float o = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) o += part[k2 * D + tid];
+        out[(long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / l);
+    }
+}
+extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
+                               const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages,
+                               int page, float scale, void* out, int64_t ldo, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(qkv && inv_freq && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
+    const size_t max_ctx = (size_t)max_pages * page;
+    size_t lds = (3 * 64 + 16 + 32 * 64 + max_ctx) * 4;
+    MMX_CHECK_ARG(lds <= 160 * 1024);
+    dim3 grid(Hq, B);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, page, scale, (bf16_t*)out, ldo);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(decode_attn_kernel<float>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, pos, (float*)kc, (float*)vc, block_table, max_pages, page, scale, (float*)out, ldo);
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;

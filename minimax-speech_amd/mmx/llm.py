@@ -92,10 +92,14 @@ class LlmEngine:
         for l, w in enumerate(self.layers):
             ops.skinny_gemm(h, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True, eps=self.eps,
                             epi=0, out_f32=qkv)
-            ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=rows,
-                              Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
-            ops.paged_attn(q, pos, self.kc[l], self.vc[l], block_table, att, B=B, rows=rows, Hq=self.Hq, Hkv=self.Hkv,
-                           page=self.page, dtype=dt)
+            if rows == 1:
+                ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
+                                Hkv=self.Hkv, page=self.page, dtype=dt)
+            else:
+                ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=rows,
+                                  Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
+                ops.paged_attn(q, pos, self.kc[l], self.vc[l], block_table, att, B=B, rows=rows, Hq=self.Hq,
+                               Hkv=self.Hkv, page=self.page, dtype=dt)
             ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h)
             ops.skinny_gemm(h, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act)
             ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h)
