@@ -87,6 +87,22 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
     float ssq[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) ssq[m] = 0.f;
+    // epilogue operands are fetched up front (by the wave that will run the epilogue) so they do not add a
+    // dependent memory round trip after the reduction
+    float pre_bias = 0.f, pre_res[MT][4];
+    if (active && ksl == 0) {
+        const int n = tile * 16 + l16;
+        if (EPI != 1 && bias && n < N) pre_bias = bias[n];
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m * 16 + 4 * g + r;
+                    pre_res[m][r] = (row < B && n < N) ? outf[(long)row * ldo_f + n] : 0.f;
+                }
+        }
+    }
 
     if (active) {
         const T* wbase = wp + ((long)tile * NB * nkb) * 64 * E + (long)lane * E;
@@ -221,8 +237,8 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
             } else {
                 const int n = tile * 16 + l16;
                 if (n < N) {
-                    float v = acc[0][m][r] * sc + (bias ? bias[n] : 0.f);
-                    if constexpr (EPI == 2) v += outf[(long)row * ldo_f + n];
+                    float v = acc[0][m][r] * sc + pre_bias;
+                    if constexpr (EPI == 2) v += pre_res[m][r];
                     if (outf) outf[(long)row * ldo_f + n] = v;
                     if (outa) outa[(long)row * ldo_a + n] = Cvt<T>::from_f(v);
                 }

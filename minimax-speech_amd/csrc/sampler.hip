@@ -128,21 +128,29 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     for (int i = 0; i < SAMP_MAXV; ++i)
         if (tid + i * SAMP_THREADS < V) x[i] = x[i] / se2;   // p
 
-    // nucleus candidates: repeated block arg-max == stable descending sort prefix
+    // nucleus candidates: repeated block arg-max == stable descending sort prefix.  Every thread keeps the
+    // arg-max of its own (not yet taken) values; only the round's winner rescans its 26 values.
     float p_work[SAMP_MAXV];
 #pragma unroll
     for (int i = 0; i < SAMP_MAXV; ++i) p_work[i] = x[i];
-    float cum = 0.f;
-    int nc = 0;
-    while (cum < top_p && nc < top_k) {
+    auto local_best = [&]() {
         ArgMax a{-2.f, 0x7fffffff};
 #pragma unroll
         for (int i = 0; i < SAMP_MAXV; ++i) a = better(a, ArgMax{p_work[i], tid + i * SAMP_THREADS});
-        a = block_argmax(a, sha);
+        return a;
+    };
+    ArgMax mine = local_best();
+    float cum = 0.f;
+    int nc = 0;
+    while (cum < top_p && nc < top_k) {
+        ArgMax a = block_argmax(mine, sha);
         if (tid == 0) { cand_p[nc] = a.v; cand_i[nc] = a.i; }
+        if ((a.i & (SAMP_THREADS - 1)) == tid) {       // index = tid + i*256 -> owner thread
 #pragma unroll
-        for (int i = 0; i < SAMP_MAXV; ++i)
-            if (tid + i * SAMP_THREADS == a.i) p_work[i] = -1.f;
+            for (int i = 0; i < SAMP_MAXV; ++i)
+                if (tid + i * SAMP_THREADS == a.i) p_work[i] = -1.f;
+            mine = local_best();
+        }
         cum += a.v;                                    // fp32 running sum, same order as common.py:127
         nc++;
     }

@@ -1,0 +1,142 @@
+"""CPU-side checks (no GPU): the C ABI library loads and exports every symbol include/mmx_hip.h declares; the
+state-dict manifests generated from constructor arguments equal the ones captured from the reference's modules;
+the weight packing that turns Conv1d / ConvTranspose1d into windowed GEMMs is algebraically right; the product
+path fails loudly without a GPU; utterance sharding + audio all-gather work across 2 gloo ranks."""
+import json
+import math
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_symbols_declared_in_header_are_exported():
+    from mmx import _lib
+    hdr = open(os.path.join(ROOT, "include", "mmx_hip.h")).read()
+    declared = sorted(set(re.findall(r"\bint\s+(mmx_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    lib = _lib.load()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(_lib.SYMBOLS) == declared
+    assert lib.mmx_abi_version() == 1
+
+
+def test_gemm_params_struct_matches_header_layout():
+    """ctypes mirror of MmxGemmParams: field order/names must follow the header."""
+    from mmx import _lib
+    hdr = open(os.path.join(ROOT, "include", "mmx_hip.h")).read()
+    start = hdr.index("typedef struct MmxGemmParams {") + len("typedef struct MmxGemmParams {")
+    body = hdr[start:hdr.index("} MmxGemmParams;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
+    assert names == [f[0] for f in _lib.GemmParams._fields_]
+
+
+@pytest.mark.parametrize("name,fn", [("dac80", lambda s: s.dac_decoder_manifest(80)), ("dac128", lambda s: s.dac_decoder_manifest(128)),
+                                     ("flow", lambda s: s.flow_manifest()), ("llm", lambda s: s.llm_manifest())])
+def test_manifests_equal_reference_state_dicts(golden_dir, name, fn):
+    from mmx import shapes
+    ref = {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, f"manifest_{name}.json"))).items()}
+    assert fn(shapes) == ref
+
+
+def _window_gemm(x, Wp, M, N, cin, ntaps, dil, row_off, row_hi):
+    """numpy-level statement of the windowed GEMM contract (include/mmx_hip.h) for packing checks."""
+    out = torch.zeros(M, N)
+    for tap in range(ntaps):
+        rows = torch.arange(M) + tap * dil + row_off
+        ok = (rows >= 0) & (rows < row_hi)
+        a = torch.zeros(M, cin)
+        a[ok] = x[rows[ok]]
+        out += a @ Wp[:, tap * cin:(tap + 1) * cin].t()
+    return out
+
+
+@pytest.mark.parametrize("k,dil", [(7, 1), (7, 9), (3, 1), (1, 1)])
+def test_conv1d_packing(k, dil):
+    from mmx import ops
+    g = torch.Generator().manual_seed(k + dil)
+    Cin, Cout, T = 16, 24, 40
+    x, w = torch.randn(T, Cin, generator=g), torch.randn(Cout, Cin, k, generator=g)
+    pad = (k - 1) * dil // 2
+    Wp = ops.pack_conv1d(w, 0)
+    got = _window_gemm(x, Wp, T, Cout, Cin, k, dil, -pad, T)
+    ref = F.conv1d(x.t()[None], w, dilation=dil, padding=pad)[0].t()
+    assert torch.allclose(got, ref, atol=1e-4)
+
+
+@pytest.mark.parametrize("s", [2, 3, 4, 5])
+def test_convtranspose1d_packing(s):
+    from mmx import ops
+    g = torch.Generator().manual_seed(s)
+    Cin, Cout, T = 16, 8, 11
+    x, w = torch.randn(T, Cin, generator=g), torch.randn(Cin, Cout, 2 * s, generator=g)
+    Wp = ops.pack_convtranspose1d(w, s, 0)
+    z = _window_gemm(x, Wp, T + 1, s * Cout, Cin, 2, 1, -1, T)          # rows q = 0..T, columns (k0, co)
+    pad = math.ceil(s / 2)
+    flat = z.reshape(-1)[pad * Cout: pad * Cout + T * s * Cout].reshape(T * s, Cout)
+    ref = F.conv_transpose1d(x.t()[None], w, stride=s, padding=pad, output_padding=s % 2)[0].t()
+    assert torch.allclose(flat, ref, atol=1e-4)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: CPU tensors are rejected before anything is launched."""
+    from mmx import ops
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the CPU-only container")
+    with pytest.raises((AssertionError, RuntimeError)):
+        ops.rownorm(torch.zeros(4, 8), torch.ones(8), None, 1e-5, rows=4, C_=8, out_f32=torch.zeros(4, 8))
+
+
+def test_shard_utterances_is_balanced():
+    from mmx.dist import shard_utterances
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(50, 501, (256,), generator=g).tolist()
+    sh = shard_utterances(lens, 8)
+    assert sorted(i for s in sh for i in s) == list(range(256))
+    assert {len(s) for s in sh} == {32}
+    tot = [sum(lens[i] for i in s) for s in sh]
+    assert max(tot) / min(tot) < 1.02
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "minimax-speech_amd"))
+from mmx.dist import shard_utterances, gather_audio
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+lens = [300, 120, 480, 50, 77]
+sh = shard_utterances(lens, 2)
+mine = sh[rank]
+wavs = [torch.full((lens[i] * 3,), float(i + 1)) for i in mine]
+audio, n = gather_audio(wavs, mine, len(lens), 480 * 3)
+for i, L in enumerate(lens):
+    assert int(n[i]) == L * 3, (i, n)
+    assert torch.all(audio[i, :L * 3] == i + 1) and torch.all(audio[i, L * 3:] == 0)
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_two_rank_audio_all_gather_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = 29500 + os.getpid() % 2000
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
