@@ -102,9 +102,10 @@ int mmx_copy2d(const void* in, int in_dtype, int64_t ibs, int64_t irs, int64_t i
 
 /* Estimator input pack (decoder.py:424-432): h[b][t] = [x | mu | spks | cond] as T, + sinusoidal
  * timestep embedding (matcha decoder.py:14-29, scale 1000) emb[b][:] as T.
- * x/mu/cond are fp32 time-major [B][T][80] (x with batch stride x_bs elements, 0 = shared by the CFG pair);
+ * x/mu/cond are fp32 time-major [B][T][80]; batch b reads x[(b % x_mod) * x_bs ...] so the conditional and the
+ * unconditional half of a CFG batch share one state tensor (x_mod = number of utterances);
  * spks [B][80]; NULL mu/spks/cond read as zero. */
-int mmx_est_pack(const float* x, int64_t x_bs, const float* mu, const float* spks, const float* cond, int B, int T, int C,
+int mmx_est_pack(const float* x, int64_t x_bs, int x_mod, const float* mu, const float* spks, const float* cond, int B, int T, int C,
                  void* h, int64_t ldh, int dtype, hipStream_t stream);
 int mmx_sinusoidal_emb(const float* t, int B, int dim, float scale, void* out, int dtype, hipStream_t stream);
 

@@ -140,7 +140,7 @@ extern "C" int mmx_copy2d(const void* in, int in_dtype, int64_t ibs, int64_t irs
 
 // ---------------------------------------------------------------------------- estimator input pack / time embedding
 template <typename T>
-__global__ void est_pack_kernel(const float* __restrict__ x, long x_bs, const float* __restrict__ mu, const float* __restrict__ spks,
+__global__ void est_pack_kernel(const float* __restrict__ x, long x_bs, int x_mod, const float* __restrict__ mu, const float* __restrict__ spks,
                                 const float* __restrict__ cond, int Tn, int C, T* __restrict__ h, long ldh) {
     const int b = blockIdx.y;
     const long row = blockIdx.x;                   // frame
@@ -148,19 +148,19 @@ __global__ void est_pack_kernel(const float* __restrict__ x, long x_bs, const fl
     for (int c = threadIdx.x; c < 4 * C; c += blockDim.x) {
         int part = c / C, cc = c % C;
         float v;
-        if (part == 0) v = x[(long)b * x_bs + row * C + cc];
+        if (part == 0) v = x[(long)(b % x_mod) * x_bs + row * C + cc];
         else if (part == 1) v = mu ? mu[o * C + cc] : 0.f;
         else if (part == 2) v = spks ? spks[(long)b * C + cc] : 0.f;
         else v = cond ? cond[o * C + cc] : 0.f;
         h[o * ldh + c] = Cvt<T>::from_f(v);
     }
 }
-extern "C" int mmx_est_pack(const float* x, int64_t x_bs, const float* mu, const float* spks, const float* cond, int B, int T_, int C,
+extern "C" int mmx_est_pack(const float* x, int64_t x_bs, int x_mod, const float* mu, const float* spks, const float* cond, int B, int T_, int C,
                             void* h, int64_t ldh, int dtype, hipStream_t stream) {
-    MMX_CHECK_ARG(x && h && B > 0 && T_ > 0 && C > 0 && ldh >= 4 * C);
+    MMX_CHECK_ARG(x && h && B > 0 && T_ > 0 && C > 0 && ldh >= 4 * C && x_mod > 0);
     dim3 grid(T_, B);
-    if (dtype == MMX_BF16) hipLaunchKernelGGL(est_pack_kernel<bf16_t>, grid, dim3(128), 0, stream, x, x_bs, mu, spks, cond, T_, C, (bf16_t*)h, ldh);
-    else if (dtype == MMX_F32) hipLaunchKernelGGL(est_pack_kernel<float>, grid, dim3(128), 0, stream, x, x_bs, mu, spks, cond, T_, C, (float*)h, ldh);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(est_pack_kernel<bf16_t>, grid, dim3(128), 0, stream, x, x_bs, x_mod, mu, spks, cond, T_, C, (bf16_t*)h, ldh);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(est_pack_kernel<float>, grid, dim3(128), 0, stream, x, x_bs, x_mod, mu, spks, cond, T_, C, (float*)h, ldh);
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     const int nb = gridDim.x;                          // state is field-major: state[field * B + b]
     int32_t* st = state + b;
 #define ST(f) st[(f) * nb]
-    const int pos = ST(0), step = ST(1), n_out = ST(2), finished = ST(3), min_len = ST(4), seq = ST(6);
+    const int pos = ST(0), step = ST(1), n_out = ST(2), finished = ST(3), min_len = ST(4), max_len = ST(5), seq = ST(6);
     if (finished) return;                              // uniform per block
     const float* lg = logits + (long)b * ldl;
 
@@ -195,7 +195,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
         for (int c = tid; c < E; c += SAMP_THREADS) next_x[(long)b * ldx + c] = speech_emb[(long)top * E + c];
         if (tid == 0) { out_tokens[(long)b * max_out + n_out] = top; ST(2) = n_out + 1; }
     }
-    if (tid == 0) { ST(0) = pos + 1; ST(1) = step + 1; }
+    if (tid == 0) {
+        ST(0) = pos + 1;
+        ST(1) = step + 1;
+        if (step + 1 >= max_len) ST(3) = 1;              // llm.py:746: for i in range(max_len)
+    }
 #undef ST
 }
 

@@ -284,8 +284,8 @@ class FlowEngine:
             self._plans[key] = torch.zeros(B, 512, Tp, dtype=self.tdt, device=self.dev)   # pad columns stay zero
         return self._plans[key]
 
-    def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None):
-        """All inputs fp32 time-major device tensors: x [*,T,80] (batch stride x_bstride), mu/cond [B,T,80],
+    def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None):
+        """All inputs fp32 time-major device tensors: x [x_mod,T,80] (batch b reads x[b % x_mod]), mu/cond [B,T,80],
         spks [B,80], t [B]; mask fp32 [B,T] or None.  Returns fp32 [B,T,80]."""
         dt, C = self.dtype, self.C
         chunk = self.est_chunk if streaming else 0
@@ -298,7 +298,7 @@ class FlowEngine:
         tv = self._new(B, self.mlp_w.shape[0], f32=True)
         ops.linear(t2, self.mlp_w, 1024, dtype=dt, bias=self.mlp_b, out_f32=tv)                  # all 14 resnet mlps
         h0 = self._new(B, T, 320)
-        ops.est_pack(x, mu, spks, cond, h0, B=B, T=T, dtype=dt, x_bstride=x_bstride)
+        ops.est_pack(x, mu, spks, cond, h0, B=B, T=T, dtype=dt, x_bstride=x_bstride, x_mod=(x_mod or B))
         xs = self._new(B, T, C, f32=True)
         cat = self._new(B, T, 2 * C)                     # [mid output | skip] for the up block
         # down block: resnet + 4 transformer blocks; the last block drops its activation copy into cat[:, :, C:]
@@ -372,45 +372,73 @@ class FlowEngine:
     class _Plan:
         pass
 
-    def _cfm_plan(self, T, streaming):
-        key = ("cfm", T, bool(streaming))
+    def _cfm_plan(self, n, T, streaming, masked):
+        """Plan for n utterances padded to T frames: static buffers + the graph of the whole Euler solve."""
+        key = ("cfm", n, T, bool(streaming), bool(masked))
         if key in self._plans:
             return self._plans[key]
         P = FlowEngine._Plan()
-        P.x = self._new(T, 80, f32=True)                # the ODE state (shared by the CFG pair)
-        P.mu = torch.zeros(2, T, 80, device=self.dev)   # row 1 stays zero: the unconditional branch
-        P.spks = torch.zeros(2, 80, device=self.dev)
-        P.cond = torch.zeros(2, T, 80, device=self.dev)
-        P.d = self._new(2, T, 80, f32=True)
+        P.x = self._new(n, T, 80, f32=True)             # ODE state, shared by the two halves of the CFG batch
+        P.mu = torch.zeros(2 * n, T, 80, device=self.dev)   # rows n.. stay zero: the unconditional branch
+        P.spks = torch.zeros(2 * n, 80, device=self.dev)
+        P.cond = torch.zeros(2 * n, T, 80, device=self.dev)
+        P.mask = torch.ones(2 * n, T, device=self.dev) if masked else None
+        P.d = self._new(2 * n, T, 80, f32=True)
         tt, dd = self.t_schedule()
-        P.t_all = torch.tensor([[v, v] for v in tt], dtype=torch.float32, device=self.dev)
-        P.z = self.rand_noise[0, :, :T].t().contiguous().to(self.dev)      # [T,80]
+        P.t_all = torch.tensor([[v] * (2 * n) for v in tt], dtype=torch.float32, device=self.dev)
+        P.z = self.rand_noise[0, :, :T].t().contiguous().to(self.dev)      # [T,80], the same noise for every utterance
 
         def run():
-            P.x.copy_(P.z)
+            P.x.copy_(P.z.unsqueeze(0).expand(n, T, 80))
             for s in range(self.n_timesteps):
-                self.estimator(P.x, 0, P.mu, P.spks, P.cond, P.t_all[s], 2, T, None, streaming, out=P.d)
-                ops.cfg_euler(P.x, P.d[0], P.d[1], self.cfg, dd[s], T * 80)
+                self.estimator(P.x, T * 80, P.mu, P.spks, P.cond, P.t_all[s], 2 * n, T, P.mask, streaming, out=P.d, x_mod=n)
+                ops.cfg_euler(P.x, P.d[:n], P.d[n:], self.cfg, dd[s], n * T * 80)
 
         P.run = Graphed(run, self.use_graphs)
         self._plans[key] = P
         return P
 
+    def cfm_batch(self, mus, spks, conds, streaming=False, pad_to=1):
+        """n utterances in one solve: mus/conds lists of fp32 [T_i,80], spks list of [80].  Shorter utterances are
+        zero padded and masked (row mask on every activation, key mask in attention), exactly like a padded batch
+        of the reference's estimator (decoder.py:433-496 with mask).  Returns a list of fp32 [T_i,80] views of the
+        plan's state (copy before the next call)."""
+        n = len(mus)
+        Ts = [m.shape[0] for m in mus]
+        T = ops.round_up(max(Ts), pad_to)
+        masked = any(t != T for t in Ts)
+        P = self._cfm_plan(n, T, streaming, masked)
+        if masked:
+            P.mu[:n].zero_()
+            P.cond[:n].zero_()
+            P.mask.zero_()
+        for i in range(n):
+            P.mu[i, :Ts[i]].copy_(mus[i])
+            P.cond[i, :Ts[i]].copy_(conds[i])
+            P.spks[i].copy_(spks[i].reshape(-1))
+            if masked:
+                P.mask[i, :Ts[i]] = 1.0
+                P.mask[n + i, :Ts[i]] = 1.0
+        P.run()
+        return [P.x[i, :Ts[i]] for i in range(n)]
+
     def cfm(self, mu, spks, cond, streaming=False) -> torch.Tensor:
         """mu, cond fp32 [T,80] time-major; spks fp32 [80] -> x fp32 [T,80] (owned by the plan: copy if kept)."""
-        T = mu.shape[0]
-        P = self._cfm_plan(T, streaming)
-        P.mu[0].copy_(mu)
-        P.spks[0].copy_(spks.reshape(-1))
-        P.cond[0].copy_(cond)
-        P.run()
-        return P.x
+        return self.cfm_batch([mu], [spks], [cond], streaming)[0]
 
     # ------------------------------------------------------------------ flow.inference
     @torch.no_grad()
     def inference_time_major(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):
         """token [1,Lt], prompt_token [1,Lp] ints; prompt_feat [1,Tp,80]; embedding [1,192] (device tensors).
         Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped)."""
+        mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize)
+        x = self.cfm(mu, spks, cond, streaming)
+        return x[mel_len1:]
+
+    @torch.no_grad()
+    def conditions(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):
+        """Everything of flow.inference ahead of the ODE solve (flow.py:455-498): speaker projection, token
+        embedding + conformer encoder -> mu, prompt condition.  Returns (mu [T,80], spks [1,80], cond [T,80], Tp)."""
         dt = self.dtype
         emb = embedding.to(self.dev, torch.float32).contiguous()
         en = self._new(1, self.spk_dim)
@@ -425,8 +453,7 @@ class FlowEngine:
         cond = torch.zeros(T, 80, device=self.dev)
         if mel_len1:
             cond[:mel_len1].copy_(prompt_feat[0].to(self.dev, torch.float32))
-        x = self.cfm(mu, spks, cond, streaming)
-        return x[mel_len1:]
+        return mu, spks, cond, mel_len1
 
     @torch.no_grad()
     def inference(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):

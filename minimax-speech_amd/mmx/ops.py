@@ -121,8 +121,8 @@ def copy2d(src, src_dt, ibs, irs, ics, dst, dst_dt, obs, ors, ocs, rows, cols, b
                             i64(ocs), rows, cols, batch, stream()), "mmx_copy2d")
 
 
-def est_pack(x, mu, spks, cond, h, *, B, T, dtype, x_bstride=None):
-    check(load().mmx_est_pack(_p(x), i64(T * 80 if x_bstride is None else x_bstride), _p(mu), _p(spks), _p(cond), B, T, 80, _p(h), i64(h.shape[-1]), dtype, stream()),
+def est_pack(x, mu, spks, cond, h, *, B, T, dtype, x_bstride=None, x_mod=None):
+    check(load().mmx_est_pack(_p(x), i64(T * 80 if x_bstride is None else x_bstride), (B if x_mod is None else x_mod), _p(mu), _p(spks), _p(cond), B, T, 80, _p(h), i64(h.shape[-1]), dtype, stream()),
           "mmx_est_pack")
 
 

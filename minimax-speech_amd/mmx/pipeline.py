@@ -30,11 +30,13 @@ class TtsEngine:
 
     @torch.no_grad()
     def generate_tokens(self, texts: List[torch.Tensor], prompt_texts=None, prompt_speech=None, seed=0,
-                        min_ratio=2, max_ratio=20, exact_steps: Optional[int] = None) -> List[torch.Tensor]:
-        """Batched AR decode (Qwen2LM.inference semantics per sequence). exact_steps forces exactly that many
-        sampling steps with EOS ignored (BASELINE config 3: 250 steps for a 10 s utterance)."""
+                        min_ratio=2, max_ratio=20, exact_steps=None) -> List[torch.Tensor]:
+        """Batched AR decode (Qwen2LM.inference semantics per sequence). exact_steps (int or list) forces exactly
+        that many sampling steps with EOS ignored (BASELINE config 3: 250 steps for a 10 s utterance)."""
         B = len(texts)
         assert B == self.llm.B
+        if exact_steps is not None and not isinstance(exact_steps, (list, tuple)):
+            exact_steps = [exact_steps] * B
         z = lambda: torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         xs, mins, maxs = [], [], []
         for b in range(B):
@@ -42,8 +44,8 @@ class TtsEngine:
             ps = prompt_speech[b] if prompt_speech else z()
             xs.append(self.llm.build_lm_input(texts[b], pt, ps))
             n = texts[b].numel()
-            mins.append(exact_steps if exact_steps is not None else int(n * min_ratio))
-            maxs.append(exact_steps if exact_steps is not None else int(n * max_ratio))
+            mins.append(exact_steps[b] if exact_steps is not None else int(n * min_ratio))
+            maxs.append(exact_steps[b] if exact_steps is not None else int(n * max_ratio))
         self.llm.start(xs, mins, maxs, seed=seed)
         self.llm.run(max(maxs))
         n = self.llm.state[2].tolist()
@@ -70,3 +72,33 @@ class TtsEngine:
         pf = prompt_speech_feat if prompt_speech_feat is not None else torch.zeros(1, 0, 80, device=self.dev)
         pt = flow_prompt_speech_token if flow_prompt_speech_token is not None else z
         return self.token2wav(toks.reshape(1, -1), pt, pf, flow_embedding)
+
+    @torch.no_grad()
+    def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=8, max_pad_ratio=1.25,
+                  frame_quantum=32) -> List[torch.Tensor]:
+        """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share):
+        one batched AR decode for all of them, per-utterance conformer encoder, flow ODE solves batched over
+        groups of similar length (zero padded + masked), DAC decode per utterance.  No prompts (synthetic load)."""
+        B = len(texts)
+        z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
+        zf = torch.zeros(1, 0, 80, device=self.dev)
+        toks = self.generate_tokens(texts, seed=seed, exact_steps=exact_steps)
+        conds = [self.flow.conditions(toks[b].reshape(1, -1), z, zf, flow_embeddings[b]) for b in range(B)]
+        order = sorted(range(B), key=lambda b: conds[b][0].shape[0])
+        wavs: List[Optional[torch.Tensor]] = [None] * B
+        i = 0
+        while i < B:
+            j = i + 1
+            t0 = conds[order[i]][0].shape[0]
+            while j < B and j - i < group_size and conds[order[j]][0].shape[0] <= max(t0 * max_pad_ratio, t0 + frame_quantum):
+                j += 1
+            grp = order[i:j]
+            xs = self.flow.cfm_batch([conds[b][0] for b in grp], [conds[b][1] for b in grp], [conds[b][2] for b in grp],
+                                     pad_to=frame_quantum)
+            for b, lat in zip(grp, xs):
+                T2 = lat.shape[0]
+                zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
+                ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
+                wavs[b] = self.dac.decode_time_major(zt, 1, T2)
+            i = j
+        return wavs

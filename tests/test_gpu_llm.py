@@ -76,3 +76,19 @@ def test_batched_decode_matches_single(llm_sd):
     e3.start([e3.build_lm_input(*r) for r in reqs], [12] * 3, [12] * 3, seed=2, seq_ids=[0, 1, 2])
     got = e3.run(12)
     assert got == single
+
+
+def test_max_len_stops_sequences_independently(llm_sd):
+    """exact-length decode (min_len == max_len, EOS ignored): every sequence stops at its own max_len
+    (llm.py:746 `for i in range(max_len)`), tokens <= steps (ids > EOS are skipped, llm.py:755)."""
+    from mmx.llm import LlmEngine, ST_STEP, ST_FIN
+    g = torch.Generator().manual_seed(4)
+    eng = LlmEngine(llm_sd, dtype=1, max_batch=3, max_ctx=256)
+    z = torch.zeros(1, 0, dtype=torch.long).cuda()
+    xs = [eng.build_lm_input(torch.randint(0, 151936, (1, 9), generator=g).cuda(), z, z) for _ in range(3)]
+    lens = [5, 17, 11]
+    eng.start(xs, lens, lens, seed=1)
+    toks = eng.run(max(lens))
+    assert eng.state[ST_FIN].tolist() == [1, 1, 1]
+    assert eng.state[ST_STEP].tolist() == lens
+    assert all(len(t) <= n and len(t) >= n - 2 for t, n in zip(toks, lens))
