@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="batch", choices=["batch", "single"])
+    ap.add_argument("--per-gpu", type=int, default=32)
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -113,27 +115,32 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from mmx.pipeline import TtsEngine, TOKEN_RATE, SAMPLE_RATE
+    from mmx.dist import gather_audio, shard_utterances
     dt = 1 if a.dtype == "bf16" else 0
     llm_sd, flow_sd, dac_sd = build_weights(0)
-    eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=dt, device=f"cuda:{local}", max_batch=1, max_ctx=1024)
+    PER_GPU = 1 if a.workload == "single" else a.per_gpu
+    eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=dt, device=f"cuda:{local}", max_batch=PER_GPU, max_ctx=640)
     del llm_sd, flow_sd, dac_sd
-    # BASELINE config 3 / SURVEY §8d.3: 48 random text ids, no prompt, exactly 250 decode steps (a 10 s utterance)
-    g = torch.Generator().manual_seed(2 + rank)
-    text = torch.randint(0, 151936, (1, 48), generator=g).cuda()
     emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).cuda()
-    NTOK = 250
-    max_samples = 2 * NTOK * eng.hop
-    gather_buf = torch.zeros(world, max_samples, device="cuda") if world > 1 else None
-    mine = torch.zeros(max_samples, device="cuda")
+    if a.workload == "single":
+        # BASELINE config 3 / SURVEY 8d.3: 48 random text ids, no prompt, exactly 250 decode steps (10 s of audio)
+        lens_all = [250] * world
+    else:
+        # BASELINE config 4 / SURVEY 8d.4 (one rank's share): audio lengths U{2..20 s} = 50..500 tokens, seed 3,
+        # PER_GPU utterances per GPU, dealt to the ranks by length (mmx.dist.shard_utterances)
+        lens_all = torch.randint(50, 501, (PER_GPU * world,), generator=torch.Generator().manual_seed(3)).tolist()
+    mine = shard_utterances(lens_all, world)[rank]
+    lens = [lens_all[i] for i in mine]
+    g = torch.Generator().manual_seed(2)
+    all_text = [torch.randint(0, 151936, (1, 48), generator=g) for _ in range(len(lens_all))]
+    texts = [all_text[i].cuda() for i in mine]
+    max_samples = 2 * max(lens_all) * eng.hop
 
     def step():
-        wav = eng.tts(text, emb, seed=rank, exact_steps=NTOK)
-        n = wav.shape[-1]
+        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens)
         if world > 1:
-            mine.zero_()
-            mine[:n].copy_(wav.reshape(-1))
-            dist.all_gather_into_tensor(gather_buf, mine)
-        return n
+            gather_audio(wavs, mine, len(lens_all), max_samples)      # the path's one exchange step (RCCL all-gather)
+        return sum(w.shape[-1] for w in wavs)
 
     def fence():
         torch.cuda.synchronize()
@@ -159,14 +166,20 @@ def main():
         samples = float(tot.item())
     audio_s = samples / SAMPLE_RATE
     if rank == 0:
+        if a.workload == "single":
+            wl = ("BASELINE config 3: one 10 s utterance per GPU per step (48 text ids, 250 AR decode steps, flow 500 frames "
+                  "x 10 Euler steps with CFG, DAC 240000 samples)")
+        else:
+            wl = (f"BASELINE config 4, one rank's share: {PER_GPU} utterances per GPU per step, lengths U{{2..20 s}} (50-500 "
+                  "tokens, seed 3), batched AR decode, length-grouped batched flow (10 Euler steps, CFG), DAC decode, "
+                  "all_gather of audio for N > 1")
         out = {"metric": "24 kHz audio-seconds generated per wall-second per node (CosyVoice2-0.5B-shaped LM + flow + DAC-VAE, end to end)",
                "value": round(audio_s / el, 3), "unit": "audio_s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic text ids, random-init weights (deterministic synth init)",
                "rtf": round(el / audio_s * world, 5),
-               "config": {"workload": "BASELINE config 3: one 10 s utterance per GPU per step (48 text ids, 250 AR decode steps, "
-                                      "flow 500 frames x 10 Euler steps with CFG, DAC 240000 samples)",
-                          "utterances_per_gpu": 1, "tokens": NTOK, "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
+               "config": {"workload": wl, "utterances_per_gpu": PER_GPU, "audio_s_per_step": round(audio_s / a.steps, 2),
+                          "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
         if world == 1:
             out["roofline"] = measure_dominant_kernel(eng)
             if not a.no_cpu_baseline:
