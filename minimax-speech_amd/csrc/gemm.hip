@@ -168,38 +168,114 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     }
 
     // ------------------------------------------------------------------ fused epilogue
+    // The MFMA C layout gives a lane 4 ROWS x 1 column per fragment: storing from it writes 32-64 B row
+    // segments (measured: ~250 GB/s of output, the whole cost of a short-K GEMM).  Instead each wave passes its
+    // tile through a private LDS patch, 16 rows at a time, and every lane then owns CW consecutive columns of one
+    // row: residual loads and both output stores are 16-byte accesses, 4 lanes cover a full 128-256 B line.
+    __syncthreads();                                   // all waves are done with the operand tiles
+    constexpr int WNC = BN / WN;                       // columns of the wave tile
+    constexpr int CW = WNC / 4;                        // consecutive columns per lane (16 / 8 / 4)
+    constexpr int LDC = WNC + 4;                       // padded fp32 row: conflict-free ds_write_b32
+    float* Cs = reinterpret_cast<float*>(smem) + wave * 16 * LDC;
     float* outf = p.out_f32 ? p.out_f32 + (long)b * p.of_bstride : nullptr;
     T* outa = p.out_act ? reinterpret_cast<T*>(p.out_act) + (long)b * p.oa_bstride : nullptr;
     const float* res = p.residual ? p.residual + (long)b * p.r_bstride : nullptr;
     const float* rmask = p.rowmask ? p.rowmask + (long)b * p.rm_bstride : nullptr;
+    constexpr int VA = 16 / sizeof(T);                 // act elements per 16 bytes
+    const bool vec_f = outf && (p.ldo_f % 4 == 0) && (p.out_off % 4 == 0) && (p.of_bstride % 4 == 0) && ((uintptr_t)p.out_f32 % 16 == 0);
+    const bool vec_a = outa && (p.ldo_a % VA == 0) && (p.out_off % VA == 0) && (p.oa_bstride % VA == 0) && ((uintptr_t)p.out_act % 16 == 0) && (CW % VA == 0);
+    const bool vec_r = res && (p.ldr % 4 == 0) && (p.r_bstride % 4 == 0) && ((uintptr_t)p.residual % 16 == 0);
+    const int erow = lane >> 2, ecol = (lane & 3) * CW;
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * (BM / WM) + i * 16 + 4 * g + r;
-            if (m >= p.M) continue;
-            const float rm = rmask ? rmask[m] : 1.f;
+        for (int j = 0; j < NF; ++j)
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int n = n0 + wn * (BN / WN) + j * 16 + l16;
-                if (n >= p.N) continue;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[p.bias_per_row ? m : (n % p.bias_mod)];
-                v = act_apply<PRECISE>(v, p.act, p.slope);
-                if (res) v += res[(long)m * p.ldr + n];
-                v *= rm;
-                if (outf) {
-                    long lin = (long)m * p.ldo_f + n + p.out_off;
-                    if (lin >= 0 && lin < p.out_len) outf[lin] = v;
+            for (int r = 0; r < 4; ++r) Cs[(4 * g + r) * LDC + j * 16 + l16] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float v[CW];
+#pragma unroll
+        for (int c = 0; c < CW; c += 4) {
+            float4_t t4 = *reinterpret_cast<const float4_t*>(Cs + erow * LDC + ecol + c);
+            v[c] = t4[0]; v[c + 1] = t4[1]; v[c + 2] = t4[2]; v[c + 3] = t4[3];
+        }
+        __builtin_amdgcn_wave_barrier();               // patch is rewritten by the next i
+        const int m = m0 + wm * (BM / WM) + i * 16 + erow;
+        const int nb = n0 + wn * WNC + ecol;
+        if (m >= p.M || nb >= p.N) continue;
+        const bool full = nb + CW <= p.N;
+        const float rm = rmask ? rmask[m] : 1.f;
+        float rr[CW];
+        if (res) {
+            if (vec_r && full) {
+#pragma unroll
+                for (int c = 0; c < CW; c += 4) {
+                    float4_t t4 = *reinterpret_cast<const float4_t*>(res + (long)m * p.ldr + nb + c);
+                    rr[c] = t4[0]; rr[c + 1] = t4[1]; rr[c + 2] = t4[2]; rr[c + 3] = t4[3];
                 }
-                if (outa) {
-                    long lin = (long)m * p.ldo_a + n + p.out_off;
-                    if (lin >= 0 && lin < p.out_len) {
-                        float w = act_apply<PRECISE>(v, p.act2, p.slope);
-                        if (p.alpha) w = snake_apply<PRECISE>(w, p.alpha[n % p.alpha_mod]);
-                        outa[lin] = Cvt<T>::from_f(w);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CW; ++c) rr[c] = (nb + c < p.N) ? res[(long)m * p.ldr + nb + c] : 0.f;
+            }
+        }
+        int bidx = p.bias ? (p.bias_per_row ? m : nb % p.bias_mod) : 0;
+        int aidx = p.alpha ? nb % p.alpha_mod : 0;
+        float w2[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            float x = v[c];
+            if (p.bias) {
+                x += p.bias[bidx];
+                if (!p.bias_per_row && ++bidx == p.bias_mod) bidx = 0;
+            }
+            x = act_apply<PRECISE>(x, p.act, p.slope);
+            if (res) x += rr[c];
+            x *= rm;
+            v[c] = x;
+            if (outa) {
+                float w = act_apply<PRECISE>(x, p.act2, p.slope);
+                if (p.alpha) {
+                    w = snake_apply<PRECISE>(w, p.alpha[aidx]);
+                    if (++aidx == p.alpha_mod) aidx = 0;
+                }
+                w2[c] = w;
+            }
+        }
+        if (outf) {
+            const long lin = (long)m * p.ldo_f + nb + p.out_off;
+            if (vec_f && full && lin >= 0 && lin + CW <= p.out_len) {
+#pragma unroll
+                for (int c = 0; c < CW; c += 4)
+                    *reinterpret_cast<float4_t*>(outf + lin + c) = float4_t{v[c], v[c + 1], v[c + 2], v[c + 3]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (nb + c < p.N && lin + c >= 0 && lin + c < p.out_len) outf[lin + c] = v[c];
+            }
+        }
+        if (outa) {
+            const long lin = (long)m * p.ldo_a + nb + p.out_off;
+            if (vec_a && full && lin >= 0 && lin + CW <= p.out_len) {
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int c = 0; c < CW; c += 8) {
+                        uint4 pk;
+                        pk.x = (unsigned)f2bf(w2[c]) | ((unsigned)f2bf(w2[c + 1]) << 16);
+                        pk.y = (unsigned)f2bf(w2[c + 2]) | ((unsigned)f2bf(w2[c + 3]) << 16);
+                        pk.z = (unsigned)f2bf(w2[c + 4]) | ((unsigned)f2bf(w2[c + 5]) << 16);
+                        pk.w = (unsigned)f2bf(w2[c + 6]) | ((unsigned)f2bf(w2[c + 7]) << 16);
+                        *reinterpret_cast<uint4*>(outa + lin + c) = pk;
                     }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CW; c += 4)
+                        *reinterpret_cast<float4_t*>(outa + lin + c) = float4_t{w2[c], w2[c + 1], w2[c + 2], w2[c + 3]};
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (nb + c < p.N && lin + c >= 0 && lin + c < p.out_len) outa[lin + c] = Cvt<T>::from_f(w2[c]);
             }
         }
     }
@@ -209,6 +285,8 @@ template <typename T, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch);
     size_t lds = (size_t)2 * (BM + BN) * Frag<T>::LDS_ROW * sizeof(T);
+    const size_t lds_epi = (size_t)4 * 16 * (BN / WN + 4) * sizeof(float);    // per-wave epilogue patches
+    if (lds_epi > lds) lds = lds_epi;
     hipLaunchKernelGGL((gemm_win_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
     MMX_LAUNCH_CHECK();
     return MMX_OK;

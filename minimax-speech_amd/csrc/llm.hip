@@ -115,17 +115,17 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
                 for (int n = 0; n < NB; ++n)
                     if (kc + i < kb1)
                         wf[i][n] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wbase + ((long)n * nkb + kc + i) * 64 * E));
-            // (2) activations (L2 resident): for one row tile they are prefetched too
-            u32x4_t xr[MT == 1 ? KS : 1][XV];
-            if constexpr (MT == 1) {
+            // (2) activations (L2 resident) of the slice, also all in flight
+            u32x4_t xr[KS][MT][XV];
 #pragma unroll
-                for (int i = 0; i < KS; ++i)
+            for (int i = 0; i < KS; ++i)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int v = 0; v < XV; ++v)
-                        xr[i][v] = (kc + i < kb1 && l16 < B)
-                                       ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(x + (long)l16 * ldx + (kc + i) * KB + g * E) + v * 16)
-                                       : u32x4_t{0, 0, 0, 0};
-            }
+                        xr[i][m][v] = (kc + i < kb1 && m * 16 + l16 < B)
+                                          ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(x + (long)(m * 16 + l16) * ldx + (kc + i) * KB + g * E) + v * 16)
+                                          : u32x4_t{0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < KS; ++i) {
                 if (kc + i >= kb1) continue;
@@ -133,16 +133,8 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
                 for (int m = 0; m < MT; ++m) {
                     float xv[E];
                     u32x4_t raw[XV];
-                    if constexpr (MT == 1) {
 #pragma unroll
-                        for (int v = 0; v < XV; ++v) raw[v] = xr[i][v];
-                    } else {
-                        const int row = m * 16 + l16;
-#pragma unroll
-                        for (int v = 0; v < XV; ++v)
-                            raw[v] = row < B ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(x + (long)row * ldx + (kc + i) * KB + g * E) + v * 16)
-                                             : u32x4_t{0, 0, 0, 0};
-                    }
+                    for (int v = 0; v < XV; ++v) raw[v] = xr[i][m][v];
                     if constexpr (sizeof(TX) == 4) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) xv[e] = __uint_as_float(raw[e / 4][e % 4]);
@@ -251,20 +243,20 @@ template <typename T, typename TX, int EPI>
 static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, int rs,
                             float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s) {
     constexpr int KB = sizeof(T) == 2 ? 32 : 16;
-    constexpr int KS = 10;                             // k-blocks a wave keeps in flight (registers)
     const int ntiles = (N + 15) / 16;                  // for EPI==1, N is the activation width I
     const int nkb = K / KB;
     // smallest power-of-two k split (<= 8 waves = 512 threads per workgroup, so a wave may use 256 VGPRs) whose
     // slice fits KS blocks; a longer slice is walked in chunks of KS
+    const int mt = (B + 15) / 16;
+    const int KSr = mt == 1 ? 10 : (mt == 2 ? 6 : 4);  // k-blocks a wave keeps in flight (register budget)
     int ksplit = 1;
-    while (ksplit < 8 && (nkb + ksplit - 1) / ksplit > KS) ksplit *= 2;
+    while (ksplit < 8 && (nkb + ksplit - 1) / ksplit > KSr) ksplit *= 2;
     int waves = ksplit >= 4 ? ksplit : 4;
     int tpb = waves / ksplit;
     dim3 grid((ntiles + tpb - 1) / tpb), block(waves * 64);
-    const int mt = (B + 15) / 16;
     constexpr int NB = EPI == 1 ? 2 : 1;
     size_t lds = ksplit > 1 ? (size_t)waves * (NB * mt * 4 + mt) * 64 * 4 : 0;
-#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, KS>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
+#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, (MT == 1 ? 10 : (MT == 2 ? 6 : 4))>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
         bias, rs, eps, outf, ldo_f, (T*)outa, ldo_a, ksplit, ntiles)
     switch (mt) {
         case 1: SK(1); break;

@@ -73,6 +73,7 @@ class LlmEngine:
         self.forced, self._forced_buf = None, None
         self.x_in = torch.zeros(B, self.H, device=self.dev)         # next input embedding (written by the sampler)
         self.h = torch.zeros(B, self.H, device=self.dev)            # residual stream of the step
+        self.h_act = torch.zeros(B, self.H, dtype=self.tdt, device=self.dev)   # its compute-dtype copy
         self.logits = torch.zeros(B, self.V, device=self.dev)
         self.logp = torch.zeros(B, self.V, device=self.dev)
         self.want_logp = False
@@ -80,8 +81,10 @@ class LlmEngine:
         self._decode = None
 
     # ------------------------------------------------------------------ one transformer pass over `rows` tokens/seq
-    def _layers(self, h, B, rows, pos, block_table):
-        """h fp32 [B*rows, H] residual stream (in place). pos int32 [B] device, block_table [B, max_pages]."""
+    def _layers(self, h, ha, B, rows, pos, block_table):
+        """h fp32 [B*rows, H] residual stream (in place) and ha, its compute-dtype copy (kept in sync by the
+        residual epilogues: it is the A operand of the next RMSNorm-folded projection).
+        pos int32 [B] device, block_table [B, max_pages]."""
         dt, H, I = self.dtype, self.H, self.I
         n = B * rows
         assert n <= 64
@@ -90,7 +93,7 @@ class LlmEngine:
         att = torch.empty(n, self.Hq * self.D, dtype=self.tdt, device=self.dev)
         act = torch.empty(n, I, dtype=self.tdt, device=self.dev)
         for l, w in enumerate(self.layers):
-            ops.skinny_gemm(h, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True, eps=self.eps,
+            ops.skinny_gemm(ha, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True, eps=self.eps,
                             epi=0, out_f32=qkv)
             if rows == 1:
                 ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
@@ -100,13 +103,13 @@ class LlmEngine:
                                   Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
                 ops.paged_attn(q, pos, self.kc[l], self.vc[l], block_table, att, B=B, rows=rows, Hq=self.Hq,
                                Hkv=self.Hkv, page=self.page, dtype=dt)
-            ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h)
-            ops.skinny_gemm(h, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act)
-            ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h)
+            ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha)
+            ops.skinny_gemm(ha, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act)
+            ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha)
 
     def _tail(self, B):
         """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences."""
-        ops.skinny_gemm(self.h, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
+        ops.skinny_gemm(self.h_act, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
                         eps=self.eps, epi=0, out_f32=self.logits)
         ops.sample_step(self.logits, self.state, self.out_tokens, self.speech_emb, self.x_in, V=self.V, B=B,
                         eos_id=self.eos, seed=self.seed, sampled=self.sampled, forced=self.forced,
@@ -115,7 +118,8 @@ class LlmEngine:
     def _decode_step(self):
         B = self.B
         self.h.copy_(self.x_in)
-        self._layers(self.h, B, 1, self.state[ST_POS], self.block_table)
+        self.h_act.copy_(self.x_in)
+        self._layers(self.h, self.h_act, B, 1, self.state[ST_POS], self.block_table)
         self._tail(B)
 
     # ------------------------------------------------------------------ request setup
@@ -159,9 +163,11 @@ class LlmEngine:
             for c0 in range(0, L, 64):
                 c1 = min(L, c0 + 64)
                 hc = x[c0:c1].clone()
+                hca = hc.to(self.tdt)
                 pos = torch.tensor([c0], dtype=torch.int32, device=self.dev)
-                self._layers(hc, 1, c1 - c0, pos, self.block_table[b:b + 1])
+                self._layers(hc, hca, 1, c1 - c0, pos, self.block_table[b:b + 1])
             self.h[b].copy_(hc[-1])
+            self.h_act[b].copy_(hca[-1])
             self.state[ST_POS, b] = L - 1                # the sampler's +1 makes it L (= rows in the cache)
         self._tail(B)
         if self._decode is None:

@@ -1,0 +1,64 @@
+"""GPU micro-benchmarks of single kernels (HIP events around back-to-back launches on the current stream)."""
+import os
+import sys
+import math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "minimax-speech_amd"))
+import torch
+from mmx import ops
+
+
+def timeit(fn, iters=200, warm=20):
+    for _ in range(warm):
+        fn()
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        fn()
+    e1.record(s)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def gemm_case(M, N, K, batch=1, dt=1, out="act", act="none"):
+    tdt = torch.bfloat16 if dt else torch.float32
+    x = torch.randn(batch, M, K, device="cuda").to(tdt)
+    w = ops.pack_linear(torch.randn(N, K, device="cuda") / math.sqrt(K), dt)
+    of = torch.empty(batch, M, N, device="cuda") if out in ("f32", "both") else None
+    oa = torch.empty(batch, M, N, device="cuda", dtype=tdt) if out in ("act", "both") else None
+    fn = lambda: ops.gemm(x, w, M, N, dtype=dt, lda=K, cin=K, batch=batch, a_bstride=M * K, act=act,
+                          out_f32=of, ldo_f=N, of_bstride=M * N, out_act=oa, ldo_a=N, oa_bstride=M * N)
+    us = timeit(fn)
+    fl = 2.0 * M * N * K * batch
+    print(f"gemm M={M:6d} N={N:5d} K={K:5d} b={batch:3d} out={out:5s} act={act:5s}: {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+    if which == "gemm":
+        for K in (32, 256, 1024):
+            gemm_case(500, 1024, K, 2)
+        gemm_case(500, 256, 512, 2, out="f32")
+        gemm_case(500, 256, 1024, 2, out="f32")
+        gemm_case(500, 1024, 256, 16)
+        gemm_case(500, 1024, 256, 16, act="gelu")
+        gemm_case(500, 256, 1024, 16, out="f32")
+        gemm_case(8000, 1024, 256, 1)
+        gemm_case(8192, 8192, 1024, 1)
+        gemm_case(8192, 8192, 8192, 1)
+        gemm_case(240000, 48, 336, 1, out="both")
+        gemm_case(40000, 192, 1344, 1, out="both")
+    if which == "launch":
+        x = torch.zeros(64, 256, device="cuda")
+        g = torch.ones(256, device="cuda")
+        o = torch.empty(64, 256, device="cuda")
+        print("rownorm 64x256:", timeit(lambda: ops.rownorm(x, g, g, 1e-5, rows=64, C_=256, out_f32=o, dtype=0)), "us")
+        x = torch.zeros(2, 500, 256, device="cuda")
+        o = torch.empty(2, 500, 256, device="cuda", dtype=torch.bfloat16)
+        print("rownorm 2x500x256:", timeit(lambda: ops.rownorm(x, g, g, 1e-5, rows=500, C_=256, batch=2, out_act=o, dtype=1)), "us")
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(100):
+                ops.rownorm(x, g, g, 1e-5, rows=500, C_=256, batch=2, out_act=o, dtype=1)
+        print("rownorm 2x500x256 in a 100-node graph:", timeit(gr.replay, iters=20, warm=3) / 100, "us per node")
