@@ -56,15 +56,35 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     const T* A = reinterpret_cast<const T*>(p.A) + (long)b * p.a_bstride;
     const T* W = reinterpret_cast<const T*>(p.W) + (long)b * p.w_bstride;
 
-    // per-thread chunk coordinates (constant across k tiles) and incremental (tap, c) trackers
-    int a_row[A_CHUNKS], a_tap[A_CHUNKS], a_c[A_CHUNKS];
+    // Per-thread chunk state.  Address generation is strength-reduced to a pointer bump per k-tile (the
+    // straightforward form costs ~75 VALU instructions per 16-byte load and made the loop VALU-bound):
+    // A: pointer + (tap, c) trackers, the pointer jumps by dil*lda - cin elements when c wraps into the next tap;
+    // W: pointer += BK.  Row/column validity is decided from small integer trackers.
+    const T* a_ptr[A_CHUNKS];
+    int a_c[A_CHUNKS], a_tap[A_CHUNKS];
+    long a_srow[A_CHUNKS];
+    bool a_mok[A_CHUNKS];
+    const long tap_jump = (long)p.dil * p.lda - p.cin;
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
-        int id = tid + i * 256;
-        a_row[i] = id / CPR;
-        int k = (id % CPR) * CH;
+        const int id = tid + i * 256;
+        const int r = id / CPR, k = (id % CPR) * CH;
+        const int m = m0 + r;
         a_tap[i] = k / p.cin;
         a_c[i] = k % p.cin;
+        a_srow[i] = (long)m + (long)a_tap[i] * p.dil + p.row_off;
+        a_ptr[i] = A + a_srow[i] * p.lda + a_c[i];
+        a_mok[i] = (m < p.M) && (A_FULL || id < BM * CPR);
+    }
+    const T* w_ptr[W_CHUNKS];
+    bool w_ok[W_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < W_CHUNKS; ++i) {
+        const int id = tid + i * 256;
+        const int r = id / CPR, kc = (id % CPR) * CH;
+        const int n = n0 + r;
+        w_ok[i] = (n < p.N) && (W_FULL || id < BN * CPR);
+        w_ptr[i] = W + (long)(w_ok[i] ? n : 0) * p.ldw + kc;
     }
     // register-staged prefetch ring: STAGES k-tiles of global loads in flight per workgroup (these GEMMs are
     // short-K and latency bound: M ~ 500-1000 rows, K = 256..1024), 2 LDS buffers, one barrier per k-tile
@@ -72,25 +92,25 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     uint4 a_reg[STAGES][A_CHUNKS], w_reg[STAGES][W_CHUNKS];
     const int K = p.ntaps * p.cin;
 
-    auto load_tile = [&](int kt, auto slot_c) {
+    auto load_tile = [&](int kt, auto slot_c) {       // must be called for kt = 0, 1, 2, ... in order
         constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
-            int m = m0 + a_row[i];
-            long srow = (long)m + (long)a_tap[i] * p.dil + p.row_off;
-            bool ok = (m < p.M) && (a_tap[i] < p.ntaps) && (srow >= p.row_lo) && (srow < p.row_hi);
-            if (!A_FULL) ok = ok && (tid + i * 256 < BM * CPR);
-            a_reg[slot][i] = ok ? *reinterpret_cast<const uint4*>(A + srow * p.lda + a_c[i]) : make_uint4(0, 0, 0, 0);
+            const bool ok = a_mok[i] && (a_tap[i] < p.ntaps) && (a_srow[i] >= p.row_lo) && (a_srow[i] < p.row_hi);
+            a_reg[slot][i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i]) : make_uint4(0, 0, 0, 0);
+            a_ptr[i] += BK;
             a_c[i] += BK;
-            while (a_c[i] >= p.cin) { a_c[i] -= p.cin; a_tap[i]++; }
+            while (a_c[i] >= p.cin) {
+                a_c[i] -= p.cin;
+                a_tap[i]++;
+                a_srow[i] += p.dil;
+                a_ptr[i] += tap_jump;
+            }
         }
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
-            int id = tid + i * 256;
-            int r = id / CPR, kc = (id % CPR) * CH;
-            int n = n0 + r;
-            w_reg[slot][i] = (n < p.N && (W_FULL || id < BN * CPR)) ? *reinterpret_cast<const uint4*>(W + (long)n * p.ldw + kt * BK + kc)
-                                 : make_uint4(0, 0, 0, 0);
+            w_reg[slot][i] = w_ok[i] ? *reinterpret_cast<const uint4*>(w_ptr[i]) : make_uint4(0, 0, 0, 0);
+            w_ptr[i] += BK;
         }
     };
     auto store_tile = [&](int stage, auto slot_c) {
