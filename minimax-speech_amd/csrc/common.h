@@ -45,6 +45,21 @@ __device__ __forceinline__ float wave_max(float v) {
 // activations used by the fused epilogues (codes are part of the C ABI, include/mmx_hip.h)
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_MISH = 4, ACT_TANH = 5 };
 
+// compile-time activation: a runtime `switch` inside the per-element epilogue is if-converted by the compiler
+// into evaluating EVERY activation (erf, tanh, log1p, exp ...) and selecting — ~190 instructions per output
+// element, which made every GEMM epilogue and row-norm compute bound.  Kernels dispatch once, outside the loops.
+template <int ACT, bool PRECISE>
+__device__ __forceinline__ float act_c(float v, float slope) {
+    if constexpr (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    else if constexpr (ACT == ACT_SILU) return v / (1.f + (PRECISE ? expf(-v) : __expf(-v)));
+    else if constexpr (ACT == ACT_MISH) {
+        float sp = v > 20.f ? v : log1pf(PRECISE ? expf(v) : __expf(v));
+        return v * tanhf(sp);
+    } else if constexpr (ACT == ACT_TANH) return tanhf(v);
+    else return v;
+}
+
 template <bool PRECISE>
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {

@@ -5,7 +5,7 @@
 
 // ---------------------------------------------------------------------------- rownorm
 // one wave per row; C <= 1024*? handled by a strided loop. fp32 statistics (two-pass over registers).
-template <typename T, int MAXV>
+template <typename T, int MAXV, int ACT>
 __global__ __launch_bounds__(256) void rownorm_kernel(
     const float* __restrict__ x, long ldx, long x_bs, int rows, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rms, int act,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(
         if (c >= C) continue;
         float y = (v[i] - mean) * rstd * gamma[c];
         if (!rms && beta) y += beta[c];
-        y = act_apply<PRECISE>(y, act, 0.f);
+        y = act_c<ACT, PRECISE>(y, 0.f);
         y *= rm;
         if (addvec) y = (y + addvec[(long)b * av_bs + c]) * rm;
         if (outf) outf[(long)b * of_bs + (long)row * ldo_f + c] = y;
@@ -57,12 +57,15 @@ extern "C" int mmx_rownorm(const float* x, int64_t ldx, int64_t x_bstride, int r
                            void* out_act, int64_t ldo_a, int64_t oa_bstride, int dtype, hipStream_t stream) {
     MMX_CHECK_ARG(x && gamma && rows > 0 && C > 0 && C <= 1024 && batch > 0 && (out_f32 || out_act));
     dim3 grid((rows + 3) / 4, batch);
-#define RN(T, MV) hipLaunchKernelGGL((rownorm_kernel<T, MV>), grid, dim3(256), 0, stream, x, ldx, x_bstride, rows, C, \
+    MMX_CHECK_ARG(act == ACT_NONE || act == ACT_MISH);
+#define RN2(T, MV, A) hipLaunchKernelGGL((rownorm_kernel<T, MV, A>), grid, dim3(256), 0, stream, x, ldx, x_bstride, rows, C, \
         gamma, beta, eps, rms, act, rowmask, rm_bstride, addvec, av_bstride, out_f32, ldo_f, of_bstride, (T*)out_act, ldo_a, oa_bstride)
+#define RN(T, MV) do { if (act == ACT_MISH) RN2(T, MV, ACT_MISH); else RN2(T, MV, ACT_NONE); } while (0)
     if (dtype == MMX_BF16) { if (C <= 256) RN(bf16_t, 4); else if (C <= 512) RN(bf16_t, 8); else RN(bf16_t, 16); }
     else if (dtype == MMX_F32) { if (C <= 256) RN(float, 4); else if (C <= 512) RN(float, 8); else RN(float, 16); }
     else return MMX_EARG;
 #undef RN
+#undef RN2
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

@@ -206,6 +206,8 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     const bool vec_a = outa && (p.ldo_a % VA == 0) && (p.out_off % VA == 0) && (p.oa_bstride % VA == 0) && ((uintptr_t)p.out_act % 16 == 0) && (CW % VA == 0);
     const bool vec_r = res && (p.ldr % 4 == 0) && (p.r_bstride % 4 == 0) && ((uintptr_t)p.residual % 16 == 0);
     const int erow = lane >> 2, ecol = (lane & 3) * CW;
+    auto epilogue = [&](auto act_k, auto act2_k) {
+    constexpr int ACT = decltype(act_k)::value, ACT2 = decltype(act2_k)::value;
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
 #pragma unroll
@@ -249,12 +251,12 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
                 x += p.bias[bidx];
                 if (!p.bias_per_row && ++bidx == p.bias_mod) bidx = 0;
             }
-            x = act_apply<PRECISE>(x, p.act, p.slope);
+            x = act_c<ACT, PRECISE>(x, p.slope);
             if (res) x += rr[c];
             x *= rm;
             v[c] = x;
             if (outa) {
-                float w = act_apply<PRECISE>(x, p.act2, p.slope);
+                float w = act_c<ACT2, PRECISE>(x, p.slope);
                 if (p.alpha) {
                     w = snake_apply<PRECISE>(w, p.alpha[aidx]);
                     if (++aidx == p.alpha_mod) aidx = 0;
@@ -299,6 +301,18 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
             }
         }
     }
+    };
+    using std::integral_constant;
+    switch (p.act) {                                   // uniform: one activation per launch
+        case ACT_LRELU: epilogue(integral_constant<int, ACT_LRELU>{}, integral_constant<int, ACT_NONE>{}); break;
+        case ACT_GELU: epilogue(integral_constant<int, ACT_GELU>{}, integral_constant<int, ACT_NONE>{}); break;
+        case ACT_SILU: epilogue(integral_constant<int, ACT_SILU>{}, integral_constant<int, ACT_NONE>{}); break;
+        case ACT_MISH: epilogue(integral_constant<int, ACT_MISH>{}, integral_constant<int, ACT_NONE>{}); break;
+        case ACT_TANH: epilogue(integral_constant<int, ACT_TANH>{}, integral_constant<int, ACT_NONE>{}); break;
+        default:
+            if (p.act2 == ACT_MISH) epilogue(integral_constant<int, ACT_NONE>{}, integral_constant<int, ACT_MISH>{});
+            else epilogue(integral_constant<int, ACT_NONE>{}, integral_constant<int, ACT_NONE>{});
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -323,6 +337,7 @@ static int launch_T(const GemmParams& p, hipStream_t s) {
     MMX_CHECK_ARG(p.bias_mod > 0 && p.alpha_mod > 0);
     MMX_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0);
     MMX_CHECK_ARG(p.out_f32 || p.out_act);
+    MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     if (tiles128 >= 192 && p.N > 64) return launch_cfg<T, 128, 128, 2, 2>(p, s);
     if (p.N <= 64 && (long)((p.M + 127) / 128) * p.batch >= 192) return launch_cfg<T, 128, 64, 4, 1>(p, s);
