@@ -129,55 +129,63 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
 }
 
 // ------------------------------------------------------------------------------------------ flash (bf16, D = 64)
-// block = 4 waves x 16 queries; K tile [64 keys][64 d] and V^T tile [64 d][64 keys] in LDS with 144-byte
-// rows (72 bf16: 16 rows x 144 B hit 16 distinct 16-byte bank slots -> conflict-free ds_read_b128);
-// S = Q K^T and O += P V on v_mfma_f32_16x16x32_bf16; online softmax in registers, row reductions over
-// the 16 lanes that share a query row via 4 xor-shuffles; P goes through a 2 KB per-wave LDS patch to
-// turn the C-layout tile into the A-operand layout.
+// block = 4 waves x 32 queries (2 MFMA row fragments per wave, so every K / V^T fragment read from LDS feeds two
+// MFMAs); K tile [64 keys][64 d] and V^T tile [64 d][64 keys] double-buffered in LDS with 144-byte rows
+// (72 bf16: 16 rows x 144 B hit 16 distinct 16-byte bank slots -> conflict-free ds_read_b128), register-staged
+// prefetch two tiles ahead, ONE workgroup barrier per key tile; S = Q K^T and O += P V on
+// v_mfma_f32_16x16x32_bf16; online softmax in registers (exp2 with log2e folded into the scale), row reductions
+// over the 16 lanes that share a query row via 4 xor-shuffles; P goes through a per-wave LDS patch (wave-local
+// ordering only) to turn the C-layout tile into the A-operand layout.
 __global__ __launch_bounds__(256) void attn_flash_kernel(
     const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
     const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
     int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk) {
-    constexpr int D = 64, KT = 64, LD = 72;
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * LD];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[D * LD];
-    __shared__ __attribute__((aligned(16))) bf16_t Ps[4 * 16 * LD];
+    constexpr int D = 64, KT = 64, LD = 72, QW = 32, MF = 2;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KT * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][D * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[4][QW * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int qb = blockIdx.x * 64 + wave * 16;        // this wave's first query
+    const int qb = blockIdx.x * (4 * QW) + wave * QW;  // this wave's first query
     q += (long)b * q_bs + h * D;
     k += (long)b * k_bs + h * D;
     vt += (long)b * vt_bs + (long)h * D * ldvt;
     out += (long)b * o_bs + h * D;
     const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
+    const float sc2 = scale * 1.44269504088896341f;    // scores in log2 units
 
     // Q fragments (A operand): lane (row l16, k-group g) holds Q[row][ks*32 + 8g .. +7]
-    short8_t aq[2];
-    {
-        int row = qb + l16 < Tn ? qb + l16 : Tn - 1;
+    short8_t aq[MF][2];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        int row = qb + mf * 16 + l16;
+        row = row < Tn ? row : Tn - 1;
         const bf16_t* qp = q + (long)row * ldq + 8 * g;
-        aq[0] = *reinterpret_cast<const short8_t*>(qp);
-        aq[1] = *reinterpret_cast<const short8_t*>(qp + 32);
+        aq[mf][0] = *reinterpret_cast<const short8_t*>(qp);
+        aq[mf][1] = *reinterpret_cast<const short8_t*>(qp + 32);
     }
-    float4_t o[4];
+    float4_t o[MF][4];
+    float m_run[MF][4], l_run[MF][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = float4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run[4], l_run[4];
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
-
+        for (int i = 0; i < 4; ++i) {
+            o[mf][i] = float4_t{0.f, 0.f, 0.f, 0.f};
+            m_run[mf][i] = -INFINITY;
+            l_run[mf][i] = 0.f;
+        }
     // keys beyond the last query's chunk are invisible to the whole block
     int kend = Tn;
     if (chunk > 0) {
-        int qlast = blockIdx.x * 64 + 63;
+        int qlast = blockIdx.x * (4 * QW) + 4 * QW - 1;
         if (qlast > Tn - 1) qlast = Tn - 1;
         int e = (qlast / chunk + 1) * chunk;
         if (e < kend) kend = e;
     }
-    bf16_t* Pw = Ps + wave * 16 * LD;
+    const int ntile = (kend + KT - 1) / KT;
+    bf16_t* Pw = Ps[wave];
 
-    // register-staged prefetch: the next K / V^T tile is loaded while the current one is multiplied
     uint4 kreg[2], vreg[2];
     auto load_tiles = [&](int j0) {
 #pragma unroll
@@ -190,88 +198,109 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
             vreg[i] = (j0 + c < Tn) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
         }
     };
-    load_tiles(0);
-    for (int j0 = 0; j0 < kend; j0 += KT) {
-        __syncthreads();                               // previous tile fully consumed
+    auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int id = tid + i * 256;
             int r = id >> 3, c = (id & 7) * 8;
-            *reinterpret_cast<uint4*>(Ks + r * LD + c) = kreg[i];
-            *reinterpret_cast<uint4*>(Vs + r * LD + c) = vreg[i];
+            *reinterpret_cast<uint4*>(Ks[buf] + r * LD + c) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs[buf] + r * LD + c) = vreg[i];
         }
-        if (j0 + KT < kend) load_tiles(j0 + KT);
-        __syncthreads();
-        // S = Q K^T  (4 key fragments of 16)
-        float4_t s[4];
+    };
+    load_tiles(0);
+    store_tiles(0);
+    if (ntile > 1) load_tiles(KT);
+    for (int jt = 0; jt < ntile; ++jt) {
+        const int j0 = jt * KT, buf = jt & 1;
+        __syncthreads();                               // tile jt is in LDS; every wave is done with tile jt-1
+        if (jt + 1 < ntile) store_tiles(buf ^ 1);      // tile jt+1 (its buffer was last read for tile jt-1)
+        if (jt + 2 < ntile) load_tiles(j0 + 2 * KT);
+        // S = Q K^T  (4 key fragments of 16, 2 query fragments)
+        float4_t s[MF][4];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            s[nf] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) s[mf][nf] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                short8_t bk = *reinterpret_cast<const short8_t*>(Ks + (nf * 16 + l16) * LD + ks * 32 + 8 * g);
-                s[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ks], bk, s[nf], 0, 0, 0);
+                short8_t bk = *reinterpret_cast<const short8_t*>(Ks[buf] + (nf * 16 + l16) * LD + ks * 32 + 8 * g);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+                    s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[mf][ks], bk, s[mf][nf], 0, 0, 0);
             }
         }
         // mask + online softmax; C layout: row = 4g + r (query), col = nf*16 + l16 (key)
-        float alpha[4];
+        const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = qb + 4 * g + r;
-            float mx = -INFINITY;
+        for (int mf = 0; mf < MF; ++mf) {
+            float alpha[4];
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const int j = j0 + nf * 16 + l16;
-                float x = key_visible(i, j, Tn, km, chunk) ? s[nf][r] * scale : -INFINITY;
-                s[nf][r] = x;
-                mx = fmaxf(mx, x);
+            for (int r = 0; r < 4; ++r) {
+                const int i = qb + mf * 16 + 4 * g + r;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) {
+                    float x = s[mf][nf][r] * sc2;
+                    if (need_mask && !key_visible(i, j0 + nf * 16 + l16, Tn, km, chunk)) x = -INFINITY;
+                    s[mf][nf][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                const float m_new = fmaxf(m_run[mf][r], mx);
+                const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+                alpha[r] = exp2f(m_run[mf][r] - m_safe);   // m_run = -inf -> 0
+                float rs = 0.f;
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) {
+                    float pv = exp2f(s[mf][nf][r] - m_safe);
+                    s[mf][nf][r] = pv;
+                    rs += pv;
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+                l_run[mf][r] = l_run[mf][r] * alpha[r] + rs;
+                m_run[mf][r] = m_new;
             }
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-            const float m_new = fmaxf(m_run[r], mx);
-            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-            alpha[r] = __expf(m_run[r] - m_safe);      // m_run = -inf -> 0
-            float rs = 0.f;
+            for (int df = 0; df < 4; ++df)
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                float p = __expf(s[nf][r] - m_safe);
-                s[nf][r] = p;
-                rs += p;
-            }
+                for (int r = 0; r < 4; ++r) o[mf][df][r] *= alpha[r];
+            // P -> per-wave LDS patch (row-major [32 q][64 keys])
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
-            l_run[r] = l_run[r] * alpha[r] + rs;
-            m_run[r] = m_new;
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pw[(mf * 16 + 4 * g + r) * LD + nf * 16 + l16] = f2bf(s[mf][nf][r]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        short8_t ap[MF][2];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            ap[mf][0] = *reinterpret_cast<const short8_t*>(Pw + (mf * 16 + l16) * LD + 8 * g);
+            ap[mf][1] = *reinterpret_cast<const short8_t*>(Pw + (mf * 16 + l16) * LD + 32 + 8 * g);
         }
 #pragma unroll
         for (int df = 0; df < 4; ++df)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[df][r] *= alpha[r];
-        // P -> LDS (row-major [16 q][64 keys]) -> A fragments
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Pw[(4 * g + r) * LD + nf * 16 + l16] = f2bf(s[nf][r]);
-        __syncthreads();
-        short8_t ap[2];
-        ap[0] = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 8 * g);
-        ap[1] = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 32 + 8 * g);
-#pragma unroll
-        for (int df = 0; df < 4; ++df)
-#pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                short8_t bv = *reinterpret_cast<const short8_t*>(Vs + (df * 16 + l16) * LD + ks * 32 + 8 * g);
-                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[ks], bv, o[df], 0, 0, 0);
+                short8_t bv = *reinterpret_cast<const short8_t*>(Vs[buf] + (df * 16 + l16) * LD + ks * 32 + 8 * g);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+                    o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[mf][ks], bv, o[mf][df], 0, 0, 0);
             }
+        __builtin_amdgcn_wave_barrier();               // the patch is rewritten in the next tile
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = qb + 4 * g + r;
-        if (i >= Tn) continue;
-        const float inv = l_run[r] > 0.f ? 1.f / l_run[r] : 0.f;
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int df = 0; df < 4; ++df) out[(long)i * ldo + df * 16 + l16] = f2bf(o[df][r] * inv);
-    }
+        for (int r = 0; r < 4; ++r) {
+            const int i = qb + mf * 16 + 4 * g + r;
+            if (i >= Tn) continue;
+            const float inv = l_run[mf][r] > 0.f ? 1.f / l_run[mf][r] : 0.f;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) out[(long)i * ldo + df * 16 + l16] = f2bf(o[mf][df][r] * inv);
+        }
 }
 
 extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
@@ -282,7 +311,7 @@ extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, con
     MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
     MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8);
     MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0);
-    dim3 grid((T_ + 63) / 64, H, B);
+    dim3 grid((T_ + 127) / 128, H, B);
     hipLaunchKernelGGL(attn_flash_kernel, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
                        (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk);
     MMX_LAUNCH_CHECK();

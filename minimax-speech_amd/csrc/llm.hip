@@ -248,7 +248,7 @@ static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, con
     // smallest power-of-two k split (<= 8 waves = 512 threads per workgroup, so a wave may use 256 VGPRs) whose
     // slice fits KS blocks; a longer slice is walked in chunks of KS
     const int mt = (B + 15) / 16;
-    const int KSr = mt == 1 ? 10 : (mt == 2 ? 6 : 4);  // k-blocks a wave keeps in flight (register budget)
+    const int KSr = mt == 1 ? 10 : (mt == 2 ? 7 : 4);  // k-blocks a wave keeps in flight (register budget)
     int ksplit = 1;
     while (ksplit < 8 && (nkb + ksplit - 1) / ksplit > KSr) ksplit *= 2;
     int waves = ksplit >= 4 ? ksplit : 4;
@@ -256,7 +256,7 @@ static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, con
     dim3 grid((ntiles + tpb - 1) / tpb), block(waves * 64);
     constexpr int NB = EPI == 1 ? 2 : 1;
     size_t lds = ksplit > 1 ? (size_t)waves * (NB * mt * 4 + mt) * 64 * 4 : 0;
-#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, (MT == 1 ? 10 : (MT == 2 ? 6 : 4))>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
+#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, (MT == 1 ? 10 : (MT == 2 ? 7 : 4))>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
         bias, rs, eps, outf, ldo_f, (T*)outa, ldo_a, ksplit, ntiles)
     switch (mt) {
         case 1: SK(1); break;
