@@ -155,8 +155,12 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
     const float sc2 = scale * 1.44269504088896341f;    // scores in log2 units
 
-    // Q fragments (A operand): lane (row l16, k-group g) holds Q[row][ks*32 + 8g .. +7]
-    short8_t aq[MF][2];
+    // Everything is computed TRANSPOSED so that a lane owns ONE query: S^T = K Q^T (MFMA A = K fragment,
+    // B = Q fragment) puts query l16 on the lane and keys 4g+r in its registers, so the softmax row reductions are
+    // in-lane plus two xor-shuffles (16, 32), m / l / alpha are per-lane scalars, and 4 consecutive keys of P pack
+    // into one 8-byte LDS write.  O^T = V^T P^T (A = V^T fragment, B = P fragment read like an A operand) keeps the
+    // query on the lane for the rescale and yields 4 consecutive channels per lane for 8-byte output stores.
+    short8_t aq[MF][2];                                // lane (q = l16, k-group g): Q[q][ks*32 + 8g .. +7]
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         int row = qb + mf * 16 + l16;
@@ -165,16 +169,20 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         aq[mf][0] = *reinterpret_cast<const short8_t*>(qp);
         aq[mf][1] = *reinterpret_cast<const short8_t*>(qp + 32);
     }
-    float4_t o[MF][4];
-    float m_run[MF][4], l_run[MF][4];
+    float4_t o[MF][4];                                 // O^T: [mf][df] rows d = df*16 + 4g + r, column q = l16
+    float m_run[MF], l_run[MF];
+    int lim[MF];                                       // keys j < lim are visible to this lane's query
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
+    for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[mf][i] = float4_t{0.f, 0.f, 0.f, 0.f};
-            m_run[mf][i] = -INFINITY;
-            l_run[mf][i] = 0.f;
-        }
+        for (int i = 0; i < 4; ++i) o[mf][i] = float4_t{0.f, 0.f, 0.f, 0.f};
+        m_run[mf] = -INFINITY;
+        l_run[mf] = 0.f;
+        const int i = qb + mf * 16 + l16;
+        int e = Tn;
+        if (chunk > 0) { int c2 = (i / chunk + 1) * chunk; e = c2 < e ? c2 : e; }
+        lim[mf] = e;
+    }
     // keys beyond the last query's chunk are invisible to the whole block
     int kend = Tn;
     if (chunk > 0) {
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         __syncthreads();                               // tile jt is in LDS; every wave is done with tile jt-1
         if (jt + 1 < ntile) store_tiles(buf ^ 1);      // tile jt+1 (its buffer was last read for tile jt-1)
         if (jt + 2 < ntile) load_tiles(j0 + 2 * KT);
-        // S = Q K^T  (4 key fragments of 16, 2 query fragments)
+        // S^T = K Q^T: s[mf][nf][r] = score(query qb + mf*16 + l16, key j0 + nf*16 + 4g + r)
         float4_t s[MF][4];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
@@ -226,55 +234,65 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 short8_t bk = *reinterpret_cast<const short8_t*>(Ks[buf] + (nf * 16 + l16) * LD + ks * 32 + 8 * g);
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
-                    s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[mf][ks], bk, s[mf][nf], 0, 0, 0);
+                    s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, aq[mf][ks], s[mf][nf], 0, 0, 0);
             }
         }
-        // mask + online softmax; C layout: row = 4g + r (query), col = nf*16 + l16 (key)
-        const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-            float alpha[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = qb + mf * 16 + 4 * g + r;
-                float mx = -INFINITY;
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf) {
-                    float x = s[mf][nf][r] * sc2;
-                    if (need_mask && !key_visible(i, j0 + nf * 16 + l16, Tn, km, chunk)) x = -INFINITY;
-                    s[mf][nf][r] = x;
-                    mx = fmaxf(mx, x);
-                }
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-                const float m_new = fmaxf(m_run[mf][r], mx);
-                const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-                alpha[r] = exp2f(m_run[mf][r] - m_safe);   // m_run = -inf -> 0
-                float rs = 0.f;
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf) {
-                    float pv = exp2f(s[mf][nf][r] - m_safe);
-                    s[mf][nf][r] = pv;
-                    rs += pv;
-                }
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
-                l_run[mf][r] = l_run[mf][r] * alpha[r] + rs;
-                m_run[mf][r] = m_new;
-            }
-#pragma unroll
-            for (int df = 0; df < 4; ++df)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[mf][df][r] *= alpha[r];
-            // P -> per-wave LDS patch (row-major [32 q][64 keys])
+        const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);       // uniform per tile
+        float kmv[4][4];
+        if (km) {
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Pw[(mf * 16 + 4 * g + r) * LD + nf * 16 + l16] = f2bf(s[mf][nf][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + nf * 16 + 4 * g + r;
+                    kmv[nf][r] = j < Tn ? km[j] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = s[mf][nf][r] * sc2;
+                    if (need_mask) {
+                        bool vis = (j0 + nf * 16 + 4 * g + r) < lim[mf];
+                        if (km) vis = vis && kmv[nf][r] != 0.f;
+                        x = vis ? x : -INFINITY;
+                    }
+                    s[mf][nf][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[mf], mx);
+            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[mf] - m_safe);   // m_run = -inf -> 0
+            float rs = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                float p0 = __builtin_amdgcn_exp2f(s[mf][nf][0] - m_safe), p1 = __builtin_amdgcn_exp2f(s[mf][nf][1] - m_safe);
+                float p2 = __builtin_amdgcn_exp2f(s[mf][nf][2] - m_safe), p3 = __builtin_amdgcn_exp2f(s[mf][nf][3] - m_safe);
+                rs += (p0 + p1) + (p2 + p3);
+                // 4 consecutive keys of query l16 -> one 8-byte write into the row-major [q][key] patch
+                uint2 pk;
+                pk.x = (unsigned)f2bf(p0) | ((unsigned)f2bf(p1) << 16);
+                pk.y = (unsigned)f2bf(p2) | ((unsigned)f2bf(p3) << 16);
+                *reinterpret_cast<uint2*>(Pw + (mf * 16 + l16) * LD + nf * 16 + 4 * g) = pk;
+            }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run[mf] = l_run[mf] * alpha + rs;
+            m_run[mf] = m_new;
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[mf][df][r] *= alpha;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        short8_t ap[MF][2];
+        short8_t ap[MF][2];                            // lane (q = l16, g): P[q][ks*32 + 8g .. +7]
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             ap[mf][0] = *reinterpret_cast<const short8_t*>(Pw + (mf * 16 + l16) * LD + 8 * g);
@@ -287,20 +305,23 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 short8_t bv = *reinterpret_cast<const short8_t*>(Vs[buf] + (df * 16 + l16) * LD + ks * 32 + 8 * g);
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
-                    o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[mf][ks], bv, o[mf][df], 0, 0, 0);
+                    o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, ap[mf][ks], o[mf][df], 0, 0, 0);
             }
         __builtin_amdgcn_wave_barrier();               // the patch is rewritten in the next tile
     }
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
+    for (int mf = 0; mf < MF; ++mf) {
+        const int i = qb + mf * 16 + l16;
+        if (i >= Tn) continue;
+        const float inv = l_run[mf] > 0.f ? 1.f / l_run[mf] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = qb + mf * 16 + 4 * g + r;
-            if (i >= Tn) continue;
-            const float inv = l_run[mf][r] > 0.f ? 1.f / l_run[mf][r] : 0.f;
-#pragma unroll
-            for (int df = 0; df < 4; ++df) out[(long)i * ldo + df * 16 + l16] = f2bf(o[mf][df][r] * inv);
+        for (int df = 0; df < 4; ++df) {
+            uint2 pk;
+            pk.x = (unsigned)f2bf(o[mf][df][0] * inv) | ((unsigned)f2bf(o[mf][df][1] * inv) << 16);
+            pk.y = (unsigned)f2bf(o[mf][df][2] * inv) | ((unsigned)f2bf(o[mf][df][3] * inv) << 16);
+            *reinterpret_cast<uint2*>(out + (long)i * ldo + df * 16 + 4 * g) = pk;
         }
+    }
 }
 
 extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,

@@ -82,8 +82,6 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     __shared__ float cand_p[SAMP_MAXK];
     __shared__ int cand_i[SAMP_MAXK];
     __shared__ int sh_n, sh_top;
-    __shared__ float wc_p[(SAMP_THREADS / 64) * SAMP_MAXK];
-    __shared__ int wc_i[(SAMP_THREADS / 64) * SAMP_MAXK];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nb = gridDim.x;                          // state is field-major: state[field * B + b]
     int32_t* st = state + b;
@@ -130,10 +128,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     for (int i = 0; i < SAMP_MAXV; ++i)
         if (tid + i * SAMP_THREADS < V) x[i] = x[i] / se2;   // p
 
-    // nucleus candidates = prefix of the stable descending sort.  Two levels, no workgroup barrier inside the
-    // loops: every wave extracts the top_k of its own 64 x 26 values by repeated wave arg-max (shuffles only, only
-    // the round's winner rescans its values); wave 0 then merges the 4 x top_k survivors the same way while
-    // accumulating the fp32 running sum in the reference's order (common.py:124-131).
+    // nucleus candidates: repeated block arg-max == stable descending sort prefix.  Every thread keeps the
+    // arg-max of its own (not yet taken) values; only the round's winner rescans its 26 values.
     float p_work[SAMP_MAXV];
 #pragma unroll
     for (int i = 0; i < SAMP_MAXV; ++i) p_work[i] = x[i];
@@ -143,55 +139,22 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
         for (int i = 0; i < SAMP_MAXV; ++i) a = better(a, ArgMax{p_work[i], tid + i * SAMP_THREADS});
         return a;
     };
-    auto wave_argmax = [&](ArgMax v) {
+    ArgMax mine = local_best();
+    float cum = 0.f;
+    int nc = 0;
+    while (cum < top_p && nc < top_k) {
+        ArgMax a = block_argmax(mine, sha);
+        if (tid == 0) { cand_p[nc] = a.v; cand_i[nc] = a.i; }
+        if ((a.i & (SAMP_THREADS - 1)) == tid) {       // index = tid + i*256 -> owner thread
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            ArgMax y;
-            y.v = __shfl_xor(v.v, o, 64);
-            y.i = __shfl_xor(v.i, o, 64);
-            v = better(v, y);
+            for (int i = 0; i < SAMP_MAXV; ++i)
+                if (tid + i * SAMP_THREADS == a.i) p_work[i] = -1.f;
+            mine = local_best();
         }
-        return v;
-    };
-    {
-        ArgMax mine = local_best();
-        const int wv = tid >> 6;
-        for (int rnd = 0; rnd < top_k; ++rnd) {
-            ArgMax a = wave_argmax(mine);
-            if ((tid & 63) == 0) { wc_p[wv * SAMP_MAXK + rnd] = a.v; wc_i[wv * SAMP_MAXK + rnd] = a.i; }
-            if ((a.i & (SAMP_THREADS - 1)) == tid) {
-#pragma unroll
-                for (int i = 0; i < SAMP_MAXV; ++i)
-                    if (tid + i * SAMP_THREADS == a.i) p_work[i] = -1.f;
-                mine = local_best();
-            }
-        }
+        cum += a.v;                                    // fp32 running sum, same order as common.py:127
+        nc++;
     }
     __syncthreads();
-    if (tid < 64) {
-        const int nwave = SAMP_THREADS / 64, tot = nwave * top_k;        // <= 256 survivors, 4 per lane
-        ArgMax c[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int id = tid + u * 64;
-            c[u] = id < tot ? ArgMax{wc_p[(id / top_k) * SAMP_MAXK + id % top_k], wc_i[(id / top_k) * SAMP_MAXK + id % top_k]}
-                            : ArgMax{-2.f, 0x7fffffff};
-        }
-        float cum = 0.f;
-        int nc = 0;
-        while (cum < top_p && nc < top_k) {
-            ArgMax a = wave_argmax(better(better(c[0], c[1]), better(c[2], c[3])));
-            if (tid == 0) { cand_p[nc] = a.v; cand_i[nc] = a.i; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (c[u].i == a.i) c[u].v = -2.f;
-            cum += a.v;                                // fp32 running sum, same order as common.py:127
-            nc++;
-        }
-        if (tid == 0) sh_n = nc;
-    }
-    __syncthreads();
-    const int nc = sh_n;
 
     const bool ignore_eos = step < min_len;
     int top = 0;
