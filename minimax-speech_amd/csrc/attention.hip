@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 rs += (p0 + p1) + (p2 + p3);
                 // 4 consecutive keys of query l16 -> one 8-byte write into the row-major [q][key] patch
                 uint2 pk;
-                pk.x = (unsigned)f2bf(p0) | ((unsigned)f2bf(p1) << 16);
-                pk.y = (unsigned)f2bf(p2) | ((unsigned)f2bf(p3) << 16);
+                pk.x = pack_bf16x2(p0, p1);
+                pk.y = pack_bf16x2(p2, p3);
                 *reinterpret_cast<uint2*>(Pw + (mf * 16 + l16) * LD + nf * 16 + 4 * g) = pk;
             }
             rs += __shfl_xor(rs, 16, 64);
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             uint2 pk;
-            pk.x = (unsigned)f2bf(o[mf][df][0] * inv) | ((unsigned)f2bf(o[mf][df][1] * inv) << 16);
-            pk.y = (unsigned)f2bf(o[mf][df][2] * inv) | ((unsigned)f2bf(o[mf][df][3] * inv) << 16);
+            pk.x = pack_bf16x2(o[mf][df][0] * inv, o[mf][df][1] * inv);
+            pk.y = pack_bf16x2(o[mf][df][2] * inv, o[mf][df][3] * inv);
             *reinterpret_cast<uint2*>(out + (long)i * ldo + df * 16 + 4 * g) = pk;
         }
     }

@@ -15,10 +15,13 @@ typedef __attribute__((ext_vector_type(4))) short short4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 // round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// hardware conversion: a plain cast to __bf16 lowers to v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN preserved)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, v);
 }
 
 template <typename T> struct Cvt;

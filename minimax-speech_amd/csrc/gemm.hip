@@ -283,10 +283,10 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
 #pragma unroll
                     for (int c = 0; c < CW; c += 8) {
                         uint4 pk;
-                        pk.x = (unsigned)f2bf(w2[c]) | ((unsigned)f2bf(w2[c + 1]) << 16);
-                        pk.y = (unsigned)f2bf(w2[c + 2]) | ((unsigned)f2bf(w2[c + 3]) << 16);
-                        pk.z = (unsigned)f2bf(w2[c + 4]) | ((unsigned)f2bf(w2[c + 5]) << 16);
-                        pk.w = (unsigned)f2bf(w2[c + 6]) | ((unsigned)f2bf(w2[c + 7]) << 16);
+                        pk.x = pack_bf16x2(w2[c], w2[c + 1]);
+                        pk.y = pack_bf16x2(w2[c + 2], w2[c + 3]);
+                        pk.z = pack_bf16x2(w2[c + 4], w2[c + 5]);
+                        pk.w = pack_bf16x2(w2[c + 6], w2[c + 7]);
                         *reinterpret_cast<uint4*>(outa + lin + c) = pk;
                     }
                 } else {
