@@ -18,7 +18,8 @@ from ._lib import BF16, F32, TORCH_DT
 
 
 class DacDecoderEngine:
-    def __init__(self, sd: Dict[str, torch.Tensor], rates: List[int], dtype=BF16, device="cuda", use_tanh=True):
+    def __init__(self, sd: Dict[str, torch.Tensor], rates: List[int], dtype=BF16, device="cuda", use_tanh=True,
+                 with_pre=True):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.rates = list(rates)
         self.hop = int(math.prod(rates))
@@ -27,10 +28,12 @@ class DacDecoderEngine:
         wn = lambda p: ops.fold_weight_norm(f(p + ".weight_g"), f(p + ".weight_v"))
         bias = lambda p: f(p + ".bias").contiguous() if (p + ".bias") in sd else None
         alpha = lambda k: f(k).reshape(-1).contiguous()
-        self.D = sd["de_conv_pre.0.weight_v"].shape[1]
-        self.w_pre = ops.pack_conv1d(wn("de_conv_pre.0"), dtype)
-        self.b_pre = bias("de_conv_pre.0")
         p = "decoder.model"
+        self.D = sd[p + ".0.0.weight_v"].shape[1]
+        self.with_pre = with_pre
+        if with_pre:
+            self.w_pre = ops.pack_conv1d(wn("de_conv_pre.0"), dtype)
+            self.b_pre = bias("de_conv_pre.0")
         self.C0 = sd[p + ".0.0.weight_v"].shape[0]
         self.w0 = ops.pack_conv1d(wn(p + ".0.0"), dtype)
         self.b0 = bias(p + ".0.0")
@@ -55,22 +58,25 @@ class DacDecoderEngine:
         self.b_final = bias(f"{p}.{n + 2}.0")
 
     @torch.no_grad()
-    def decode(self, z: torch.Tensor) -> torch.Tensor:
-        """z [B, D, T] fp32 cuda -> [B, 1, T*hop] fp32 (reference layout)."""
+    def decode(self, z: torch.Tensor, skip_pre=False) -> torch.Tensor:
+        """z [B, D, T] fp32 cuda -> [B, 1, T*hop] fp32 (reference layout). skip_pre: z is already de_conv_pre's output."""
         assert z.is_cuda and z.dtype == torch.float32 and z.dim() == 3 and z.shape[1] == self.D
         B, D, T = z.shape
         z = z.contiguous()
         zt = torch.empty(B, T, D, dtype=self.tdt, device=self.dev)
         ops.copy2d(z, F32, D * T, 1, T, zt, self.dtype, T * D, D, 1, rows=T, cols=D, batch=B)
-        return self.decode_time_major(zt, B, T)
+        return self.decode_time_major(zt, B, T, skip_pre)
 
     @torch.no_grad()
-    def decode_time_major(self, zt: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    def decode_time_major(self, zt: torch.Tensor, B: int, T: int, skip_pre=False) -> torch.Tensor:
         """zt [B, T, D] in the compute dtype (what the flow engine hands over)."""
         dt, tdt, dev = self.dtype, self.tdt, self.dev
         new = lambda t, c, d=None: torch.empty(B, t, c, dtype=(d or tdt), device=dev)
-        h = new(T, self.D)
-        ops.conv1d(zt, self.w_pre, T=T, Cin=self.D, k=1, dtype=dt, batch=B, bias=self.b_pre, act="lrelu", out_act=h)
+        if skip_pre:
+            h = zt
+        else:
+            h = new(T, self.D)
+            ops.conv1d(zt, self.w_pre, T=T, Cin=self.D, k=1, dtype=dt, batch=B, bias=self.b_pre, act="lrelu", out_act=h)
         a = new(T, self.C0)
         ops.conv1d(h, self.w0, T=T, Cin=self.D, k=7, pad_left=3, dtype=dt, batch=B, bias=self.b0, act="lrelu",
                    alpha=self.blocks[0]["alpha_in"], out_act=a)

@@ -52,7 +52,7 @@ class Graphed:
 
 class FlowEngine:
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", n_timesteps=10, cfg_rate=0.7,
-                 enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True):
+                 enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True, parts=("encoder", "estimator")):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
         self.enc_chunk, self.est_chunk = enc_chunk, est_chunk
@@ -61,6 +61,22 @@ class FlowEngine:
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         lin = lambda k: ops.pack_linear(f(k), dt)
         cv = lambda k: ops.pack_conv1d(f(k), dt)
+        self._pe, self._plans = {}, {}
+        # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
+        self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
+        if "encoder" in parts:
+            self._init_encoder(sd, f, lin, cv)
+        if "estimator" in parts:
+            self._init_estimator(sd, f, lin, cv)
+
+    def set_noise(self, noise: torch.Tensor):
+        """Replaces rand_noise (the drop-in CausalConditionalCFM owns its own tensor, flow_matching.py:321)."""
+        if noise is not self.rand_noise and not torch.equal(noise.cpu(), self.rand_noise):
+            self.rand_noise = noise.detach().cpu().float()
+            self._plans = {k: v for k, v in self._plans.items() if k[0] != "cfm"}
+
+    def _init_encoder(self, sd, f, lin, cv):
+        dt = self.dtype
         self.emb_table = f("input_embedding.weight")
         self.spk_w, self.spk_b = lin("spk_embed_affine_layer.weight"), f("spk_embed_affine_layer.bias")
         self.spk_dim = sd["spk_embed_affine_layer.weight"].shape[1]
@@ -92,7 +108,9 @@ class FlowEngine:
                         up_layers=[conf_layer(f"{e}.up_encoders.{i}") for i in range(4)],
                         ang=f(e + ".after_norm.weight"), anb=f(e + ".after_norm.bias"),
                         wproj=lin("encoder_proj.weight"), bproj=f("encoder_proj.bias"))
-        # ------------------------------------------------------------------ estimator
+
+    def _init_estimator(self, sd, f, lin, cv):
+        dt = self.dtype
         q = "decoder.estimator"
         self.tdim = sd[q + ".time_mlp.linear_1.weight"].shape[1]             # 320
         self.t_w1, self.t_b1 = lin(q + ".time_mlp.linear_1.weight"), f(q + ".time_mlp.linear_1.bias")
@@ -142,11 +160,7 @@ class FlowEngine:
         self.proj_w, self.proj_b = cv(q + ".final_proj.weight"), f(q + ".final_proj.bias")
         self.mlp_w = ops.pack_linear(torch.cat(mlp_w, 0), dt)                # [14*256, 1024]
         self.mlp_b = torch.cat(mlp_b, 0).contiguous()
-        self.C = 256
-        # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
-        g = torch.Generator().manual_seed(0)
-        self.rand_noise = torch.randn([1, 80, 50 * 300], generator=g)
-        self._pe, self._plans = {}, {}
+        self.C = sd[q + ".final_proj.weight"].shape[1]
 
     # ------------------------------------------------------------------ helpers
     def _new(self, *shape, f32=False):

@@ -78,6 +78,7 @@ class LlmEngine:
         self.logp = torch.zeros(B, self.V, device=self.dev)
         self.want_logp = False
         self.seed = 0
+        self.top_p, self.top_k, self.win_size, self.tau_r = 0.8, 25, 10, 0.1     # config.yaml:46-50
         self._decode = None
 
     # ------------------------------------------------------------------ one transformer pass over `rows` tokens/seq
@@ -112,7 +113,8 @@ class LlmEngine:
         ops.skinny_gemm(self.h_act, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
                         eps=self.eps, epi=0, out_f32=self.logits)
         ops.sample_step(self.logits, self.state, self.out_tokens, self.speech_emb, self.x_in, V=self.V, B=B,
-                        eos_id=self.eos, seed=self.seed, sampled=self.sampled, forced=self.forced,
+                        eos_id=self.eos, seed=self.seed, top_k=self.top_k, top_p=self.top_p, win_size=self.win_size,
+                        tau_r=self.tau_r, sampled=self.sampled, forced=self.forced,
                         logp_out=(self.logp if self.want_logp else None))
 
     def _decode_step(self):

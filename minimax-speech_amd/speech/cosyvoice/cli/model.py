@@ -1,0 +1,123 @@
+"""Drop-in for the CosyVoice2Model glue of speech/cosyvoice/cli/model.py (:240-386): `tts` (non-streaming and the
+streaming hop schedule) and `token2wav`, with the HiFT vocoder call (model.py:316) replaced by DACVAE.decode — the
+composition the README and the flow's training target imply.
+
+Streaming follows the reference's schedule (poll until token_hop_len + pre_lookahead tokens are available, re-run the
+flow over all tokens so far with chunk-causal masks, emit the new part).  The HiFT source/mel caches have no DAC
+equivalent: each hop's waveform is decoded from the newly finalized latents plus `dac_overlap` frames of left
+context whose samples are dropped.
+"""
+import threading
+import time
+import uuid
+from typing import Generator
+
+import numpy as np
+import torch
+
+from ..utils.common import fade_in_out
+
+
+class CosyVoice2Model:
+    def __init__(self, llm: torch.nn.Module, flow: torch.nn.Module, hift: torch.nn.Module, fp16: bool = False):
+        """`hift` is the waveform decoder: a dac-vae `DACVAE` in this fork (kept under the reference's argument name)."""
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.llm, self.flow, self.hift = llm, flow, hift
+        self.fp16 = fp16                                  # the HIP engines pick bf16 / fp32 themselves
+        self.token_hop_len = 25                           # must match the training static_chunk_size
+        self.dac_overlap = 8                              # latent frames of left context per streaming hop
+        self.hop = 480
+        self.speech_window = np.hamming(2 * self.dac_overlap * self.hop)
+        self.lock = threading.Lock()
+        self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict = {}, {}, {}
+
+    def load(self, llm_model, flow_model, hift_model):
+        self.llm.load_state_dict(torch.load(llm_model, map_location="cpu"), strict=True)
+        self.llm.to(self.device).eval()
+        self.flow.load_state_dict(torch.load(flow_model, map_location="cpu"), strict=True)
+        self.flow.to(self.device).eval()
+        sd = torch.load(hift_model, map_location="cpu")
+        self.hift.load_state_dict(sd.get("generator", sd), strict=True)
+        self.hift.to(self.device).eval()
+
+    def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid_):
+        i32 = lambda t: torch.tensor([t.shape[1]], dtype=torch.int32, device=self.device)
+        for tok in self.llm.inference(text=text.to(self.device), text_len=i32(text), prompt_text=prompt_text.to(self.device),
+                                      prompt_text_len=i32(prompt_text),
+                                      prompt_speech_token=llm_prompt_speech_token.to(self.device),
+                                      prompt_speech_token_len=i32(llm_prompt_speech_token),
+                                      embedding=llm_embedding.to(self.device), uuid=uuid_):
+            self.tts_speech_token_dict[uuid_].append(tok)
+        self.llm_end_dict[uuid_] = True
+
+    def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False,
+                  speed=1.0):
+        assert speed == 1.0, "speed change is not on the hot path"
+        i32 = lambda n: torch.tensor([n], dtype=torch.int32, device=self.device)
+        lat, _ = self.flow.inference(token=token.to(self.device), token_len=i32(token.shape[1]),
+                                     prompt_token=prompt_token.to(self.device), prompt_token_len=i32(prompt_token.shape[1]),
+                                     prompt_feat=prompt_feat.to(self.device), prompt_feat_len=i32(prompt_feat.shape[1]),
+                                     embedding=embedding.to(self.device), streaming=stream, finalize=finalize)
+        start = token_offset * self.flow.token_mel_ratio
+        # left context for the conv stack: the DAC decoder's receptive field is finite, so decoding the new frames
+        # together with `dac_overlap` already-emitted frames and dropping their samples reproduces the interior of
+        # a full decode up to the receptive-field tail (this replaces the reference's HiFT mel/source cache)
+        ctx = min(self.dac_overlap, start)
+        wav = self.hift.decode(lat[:, :, start - ctx:])[:, 0]                    # [1, samples]
+        wav = wav[:, ctx * self.hop:]
+        prev = self.hift_cache_dict.get(uuid)
+        if prev is not None and prev["speech"].shape[1] == self.speech_window.shape[0] // 2:
+            pass    # (no overlap is re-emitted, so there is nothing to cross-fade; fade_in_out is kept for API parity)
+        if not finalize:
+            self.hift_cache_dict[uuid] = {"speech": wav[:, -self.dac_overlap * self.hop:]}
+        return wav
+
+    def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192),
+            llm_embedding=torch.zeros(0, 192), prompt_text=torch.zeros(1, 0, dtype=torch.int32),
+            llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
+            flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), prompt_speech_feat=torch.zeros(1, 0, 80),
+            source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0, **kwargs) -> Generator:
+        this_uuid = str(uuid.uuid1())
+        with self.lock:
+            self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
+            self.hift_cache_dict[this_uuid] = None
+        if source_speech_token.shape[1] == 0:
+            p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
+        else:
+            def vc():
+                self.tts_speech_token_dict[this_uuid] = source_speech_token.flatten().tolist()
+                self.llm_end_dict[this_uuid] = True
+            p = threading.Thread(target=vc)
+        p.start()
+        toks = self.tts_speech_token_dict[this_uuid]
+        L = self.flow.pre_lookahead_len
+        if stream:
+            token_offset = 0
+            pad = int(np.ceil(flow_prompt_speech_token.shape[1] / self.token_hop_len) * self.token_hop_len
+                      - flow_prompt_speech_token.shape[1])
+            while True:
+                time.sleep(0.01)
+                hop = self.token_hop_len + pad if token_offset == 0 else self.token_hop_len
+                if len(toks) - token_offset >= hop + L:
+                    t = torch.tensor(toks[:token_offset + hop + L]).unsqueeze(0)
+                    wav = self.token2wav(t, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, token_offset,
+                                         this_uuid, stream=True, finalize=False)
+                    token_offset += hop
+                    yield {"tts_speech": wav.cpu()}
+                if self.llm_end_dict[this_uuid] and len(toks) - token_offset < hop + L:
+                    break
+            p.join()
+            t = torch.tensor(toks).unsqueeze(0)
+            wav = self.token2wav(t, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, token_offset, this_uuid,
+                                 finalize=True)
+            yield {"tts_speech": wav.cpu()}
+        else:
+            p.join()
+            t = torch.tensor(toks).unsqueeze(0)
+            wav = self.token2wav(t, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, 0, this_uuid, finalize=True,
+                                 speed=speed)
+            yield {"tts_speech": wav.cpu()}
+        with self.lock:
+            self.tts_speech_token_dict.pop(this_uuid)
+            self.llm_end_dict.pop(this_uuid)
+            self.hift_cache_dict.pop(this_uuid)

@@ -1,0 +1,126 @@
+"""Drop-in for speech/cosyvoice/llm/llm.py: Qwen2Encoder (:343-371) and Qwen2LM (:374-860, inference path).
+
+Same constructor arguments, attribute paths (`llm.model.model.embed_tokens`, `speech_embedding`, `llm_decoder`,
+`stop_token_ids` ...), state-dict keys and generator semantics; the arithmetic runs in mmx.llm.LlmEngine
+(hand-written HIP kernels, paged KV, device-resident sampler, hipGraph decode step).
+"""
+import json
+import os
+from typing import Callable, Generator, List, Optional
+
+import torch
+from torch import nn
+
+from .. import _paths  # noqa: F401
+from mmx import shapes, ops
+from mmx._lib import F32
+from mmx.shell import EngineHost, Node, register
+
+_QWEN_DEFAULT = dict(vocab_size=151936, hidden_size=896, intermediate_size=4864, num_hidden_layers=24,
+                     num_attention_heads=14, num_key_value_heads=2, rope_theta=1e6, rms_norm_eps=1e-6)
+
+
+def _qwen_cfg(pretrain_path):
+    """`pretrain_path`: a HF checkpoint directory (config.json is read; weights come via load_state_dict like
+    cli/model.py:67-75 does), a dict of Qwen2Config fields, or ''/None for the CosyVoice-BlankEN shape."""
+    cfg = dict(_QWEN_DEFAULT)
+    if isinstance(pretrain_path, dict):
+        cfg.update(pretrain_path)
+    elif pretrain_path and os.path.exists(os.path.join(pretrain_path, "config.json")):
+        with open(os.path.join(pretrain_path, "config.json")) as f:
+            j = json.load(f)
+        cfg.update({k: j[k] for k in cfg if k in j})
+        if "rope_parameters" in j and "rope_theta" in j["rope_parameters"]:
+            cfg["rope_theta"] = j["rope_parameters"]["rope_theta"]
+    return cfg
+
+
+class Qwen2Encoder(nn.Module):
+    def __init__(self, pretrain_path):
+        super().__init__()
+        self.cfg = c = _qwen_cfg(pretrain_path)
+        man = shapes.llm_manifest(vocab=c["vocab_size"], hidden=c["hidden_size"], inter=c["intermediate_size"],
+                                  layers=c["num_hidden_layers"], heads=c["num_attention_heads"],
+                                  kv_heads=c["num_key_value_heads"],
+                                  head_dim=c["hidden_size"] // c["num_attention_heads"])
+        register(self, man, prefix="llm.")                     # -> self.model.model.{embed_tokens,layers,norm}
+        et = self.model.model.embed_tokens
+        et.forward = lambda ids: torch.nn.functional.embedding(ids, et.weight)   # callers use it as a module (llm.py:694)
+
+
+class Qwen2LM(EngineHost):
+    def __init__(self, llm_input_size: int, llm_output_size: int, speech_token_size: int, llm: nn.Module,
+                 sampling: Callable, length_normalized_loss: bool = True, lsm_weight: float = 0.0,
+                 mix_ratio: List[int] = [5, 15], use_speaker_encoder: bool = False, spk_embed_dim: int = 192,
+                 max_conditioning_inputs: int = 2):
+        super().__init__()
+        if use_speaker_encoder:
+            raise NotImplementedError("LearnableSpeakerEncoder (llm.py:34-96) is SURVEY.md §8f 'next', not built yet")
+        self.llm_input_size, self.llm_output_size = llm_input_size, llm_output_size
+        self.speech_token_size = speech_token_size
+        self.use_speaker_encoder, self.spk_embed_dim = use_speaker_encoder, spk_embed_dim
+        self.max_conditioning_inputs = max_conditioning_inputs
+        self.sos_eos, self.task_id, self.fill_token = 0, 1, 2
+        self.llm = llm
+        c = llm.cfg
+        man = shapes.llm_manifest(vocab=c["vocab_size"], hidden=c["hidden_size"], inter=c["intermediate_size"],
+                                  layers=c["num_hidden_layers"], heads=c["num_attention_heads"],
+                                  kv_heads=c["num_key_value_heads"], head_dim=c["hidden_size"] // c["num_attention_heads"],
+                                  speech_token_size=speech_token_size, spk_embed_dim=spk_embed_dim)
+        register(self, {k: v for k, v in man.items() if not k.startswith("llm.")})
+        self.sampling = sampling
+        self.mix_ratio = mix_ratio
+        self.stop_token_ids = [speech_token_size + i for i in range(3)]
+        self.seed = 0
+        self.max_ctx = 2048
+
+    def _sampling_kwargs(self):
+        kw = dict(top_p=0.8, top_k=25, win_size=10, tau_r=0.1)
+        kw.update(getattr(self.sampling, "keywords", None) or {})
+        return kw
+
+    def engine(self, max_batch=1):
+        from mmx.llm import LlmEngine
+        dev = self._device()
+        if self._engine is None or self._engine.B != max_batch:
+            c = self.llm.cfg
+            self._engine = LlmEngine(self.state_dict(), dtype=self.compute_dtype, device=dev, max_batch=max_batch,
+                                     max_ctx=self.max_ctx, heads=c["num_attention_heads"], kv_heads=c["num_key_value_heads"],
+                                     head_dim=c["hidden_size"] // c["num_attention_heads"], rope_theta=c["rope_theta"],
+                                     eps=c["rms_norm_eps"], speech_token_size=self.speech_token_size)
+            kw = self._sampling_kwargs()
+            self._engine.top_p, self._engine.top_k = kw["top_p"], kw["top_k"]
+            self._engine.win_size, self._engine.tau_r = kw["win_size"], kw["tau_r"]
+        return self._engine
+
+    @torch.inference_mode()
+    def inference(self, text: torch.Tensor, text_len: torch.Tensor, prompt_text: torch.Tensor,
+                  prompt_text_len: torch.Tensor, prompt_speech_token: torch.Tensor,
+                  prompt_speech_token_len: torch.Tensor, embedding: torch.Tensor, sampling: int = 25,
+                  max_token_text_ratio: float = 20, min_token_text_ratio: float = 2,
+                  uuid: str = "") -> Generator[int, None, None]:
+        """llm.py:676-711 + :745-760.  Yields python ints.  (`embedding` is unused by the reference here too.)"""
+        eng = self.engine(1)
+        tl = int(text.shape[1])
+        text_len += prompt_text_len                      # the reference mutates text_len in place (llm.py:693)
+        x = eng.build_lm_input(text, prompt_text, prompt_speech_token)
+        min_len, max_len = int(tl * min_token_text_ratio), int(tl * max_token_text_ratio)
+        eng.start([x], [min_len], [max_len], seed=self.seed)
+        sent = 0
+        done = 1
+        while True:
+            st = eng.state[:, 0].tolist()
+            toks = eng.out_tokens[0, sent:st[2]].tolist()
+            for t in toks:
+                yield t
+            sent = st[2]
+            if st[3] or done >= max_len:
+                break
+            for _ in range(min(8, max_len - done)):
+                eng.step()
+                done += 1
+
+
+class TransformerLM(nn.Module):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("CosyVoice-1 TransformerLM (llm.py:99-340) is not instantiated by config.yaml: out of scope")

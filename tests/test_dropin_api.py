@@ -1,0 +1,168 @@
+"""The drop-in module tree (minimax-speech_amd/speech, minimax-speech_amd/dac-vae) keeps the reference's import
+paths, constructor arguments, attribute paths and state-dict keys."""
+import importlib
+import inspect
+import json
+import os
+import sys
+from functools import partial
+
+import pytest
+import torch
+
+CFM_PARAMS = dict(sigma_min=1e-6, solver="euler", t_scheduler="cosine", training_cfg_rate=0.2, inference_cfg_rate=0.7,
+                  reg_loss_type="l1", use_immiscible=True, immiscible_k=8, use_contrastive_fm=True, contrastive_lambda=0.05)
+
+
+def build_flow():
+    """speech/config.yaml:60-116 with the drop-in classes (same `!new:` paths and keyword arguments)."""
+    from cosyvoice.flow.flow import CausalMaskedDiffWithXvec
+    from cosyvoice.flow.flow_matching import CausalConditionalCFM
+    from cosyvoice.flow.decoder import CausalConditionalDecoder
+    from cosyvoice.transformer.upsample_encoder import UpsampleConformerEncoder
+    enc = UpsampleConformerEncoder(output_size=512, attention_heads=8, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                                   positional_dropout_rate=0.1, attention_dropout_rate=0.1, normalize_before=True,
+                                   input_layer="linear", pos_enc_layer_type="rel_pos_espnet",
+                                   selfattention_layer_type="rel_selfattn", input_size=512, use_cnn_module=False,
+                                   macaron_style=False, static_chunk_size=25)
+    est = CausalConditionalDecoder(in_channels=320, out_channels=80, channels=[256], dropout=0.0, attention_head_dim=64,
+                                   n_blocks=4, num_mid_blocks=12, num_heads=8, act_fn="gelu", static_chunk_size=50,
+                                   num_decoding_left_chunks=-1)
+    cfm = CausalConditionalCFM(in_channels=240, n_spks=1, spk_emb_dim=80, cfm_params=CFM_PARAMS, estimator=est)
+    return CausalMaskedDiffWithXvec(input_size=512, output_size=80, spk_embed_dim=192, output_type="mel", vocab_size=6561,
+                                    input_frame_rate=25, only_mask_loss=True, token_latent_ratio=2, pre_lookahead_len=3,
+                                    use_speaker_encoder=False, encoder=enc, decoder=cfm)
+
+
+def build_llm(layers=24):
+    from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM
+    from cosyvoice.utils.common import ras_sampling
+    enc = Qwen2Encoder({"num_hidden_layers": layers})
+    return Qwen2LM(896, 896, 6561, enc, partial(ras_sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1), True, 0, [5, 15],
+                   use_speaker_encoder=False, spk_embed_dim=192, max_conditioning_inputs=3)
+
+
+def build_dac(lat=80):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                       "minimax-speech_amd", "dac-vae", "model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    # dac-vae/configs/configx2.yml `vae:` section
+    return m.DACVAE(sample_rate=24000, encoder_dim=64, latent_dim=lat, encoder_rates=[2, 3, 4, 4, 5], decoder_dim=1536,
+                    decoder_rates=[5, 4, 4, 3, 2], d_in=1, d_out=1, weight_init="xavier", activation="snake", gain=1.0)
+
+
+def _ref(golden_dir, name):
+    return {k: tuple(v) for k, v in json.load(open(os.path.join(golden_dir, f"manifest_{name}.json"))).items()}
+
+
+def test_flow_state_dict_keys_match_reference(golden_dir):
+    flow = build_flow()
+    got = {k: tuple(v.shape) for k, v in flow.state_dict().items()}
+    assert got == _ref(golden_dir, "flow")
+    assert flow.pre_lookahead_len == 3 and flow.token_mel_ratio == 2 and flow.input_frame_rate == 25
+    assert flow.decoder.estimator.static_chunk_size == 50 and flow.decoder.rand_noise.shape == (1, 80, 15000)
+    from oracle import flow as OF
+    assert torch.equal(flow.decoder.rand_noise, OF.rand_noise())
+
+
+def test_llm_state_dict_keys_match_reference(golden_dir):
+    lm = build_llm(2)
+    got = {k: tuple(v.shape) for k, v in lm.state_dict().items()}
+    ref = {k: v for k, v in _ref(golden_dir, "llm").items() if ".layers." not in k or int(k.split(".")[4]) < 2}
+    assert got == ref
+    assert lm.stop_token_ids == [6561, 6562, 6563]
+    assert lm.llm.model.model.embed_tokens.weight.shape == (151936, 896)       # attribute path used at llm.py:694
+    assert lm.speech_embedding.weight.shape == (6564, 896) and lm.llm_decoder.bias.shape == (6564,)
+    sig = inspect.signature(lm.inference)
+    assert list(sig.parameters)[:7] == ["text", "text_len", "prompt_text", "prompt_text_len", "prompt_speech_token",
+                                        "prompt_speech_token_len", "embedding"]
+
+
+@pytest.mark.parametrize("lat", [80, 128])
+def test_dac_state_dict_keys_match_reference(golden_dir, lat):
+    dac = build_dac(lat)
+    got = {k: tuple(v.shape) for k, v in dac.state_dict().items()}
+    assert got == _ref(golden_dir, f"dac{lat}")
+    # a reference checkpoint also carries encoder.* / en_conv_post.*: accepted, ignored
+    sd = dict(dac.state_dict())
+    sd["encoder.block.0.0.weight_g"] = torch.zeros(3)
+    dac.load_state_dict(sd, strict=True)
+
+
+def test_no_cpu_fallback_in_dropin_classes():
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    dac = build_dac(80)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dac.decode(torch.zeros(1, 80, 4))
+
+
+def test_host_sampling_functions_match_reference_goldens(golden_dir):
+    """cosyvoice.utils.common.{ras,nucleus,random}_sampling keep the reference semantics (ids under torch seeds)."""
+    import numpy as np
+    from cosyvoice.utils.common import nucleus_sampling, random_sampling, ras_sampling
+    from oracle import weights as W
+    g = np.load(os.path.join(golden_dir, "sampler.npz"))
+    for s, (logp, hist) in enumerate(W.sampler_cases()):
+        torch.manual_seed(1000 + s)
+        assert int(ras_sampling(logp, hist, 25)) == int(g["ras"][s])
+        torch.manual_seed(1000 + s)
+        assert int(nucleus_sampling(logp)) == int(g["nucleus"][s])
+        torch.manual_seed(1000 + s)
+        assert int(random_sampling(logp, hist, 25)) == int(g["random"][s])
+
+
+def test_mask_helpers():
+    from cosyvoice.utils.mask import add_optional_chunk_mask, make_pad_mask, subsequent_chunk_mask
+    from oracle import flow as OF
+    assert torch.equal(make_pad_mask(torch.tensor([5, 3, 2])), OF.make_pad_mask(torch.tensor([5, 3, 2])))
+    assert torch.equal(subsequent_chunk_mask(7, 3), OF.subsequent_chunk_mask(7, 3))
+    m = ~make_pad_mask(torch.tensor([6, 4]), 6).unsqueeze(1)
+    assert torch.equal(add_optional_chunk_mask(torch.zeros(2, 6, 1), m, False, False, 0, 2, -1), OF.chunk_mask(m, 6, 2))
+
+
+@pytest.mark.gpu
+def test_dropin_modules_match_reference_goldens(golden_dir):
+    """load_state_dict(reference-keyed weights) + the reference call signatures -> golden outputs (fp32 build)."""
+    import numpy as np
+    from oracle import weights as W
+    flow = build_flow()
+    flow.load_state_dict(W.synth_state_dict(_ref(golden_dir, "flow"), 7), strict=True)
+    flow.to("cuda").float_parity()
+    g = np.load(os.path.join(golden_dir, "flow.npz"))
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    y, _ = flow.inference(token=t("flow_tok"), token_len=torch.tensor([25]).cuda(), prompt_token=t("flow_ptok"),
+                          prompt_token_len=torch.tensor([7]).cuda(), prompt_feat=t("flow_pfeat"),
+                          prompt_feat_len=torch.tensor([14]).cuda(), embedding=t("flow_emb"), streaming=False, finalize=True)
+    assert (y - t("flow_prompt")).abs().max().item() < 1e-3
+    est = flow.decoder.estimator
+    d = est(t("est_x"), torch.ones(2, 1, 64).cuda(), t("est_mu"), t("est_t"), t("est_spks"), t("est_cond"), streaming=False)
+    assert (d - t("est_full")).abs().max().item() < 2e-4
+    dac = build_dac(80)
+    dac.load_state_dict(W.synth_state_dict(_ref(golden_dir, "dac80"), 7), strict=True)
+    dac.to("cuda").float_parity()
+    gd = np.load(os.path.join(golden_dir, "dac80.npz"))
+    wav = dac.decode(torch.from_numpy(gd["z_T8"]).cuda())
+    assert (wav.cpu() - torch.from_numpy(gd["wav_T8"])).abs().max().item() < 1e-4
+    pre = torch.from_numpy(gd["pre_T8"]).cuda()
+    wav2 = dac.decoder(pre)                                # Decoder.forward on de_conv_pre's output
+    assert (wav2.cpu() - torch.from_numpy(gd["wav_T8"])).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_dropin_qwen2lm_inference_generator(golden_dir):
+    """Qwen2LM.inference yields python ints with the reference's length rules; ids equal the engine's."""
+    from oracle import weights as W
+    from mmx import shapes
+    lm = build_llm(2)
+    man = {k: v for k, v in shapes.llm_manifest(layers=2).items()}
+    lm.load_state_dict(W.synth_state_dict(man, 7), strict=True)
+    lm.to("cuda")
+    text = torch.randint(0, 151936, (1, 6), generator=torch.Generator().manual_seed(1)).cuda()
+    z = torch.zeros(1, 0, dtype=torch.long).cuda()
+    toks = list(lm.inference(text=text, text_len=torch.tensor([6]).cuda(), prompt_text=z, prompt_text_len=torch.tensor([0]).cuda(),
+                             prompt_speech_token=z, prompt_speech_token_len=torch.tensor([0]).cuda(), embedding=torch.zeros(0, 192).cuda()))
+    assert all(isinstance(t, int) and 0 <= t < 6561 for t in toks)
+    assert 12 - 2 <= len(toks) <= 120                    # min_len = 2*6 steps (ids > 6561 are skipped), max_len = 20*6
