@@ -31,35 +31,45 @@ def build_weights(seed=0):
             synth.synth_state_dict(shapes.dac_decoder_manifest(80), seed))
 
 
-def measure_dominant_kernel(eng, iters=200):
-    """Roofline of the dominant kernel of the step: the weight-streaming skinny GEMM of the LM decode
-    (gate/up projection + SwiGLU instance: the largest of the 4 per layer).  Timed live with HIP events on the
-    stream the kernel is launched on.  Algorithmic bytes per launch = its bf16 weight matrix (2 x 4864 x 896 x 2 B)
-    + the fp32 input row and the bf16 output row."""
+def measure_dominant_kernel(eng, iters=240):
+    """Roofline of the dominant kernel of the step: the weight-streaming GEMM of the LM decode (skinny_gemm_kernel),
+    gate/up projection + SwiGLU instance (the largest of the 4 per layer), at the batch size of the workload.
+    Timed live with HIP events on the stream the kernel is launched on, rotating over the 24 layers' weights so
+    the 256 MiB Infinity Cache cannot serve the stream.  Algorithmic bytes per launch (bf16 weights
+    are the traffic of a decode step) = the packed bf16 weight matrix 2 x 4864 x 896 x 2 B + the activation rows in
+    and out.  `traffic` = HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+    collected in separate passes with tools/pmc_skinny.py and committed as profiles/r01_pmc_skinny.json."""
     from mmx import ops
     llm = eng.llm
-    w = llm.layers[0]
     B, H, I = llm.B, llm.H, llm.I
-    h = torch.randn(B, H, device=llm.dev)
+    x = torch.randn(B, H, device=llm.dev).to(llm.tdt)
     act = torch.empty(B, I, dtype=llm.tdt, device=llm.dev)
     esz = 2 if llm.dtype == 1 else 4
-    nbytes = 2 * I * H * esz + B * H * 4 + B * I * esz
-    # rotate over all layers' weights so the 256 MiB Infinity Cache cannot serve the stream
+    nbytes = 2 * I * H * esz + B * H * esz + B * I * esz
     s = torch.cuda.current_stream()
+    run = lambda l: ops.skinny_gemm(x, llm.layers[l]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps, epi=1, out_act=act)
     for l in range(llm.n_layers):
-        ops.skinny_gemm(h, llm.layers[l]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps, epi=1, out_act=act)
+        run(l)
+    g = torch.cuda.CUDAGraph()                  # same launch mechanism as the decode step (hipGraph replay)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        for i in range(iters):
+            run(i % llm.n_layers)
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    for i in range(iters):
-        ops.skinny_gemm(h, llm.layers[i % llm.n_layers]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps,
-                        epi=1, out_act=act)
-    e1.record(s)
+    e0.record(torch.cuda.current_stream())
+    g.replay()
+    e1.record(torch.cuda.current_stream())
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     achieved = nbytes / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "skinny_gemm_kernel (gate/up + SwiGLU, K=896, N=2x4864)", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "r01_pmc_skinny.json")
+    if os.path.exists(pj) and B == 1:
+        traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+    return {"bound": "hbm", "kernel": f"skinny_gemm_kernel (LM gate/up + SwiGLU, K=896, N=2x4864, batch {B})",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
 
 
 def cpu_baseline():
