@@ -78,8 +78,14 @@ def cpu_baseline():
     10 Euler steps) and the DAC decoder on 50 frames; per-stage cost is scaled to a 10 s utterance."""
     from oracle import dac as ODAC, flow as OFLOW, llm as OLLM
     from mmx import shapes, synth
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    # the GPU box gives a 1-GPU job a share of ~16 host cores; os.cpu_count() reports the whole machine
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    print(f"[cpu_baseline] timing the CPU oracle on {cores} threads ...", file=sys.stderr, flush=True)
     llm_sd, flow_sd, dac_sd = build_weights(0)
     g = torch.Generator().manual_seed(2)
     with torch.no_grad():
@@ -92,10 +98,12 @@ def cpu_baseline():
             y, cache = OLLM.qwen2_forward(llm_sd, cfg, llm_sd["speech_embedding.weight"][i].reshape(1, 1, -1), cache)
             torch.nn.functional.linear(y[:, -1], llm_sd["llm_decoder.weight"], llm_sd["llm_decoder.bias"]).log_softmax(-1)
         t_tok = (time.time() - t0) / 16
+        print(f"[cpu_baseline] LM {t_tok * 1e3:.1f} ms/token", file=sys.stderr, flush=True)
         tok = torch.randint(0, 6561, (1, 25), generator=g)
         t0 = time.time()
         OFLOW.flow_inference(flow_sd, tok, torch.zeros(1, 0, dtype=torch.long), torch.zeros(1, 0, 80), torch.randn(1, 192, generator=g))
         t_flow = time.time() - t0                              # 1 s of audio
+        print(f"[cpu_baseline] flow {t_flow:.2f} s per audio-second", file=sys.stderr, flush=True)
         t0 = time.time()
         ODAC.decode(dac_sd, torch.randn(1, 80, 50, generator=g), [5, 4, 4, 3, 2])
         t_dac = time.time() - t0                               # 1 s of audio
