@@ -51,14 +51,32 @@ enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_MISH = 4, AC
 // compile-time activation: a runtime `switch` inside the per-element epilogue is if-converted by the compiler
 // into evaluating EVERY activation (erf, tanh, log1p, exp ...) and selecting — ~190 instructions per output
 // element, which made every GEMM epilogue and row-norm compute bound.  Kernels dispatch once, outside the loops.
+// erf for the bf16 build: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 (one rcp + one exp + 5 fma instead of the
+// ~60-instruction libm path that cost 8 us on every FF1 epilogue); the fp32 parity build keeps erff.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+
 template <int ACT, bool PRECISE>
 __device__ __forceinline__ float act_c(float v, float slope) {
     if constexpr (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
-    else if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    else if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.f + (PRECISE ? erff(v * 0.70710678118654752f) : erf_fast(v * 0.70710678118654752f)));
     else if constexpr (ACT == ACT_SILU) return v / (1.f + (PRECISE ? expf(-v) : __expf(-v)));
     else if constexpr (ACT == ACT_MISH) {
-        float sp = v > 20.f ? v : log1pf(PRECISE ? expf(v) : __expf(v));
-        return v * tanhf(sp);
+        // x * tanh(softplus(x)) with tanh(log(1+e)) = (e^2 + 2e) / (e^2 + 2e + 2), e = exp(x)  (exact identity);
+        // torch's softplus threshold: x > 20 -> x
+        if (v > 20.f) return v;
+        const float e = PRECISE ? expf(v) : __expf(v);
+        const float n = e * (e + 2.f);
+        return v * (n / (n + 2.f));
     } else if constexpr (ACT == ACT_TANH) return tanhf(v);
     else return v;
 }

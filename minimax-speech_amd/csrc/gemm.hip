@@ -338,11 +338,11 @@ static int launch_T(const GemmParams& p, hipStream_t s) {
     MMX_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0);
     MMX_CHECK_ARG(p.out_f32 || p.out_act);
     MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use
-    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
-    if (tiles128 >= 192 && p.N > 64) return launch_cfg<T, 128, 128, 2, 2>(p, s);
-    if (p.N <= 64 && (long)((p.M + 127) / 128) * p.batch >= 192) return launch_cfg<T, 128, 64, 4, 1>(p, s);
-    const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
-    if (tiles64 >= 128 || p.M > 32) return launch_cfg<T, 64, 64, 2, 2>(p, s);
+    // largest tile that still gives every CU a workgroup (256 CUs); short-K GEMMs want many MFMAs per barrier
+    auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch; };
+    if (p.N > 64 && blocks(128, 128) >= 192) return launch_cfg<T, 128, 128, 2, 2>(p, s);
+    if (blocks(128, 64) >= 192) return launch_cfg<T, 128, 64, 4, 1>(p, s);
+    if (p.M > 32) return launch_cfg<T, 64, 64, 2, 2>(p, s);
     return launch_cfg<T, 32, 64, 1, 4>(p, s);
 }
 
