@@ -21,6 +21,8 @@
 #include "common.h"
 #include "gemm.h"
 #include <utility>
+#include <cstdlib>
+#include <cstring>
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
@@ -340,9 +342,20 @@ static int launch_T(const GemmParams& p, hipStream_t s) {
     MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use
     // largest tile that still gives every CU a workgroup (256 CUs); short-K GEMMs want many MFMAs per barrier
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch; };
-    if (p.N > 64 && blocks(128, 128) >= 192) return launch_cfg<T, 128, 128, 2, 2>(p, s);
-    if (blocks(128, 64) >= 192) return launch_cfg<T, 128, 64, 4, 1>(p, s);
-    if (p.M > 32) return launch_cfg<T, 64, 64, 2, 2>(p, s);
+    static const char* force = getenv("MMX_GEMM_TILE");                // tuning aid (tools/microbench.py)
+    if (force) {
+        if (!strcmp(force, "128x128")) return launch_cfg<T, 128, 128, 2, 2>(p, s);
+        if (!strcmp(force, "128x64")) return launch_cfg<T, 128, 64, 4, 1>(p, s);
+        if (!strcmp(force, "64x64")) return launch_cfg<T, 64, 64, 2, 2>(p, s);
+        if (!strcmp(force, "32x64")) return launch_cfg<T, 32, 64, 1, 4>(p, s);
+    }
+    // measured on MI355X (tools/microbench.py tiles, profiles/r01_gemm_tiles.txt): these GEMMs are short-K and
+    // latency bound, so more (smaller) workgroups win until the problem is large: 64x64 beats 128x128 up to
+    // ~1000 128-tiles (234 vs 239 TFLOP/s at M=8192,N=1024,K=256; 256 vs 153 at N=256,K=1024) and by 2x at M=1024.
+    const long b128 = blocks(128, 128);
+    if (p.N > 64 && (b128 >= 1024 || (p.ntaps * p.cin >= 1024 && b128 >= 512))) return launch_cfg<T, 128, 128, 2, 2>(p, s);
+    if (p.N <= 64 && blocks(128, 64) >= 512) return launch_cfg<T, 128, 64, 4, 1>(p, s);
+    if (blocks(64, 64) >= 64 || p.M > 32) return launch_cfg<T, 64, 64, 2, 2>(p, s);
     return launch_cfg<T, 32, 64, 1, 4>(p, s);
 }
 

@@ -92,3 +92,22 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "flash":
     for B, T in ((2, 128), (2, 512), (2, 1024), (16, 512), (16, 1024), (64, 512)):
         flash_case(B, T)
     flash_case(16, 512, 50)
+
+
+def gemm_graph_case(M, N, K, batch, act="none", out="act"):
+    dt = 1
+    x = torch.randn(batch, M, K, device="cuda").bfloat16()
+    w = ops.pack_linear(torch.randn(N, K, device="cuda") / math.sqrt(K), dt)
+    of = torch.empty(batch, M, N, device="cuda") if out in ("f32", "both") else None
+    oa = torch.empty(batch, M, N, device="cuda", dtype=torch.bfloat16) if out in ("act", "both") else None
+    res = torch.randn(batch, M, N, device="cuda") if out == "f32" else None
+    fn = lambda: ops.gemm(x, w, M, N, dtype=dt, lda=K, cin=K, batch=batch, a_bstride=M * K, act=act, residual=res, ldr=N,
+                          r_bstride=M * N, out_f32=of, ldo_f=N, of_bstride=M * N, out_act=oa, ldo_a=N, oa_bstride=M * N)
+    us = graph_time(fn)
+    print(f"tile={os.environ.get('MMX_GEMM_TILE','auto'):8s} M={M} N={N:5d} K={K:5d} b={batch:3d} act={act:5s} out={out}: {us:7.2f} us {2.0*M*N*K*batch/us/1e6:7.1f} TF")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tiles":
+    for (N, K, act, out) in ((1024, 256, "none", "act"), (1024, 256, "gelu", "act"), (256, 1024, "none", "f32"), (256, 512, "none", "f32"), (256, 768, "none", "f32")):
+        gemm_graph_case(512, N, K, 16, act, out)
+        gemm_graph_case(512, N, K, 2, act, out)
