@@ -170,9 +170,11 @@ int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, in
                    const int32_t* pos, const void* kc, const void* vc, const int32_t* block_table, int max_pages,
                    int page, void* out, int64_t ldo, int64_t o_bs, int dtype, hipStream_t stream);
 /* Single-token decode: RoPE(q), RoPE(k_new), KV append and causal GQA attention in ONE launch per layer
- * (same arithmetic as mmx_rope_kv_store + mmx_paged_attn with rows = 1).  qkv fp32 [B][ldqkv], out T [B][ldo]. */
+ * (same arithmetic as mmx_rope_kv_store + mmx_paged_attn with rows = 1).  qkv fp32 [B][ldqkv], out T [B][ldo].
+ * rope_tab (optional, fp32 [max_pos][D] = cos | sin per position, as HF's rotary embedding computes them) replaces
+ * the in-kernel cosf/sinf of pos * inv_freq. */
 int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
-                    const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
+                    const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
                     float scale, void* out, int64_t ldo, int dtype, hipStream_t stream);
 /* SwiGLU for prefill: out = T(silu(gu[:, :I]) * gu[:, I:2I]) */
 int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* out, int64_t ldo, int dtype, hipStream_t stream);

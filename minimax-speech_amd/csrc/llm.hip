@@ -435,8 +435,8 @@ __device__ __forceinline__ void load8(const T* p, float o[8]) {
 template <typename T>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
-    const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc, const int32_t* __restrict__ block_table,
-    int max_pages, int page, float scale, T* __restrict__ out, long ldo) {
+    const float* __restrict__ rope_tab, const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc,
+    const int32_t* __restrict__ block_table, int max_pages, int page, float scale, T* __restrict__ out, long ldo) {
     constexpr int D = 64, HALF = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = reinterpret_cast<float*>(smem);        // [D]
@@ -454,8 +454,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     if (tid < 2 * HALF) {
         const int which = tid >> 5, d = tid & 31;      // 0: q head h, 1: k head hk
         const float* x = src + (which == 0 ? h * D : (Hq + hk) * D);
-        const float ang = (float)p * inv_freq[d];
-        const float c = cosf(ang), s = sinf(ang);
+        float c, s;
+        if (rope_tab) {                                // [pos][cos 0..31 | sin 0..31], computed like HF on the host
+            c = rope_tab[(long)p * D + d];
+            s = rope_tab[(long)p * D + HALF + d];
+        } else {
+            const float ang = (float)p * inv_freq[d];
+            c = cosf(ang);
+            s = sinf(ang);
+        }
         const float y0 = x[d] * c - x[d + HALF] * s, y1 = x[d + HALF] * c + x[d] * s;
         if (which == 0) { qs[d] = y0; qs[d + HALF] = y1; }
         else { kn[d] = Cvt<T>::to_f(Cvt<T>::from_f(y0)); kn[d + HALF] = Cvt<T>::to_f(Cvt<T>::from_f(y1)); }
@@ -531,15 +538,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     }
 }
 extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
-                               const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages,
+                               const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages,
                                int page, float scale, void* out, int64_t ldo, int dtype, hipStream_t stream) {
-    MMX_CHECK_ARG(qkv && inv_freq && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
+    MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
     const size_t max_ctx = (size_t)max_pages * page;
     size_t lds = (3 * 64 + 16 + 32 * 64 + max_ctx) * 4;
     MMX_CHECK_ARG(lds <= 160 * 1024);
     dim3 grid(Hq, B);
-    if (dtype == MMX_BF16) hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, page, scale, (bf16_t*)out, ldo);
-    else if (dtype == MMX_F32) hipLaunchKernelGGL(decode_attn_kernel<float>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, pos, (float*)kc, (float*)vc, block_table, max_pages, page, scale, (float*)out, ldo);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, page, scale, (bf16_t*)out, ldo);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(decode_attn_kernel<float>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (float*)kc, (float*)vc, block_table, max_pages, page, scale, (float*)out, ldo);
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;

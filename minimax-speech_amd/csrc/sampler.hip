@@ -69,8 +69,9 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 }
 
 constexpr int SAMP_THREADS = 256;
-constexpr int SAMP_MAXV = 32;        // V <= 8192
+constexpr int SAMP_MAXV = 26;        // V <= 6656 (speech_token_size + 3 = 6564)
 constexpr int SAMP_MAXK = 64;
+constexpr int SAMP_LIST = 512;       // candidates >= the top_k-th local maximum (ties / clustered values included)
 
 __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     const float* __restrict__ logits, long ldl, int V, int eos_id, int top_k, float top_p, int win_size, float tau_r,
@@ -81,7 +82,13 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     __shared__ ArgMax sha[8];
     __shared__ float cand_p[SAMP_MAXK];
     __shared__ int cand_i[SAMP_MAXK];
-    __shared__ int sh_n, sh_top;
+    __shared__ int sh_n, sh_top, sh_cnt, sh_thr_i;
+    __shared__ float sh_thr_v;
+    __shared__ float lmax_p[SAMP_THREADS];
+    __shared__ int lmax_i[SAMP_THREADS];
+    __shared__ float p_lds[SAMP_THREADS * SAMP_MAXV];
+    __shared__ float list_p[SAMP_LIST];
+    __shared__ int list_i[SAMP_LIST];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nb = gridDim.x;                          // state is field-major: state[field * B + b]
     int32_t* st = state + b;
@@ -126,35 +133,92 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     se2 = block_sum(se2, shf);
 #pragma unroll
     for (int i = 0; i < SAMP_MAXV; ++i)
-        if (tid + i * SAMP_THREADS < V) x[i] = x[i] / se2;   // p
+        if (tid + i * SAMP_THREADS < V) {
+            x[i] = x[i] / se2;                         // p
+            p_lds[tid + i * SAMP_THREADS] = x[i];
+        }
 
-    // nucleus candidates: repeated block arg-max == stable descending sort prefix.  Every thread keeps the
-    // arg-max of its own (not yet taken) values; only the round's winner rescans its 26 values.
-    float p_work[SAMP_MAXV];
+    // nucleus candidates = prefix of the stable descending sort (value desc, index asc).
+    // (1) every thread's local maximum; (2) wave 0 finds the top_k-th largest of the 256 maxima (T): at least top_k
+    // elements are >= T, so every global top_k element is >= T; (3) all elements >= T are pushed to a small LDS
+    // list; (4) wave 0 extracts the sorted prefix from that list with wave arg-max rounds, accumulating the fp32
+    // running sum in the reference's order (common.py:124-131).  No workgroup barrier inside the loops.
+    auto wave_argmax = [&](ArgMax v) {
 #pragma unroll
-    for (int i = 0; i < SAMP_MAXV; ++i) p_work[i] = x[i];
-    auto local_best = [&]() {
+        for (int o = 32; o > 0; o >>= 1) {
+            ArgMax y;
+            y.v = __shfl_xor(v.v, o, 64);
+            y.i = __shfl_xor(v.i, o, 64);
+            v = better(v, y);
+        }
+        return v;
+    };
+    {
         ArgMax a{-2.f, 0x7fffffff};
 #pragma unroll
-        for (int i = 0; i < SAMP_MAXV; ++i) a = better(a, ArgMax{p_work[i], tid + i * SAMP_THREADS});
-        return a;
-    };
-    ArgMax mine = local_best();
-    float cum = 0.f;
-    int nc = 0;
-    while (cum < top_p && nc < top_k) {
-        ArgMax a = block_argmax(mine, sha);
-        if (tid == 0) { cand_p[nc] = a.v; cand_i[nc] = a.i; }
-        if ((a.i & (SAMP_THREADS - 1)) == tid) {       // index = tid + i*256 -> owner thread
+        for (int i = 0; i < SAMP_MAXV; ++i) a = better(a, ArgMax{x[i], tid + i * SAMP_THREADS});
+        lmax_p[tid] = a.v;
+        lmax_i[tid] = a.i;
+    }
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    if (tid < 64) {
+        ArgMax c[SAMP_THREADS / 64];
 #pragma unroll
-            for (int i = 0; i < SAMP_MAXV; ++i)
-                if (tid + i * SAMP_THREADS == a.i) p_work[i] = -1.f;
-            mine = local_best();
+        for (int u = 0; u < SAMP_THREADS / 64; ++u) c[u] = ArgMax{lmax_p[tid + u * 64], lmax_i[tid + u * 64]};
+        ArgMax kth{0.f, 0};
+        for (int rnd = 0; rnd < top_k; ++rnd) {
+            ArgMax m = c[0];
+#pragma unroll
+            for (int u = 1; u < SAMP_THREADS / 64; ++u) m = better(m, c[u]);
+            kth = wave_argmax(m);
+#pragma unroll
+            for (int u = 0; u < SAMP_THREADS / 64; ++u)
+                if (c[u].i == kth.i) c[u].v = -2.f;
         }
-        cum += a.v;                                    // fp32 running sum, same order as common.py:127
-        nc++;
+        if (tid == 0) { sh_thr_v = kth.v; sh_thr_i = kth.i; }
     }
     __syncthreads();
+    {
+        const ArgMax thr{sh_thr_v, sh_thr_i};
+#pragma unroll
+        for (int i = 0; i < SAMP_MAXV; ++i) {
+            const ArgMax e{x[i], tid + i * SAMP_THREADS};
+            // e >= thr in the sort order  <=>  !(thr strictly better than e)
+            const bool take = e.i < V && !(thr.v > e.v || (thr.v == e.v && thr.i < e.i));
+            if (take) {
+                int slot = atomicAdd(&sh_cnt, 1);
+                if (slot < SAMP_LIST) { list_p[slot] = e.v; list_i[slot] = e.i; }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int cnt = min(sh_cnt, SAMP_LIST);
+        ArgMax c[SAMP_LIST / 64];
+#pragma unroll
+        for (int u = 0; u < SAMP_LIST / 64; ++u) {
+            const int id = tid + u * 64;
+            c[u] = id < cnt ? ArgMax{list_p[id], list_i[id]} : ArgMax{-2.f, 0x7fffffff};
+        }
+        float cum = 0.f;
+        int nc = 0;
+        while (cum < top_p && nc < top_k) {
+            ArgMax m = c[0];
+#pragma unroll
+            for (int u = 1; u < SAMP_LIST / 64; ++u) m = better(m, c[u]);
+            m = wave_argmax(m);
+            if (tid == 0) { cand_p[nc] = m.v; cand_i[nc] = m.i; }
+#pragma unroll
+            for (int u = 0; u < SAMP_LIST / 64; ++u)
+                if (c[u].i == m.i) c[u].v = -2.f;
+            cum += m.v;                                // fp32 running sum, same order as common.py:127
+            nc++;
+        }
+        if (tid == 0) sh_n = nc;
+    }
+    __syncthreads();
+    const int nc = sh_n;
 
     const bool ignore_eos = step < min_len;
     int top = 0;
@@ -169,11 +233,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
         for (int j = max(0, n_out - win_size); j < n_out; ++j) rep += out_tokens[(long)b * max_out + j] == top;
         if ((float)rep >= (float)win_size * tau_r) {
             ArgMax r{-1.f, 0x7fffffff};
-#pragma unroll
-            for (int i = 0; i < SAMP_MAXV; ++i) {
-                int idx = tid + i * SAMP_THREADS;
-                if (idx < V) r = better(r, ArgMax{x[i] / exp_noise(seed, seq, step, trial, 1, idx), idx});
-            }
+#pragma unroll 1
+            for (int idx = tid; idx < V; idx += SAMP_THREADS)      // rolled: p from LDS keeps this rare path compact
+                r = better(r, ArgMax{p_lds[idx] / exp_noise(seed, seq, step, trial, 1, idx), idx});
             r = block_argmax(r, sha);
             top = r.i;
         }

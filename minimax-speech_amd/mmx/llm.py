@@ -58,6 +58,9 @@ class LlmEngine:
         self.llm_emb = f("llm_embedding.weight")
         # HF Qwen2RotaryEmbedding inv_freq (modeling_qwen2.py: 1 / theta^(arange(0,d,2)/d)), computed like HF in fp32
         self.inv_freq = (1.0 / (rope_theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))).to(self.dev)
+        # cos/sin per position exactly as HF computes them (fp32 outer product, then cos/sin): [max_ctx][cos 32 | sin 32]
+        ang = torch.arange(max_ctx, dtype=torch.float32)[:, None] * self.inv_freq.cpu()[None, :]
+        self.rope_tab = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous().to(self.dev)
         # paged KV cache: [layers][pages][Hkv][page][D]; sequence b owns table row b (static allocation for now)
         self.B = max_batch
         self.max_pages = (max_ctx + page - 1) // page
@@ -98,7 +101,7 @@ class LlmEngine:
                             epi=0, out_f32=qkv)
             if rows == 1:
                 ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
-                                Hkv=self.Hkv, page=self.page, dtype=dt)
+                                Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab)
             else:
                 ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=rows,
                                   Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)

@@ -191,8 +191,8 @@ def paged_attn(q, pos, kc, vc, block_table, out, *, B, rows, Hq, Hkv, page, dtyp
                                 i64(Hq * 64), i64(rows * Hq * 64), dtype, stream()), "mmx_paged_attn")
 
 
-def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype):
-    check(load().mmx_decode_attn(_p(qkv), i64((Hq + 2 * Hkv) * 64), B, Hq, Hkv, 64, _p(inv_freq), _p(pos), _p(kc),
+def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None):
+    check(load().mmx_decode_attn(_p(qkv), i64((Hq + 2 * Hkv) * 64), B, Hq, Hkv, 64, _p(inv_freq), _p(rope_tab), _p(pos), _p(kc),
                                  _p(vc), _p(block_table), block_table.shape[1], page, C.c_float(0.125), _p(out),
                                  i64(Hq * 64), dtype, stream()), "mmx_decode_attn")
 
