@@ -29,8 +29,15 @@ def espnet_rel_pe(T: int, d: int) -> torch.Tensor:
     return pe
 
 
+import threading
+
+CAPTURE_LOCK = threading.RLock()     # graph capture is serialised against every other launch of the process
+
+
 class Graphed:
-    """Runs `fn` eagerly once (warm-up), then records it into a hipGraph and replays it."""
+    """Runs `fn` eagerly once (warm-up), then records it into a hipGraph and replays it.  Capture takes
+    CAPTURE_LOCK (callers that launch from another thread take it around their own launches), and uses the
+    thread-local capture mode so that a concurrent stream of another thread does not invalidate it."""
 
     def __init__(self, fn, enabled=True):
         self.fn, self.enabled, self.graph, self.calls = fn, enabled, None, 0
@@ -42,11 +49,12 @@ class Graphed:
             self.calls += 1
             if self.calls == 1:
                 return self.fn()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.fn()
-            self.graph = g
+            with CAPTURE_LOCK:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.fn()
+                self.graph = g
         self.graph.replay()
 
 

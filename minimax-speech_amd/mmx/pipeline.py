@@ -73,32 +73,122 @@ class TtsEngine:
         pt = flow_prompt_speech_token if flow_prompt_speech_token is not None else z
         return self.token2wav(toks.reshape(1, -1), pt, pf, flow_embedding)
 
-    @torch.no_grad()
-    def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=8, max_pad_ratio=1.25,
-                  frame_quantum=32) -> List[torch.Tensor]:
-        """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share):
-        one batched AR decode for all of them, per-utterance conformer encoder, flow ODE solves batched over
-        groups of similar length (zero padded + masked), DAC decode per utterance.  No prompts (synthetic load)."""
-        B = len(texts)
+    # ------------------------------------------------------------------ batch of independent utterances
+    def _groups(self, order, frames, group_size, max_pad_ratio, frame_quantum):
+        """Consecutive runs of `order` (sorted by length) whose lengths are within the padding budget."""
+        out, i = [], 0
+        while i < len(order):
+            j, t0 = i + 1, frames[order[i]]
+            while j < len(order) and j - i < group_size and frames[order[j]] <= max(t0 * max_pad_ratio, t0 + frame_quantum):
+                j += 1
+            out.append(order[i:j])
+            i = j
+        return out
+
+    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum):
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
-        toks = self.generate_tokens(texts, seed=seed, exact_steps=exact_steps)
-        conds = [self.flow.conditions(toks[b].reshape(1, -1), z, zf, flow_embeddings[b]) for b in range(B)]
-        order = sorted(range(B), key=lambda b: conds[b][0].shape[0])
+        conds = [self.flow.conditions(toks[b].reshape(1, -1), z, zf, embs[b]) for b in grp]
+        xs = self.flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
+        for b, lat in zip(grp, xs):
+            T2 = lat.shape[0]
+            zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
+            ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
+            wavs[b] = self.dac.decode_time_major(zt, 1, T2)
+
+    @torch.no_grad()
+    def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=8, max_pad_ratio=1.25,
+                  frame_quantum=32, overlap=True, poll_every=8) -> List[torch.Tensor]:
+        """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
+        AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
+        conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
+        issued by a second host thread on a second HIP stream, so the latency-bound decode loop and the MFMA-bound
+        flow overlap on the chip (the reference overlaps the same two stages with its llm_job thread,
+        cli/model.py:332-335).  overlap=False runs the stages back to back.  No prompts (synthetic load)."""
+        import queue
+        import threading
+        from .flow import CAPTURE_LOCK
+        from .llm import ST_FIN, ST_NOUT
+        B = len(texts)
+        assert B == self.llm.B
+        if exact_steps is not None and not isinstance(exact_steps, (list, tuple)):
+            exact_steps = [exact_steps] * B
+        z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
+        xs = [self.llm.build_lm_input(t, z, z) for t in texts]
+        mins = [exact_steps[b] if exact_steps is not None else int(texts[b].numel() * 2) for b in range(B)]
+        maxs = [exact_steps[b] if exact_steps is not None else int(texts[b].numel() * 20) for b in range(B)]
         wavs: List[Optional[torch.Tensor]] = [None] * B
-        i = 0
-        while i < B:
-            j = i + 1
-            t0 = conds[order[i]][0].shape[0]
-            while j < B and j - i < group_size and conds[order[j]][0].shape[0] <= max(t0 * max_pad_ratio, t0 + frame_quantum):
-                j += 1
-            grp = order[i:j]
-            xs = self.flow.cfm_batch([conds[b][0] for b in grp], [conds[b][1] for b in grp], [conds[b][2] for b in grp],
-                                     pad_to=frame_quantum)
-            for b, lat in zip(grp, xs):
-                T2 = lat.shape[0]
-                zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
-                ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
-                wavs[b] = self.dac.decode_time_major(zt, 1, T2)
-            i = j
+        toks: List[Optional[torch.Tensor]] = [None] * B
+        if not overlap:
+            self.llm.start(xs, mins, maxs, seed=seed)
+            self.llm.run(max(maxs), poll_every)
+            n = self.llm.state[ST_NOUT].tolist()
+            for b in range(B):
+                toks[b] = self.llm.out_tokens[b, :n[b]].to(torch.int64)
+            order = sorted(range(B), key=lambda b: (n[b], b))
+            for grp in self._groups(order, [2 * v for v in n], group_size, max_pad_ratio, frame_quantum):
+                self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum)
+            return wavs
+
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.dev)
+        side, q, err = self._side, queue.Queue(), []
+
+        def worker():
+            try:
+                torch.cuda.set_device(self.dev)
+                with torch.cuda.stream(side):
+                    while True:
+                        item = q.get()
+                        if item is None:
+                            return
+                        grp, ev = item
+                        side.wait_event(ev)                      # the group's token ids were written on the LM stream
+                        self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum)
+            except BaseException as e:                           # surfaced by the caller
+                err.append(e)
+
+        th = threading.Thread(target=worker, daemon=True)
+        th.start()
+        main = torch.cuda.current_stream()
+        pending: List[int] = []
+        seen = set()
+
+        def harvest(final):
+            fin = self.llm.state[ST_FIN].tolist()
+            n = self.llm.state[ST_NOUT].tolist()
+            new = sorted([b for b in range(B) if (fin[b] or final) and b not in seen], key=lambda b: (n[b], b))
+            for b in new:
+                seen.add(b)
+                toks[b] = self.llm.out_tokens[b, :n[b]].to(torch.int64)
+                pending.append(b)
+            frames = {b: 2 * toks[b].numel() for b in pending}
+            groups = self._groups(pending, frames, group_size, max_pad_ratio, frame_quantum)
+            if not final and groups and len(groups[-1]) < group_size:
+                groups = groups[:-1]                             # keep a partial group open for later arrivals
+            for grp in groups:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                q.put((grp, ev))
+                for b in grp:
+                    pending.remove(b)
+
+        with CAPTURE_LOCK:
+            self.llm.start(xs, mins, maxs, seed=seed)
+        done, max_steps = 1, max(maxs)
+        while done < max_steps:
+            k = min(poll_every, max_steps - done)
+            with CAPTURE_LOCK:                                   # never launch while the other thread records a graph
+                for _ in range(k):
+                    self.llm.step()
+            done += k
+            harvest(False)
+            if len(seen) == B:
+                break
+        harvest(True)
+        q.put(None)
+        th.join()
+        if err:
+            raise err[0]
+        main.wait_stream(side)
         return wavs
