@@ -23,6 +23,9 @@ class TtsEngine:
     def __init__(self, llm_sd, flow_sd, dac_sd, dtype=BF16, device="cuda", max_batch=1, max_ctx=2048,
                  dac_rates=(5, 4, 4, 3, 2), use_graphs=True):
         self.dtype, self.dev = dtype, torch.device(device)
+        if self.dev.type == "cuda" and self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        device = self.dev
         self.llm = LlmEngine(llm_sd, dtype=dtype, device=device, max_batch=max_batch, max_ctx=max_ctx, use_graphs=use_graphs)
         self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs)
         self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device)
