@@ -134,8 +134,13 @@ class TtsEngine:
             return wavs
 
         if not hasattr(self, "_side"):
-            self._side = torch.cuda.Stream(device=self.dev)
+            # the decode loop is a chain of short latency-bound kernels: give it the high-priority queue so its
+            # launches are not parked behind the flow's large grids
+            self._side = torch.cuda.Stream(device=self.dev, priority=0)
+            self._hi = torch.cuda.Stream(device=self.dev, priority=-1)
         side, q, err = self._side, queue.Queue(), []
+        caller = torch.cuda.current_stream()
+        self._hi.wait_stream(caller)
 
         def worker():
             try:
@@ -153,7 +158,7 @@ class TtsEngine:
 
         th = threading.Thread(target=worker, daemon=True)
         th.start()
-        main = torch.cuda.current_stream()
+        main = self._hi
         pending: List[int] = []
         seen = set()
 
@@ -176,22 +181,24 @@ class TtsEngine:
                 for b in grp:
                     pending.remove(b)
 
-        with CAPTURE_LOCK:
-            self.llm.start(xs, mins, maxs, seed=seed)
-        done, max_steps = 1, max(maxs)
-        while done < max_steps:
-            k = min(poll_every, max_steps - done)
-            with CAPTURE_LOCK:                                   # never launch while the other thread records a graph
-                for _ in range(k):
-                    self.llm.step()
-            done += k
-            harvest(False)
-            if len(seen) == B:
-                break
-        harvest(True)
+        with torch.cuda.stream(main):
+            with CAPTURE_LOCK:
+                self.llm.start(xs, mins, maxs, seed=seed)
+            done, max_steps = 1, max(maxs)
+            while done < max_steps:
+                k = min(poll_every, max_steps - done)
+                with CAPTURE_LOCK:                               # never launch while the other thread records a graph
+                    for _ in range(k):
+                        self.llm.step()
+                done += k
+                harvest(False)
+                if len(seen) == B:
+                    break
+            harvest(True)
         q.put(None)
         th.join()
         if err:
             raise err[0]
-        main.wait_stream(side)
+        caller.wait_stream(side)
+        caller.wait_stream(main)
         return wavs
