@@ -156,6 +156,8 @@ class TtsEngine:
             except BaseException as e:                           # surfaced by the caller
                 err.append(e)
 
+        import time as _time
+        self._t0 = _time.perf_counter()
         th = threading.Thread(target=worker, daemon=True)
         th.start()
         main = self._hi
@@ -195,10 +197,19 @@ class TtsEngine:
                 if len(seen) == B:
                     break
             harvest(True)
+        import os, time
+        timing = os.environ.get("MMX_TIMING")
+        if timing:
+            main.synchronize()
+            t_lm = time.perf_counter()
         q.put(None)
         th.join()
         if err:
             raise err[0]
+        if timing:
+            side.synchronize()
+            print(f"[tts_batch] LM loop done at {(t_lm - self._t0) * 1e3:.0f} ms, flow/DAC tail until {(time.perf_counter() - self._t0) * 1e3:.0f} ms, "
+                  f"decode steps {done}", flush=True)
         caller.wait_stream(side)
         caller.wait_stream(main)
         return wavs
