@@ -77,12 +77,17 @@ class TtsEngine:
         return self.token2wav(toks.reshape(1, -1), pt, pf, flow_embedding)
 
     # ------------------------------------------------------------------ batch of independent utterances
-    def _groups(self, order, frames, group_size, max_pad_ratio, frame_quantum):
-        """Consecutive runs of `order` (sorted by length) whose lengths are within the padding budget."""
+    def _groups(self, order, frames, group_size, max_pad_ratio, frame_quantum, first=0):
+        """Consecutive runs of `order` (sorted by length) whose lengths are within the padding budget.
+        group_size may be a list: the size limit of the k-th group issued (k counted from `first`); the last entry
+        repeats.  A ramp such as [2, 2, 4, 8] lets the flow stage start as soon as the two shortest utterances are
+        decoded instead of waiting for eight."""
+        sizes = group_size if isinstance(group_size, (list, tuple)) else [group_size]
         out, i = [], 0
         while i < len(order):
+            gs = sizes[min(first + len(out), len(sizes) - 1)]
             j, t0 = i + 1, frames[order[i]]
-            while j < len(order) and j - i < group_size and frames[order[j]] <= max(t0 * max_pad_ratio, t0 + frame_quantum):
+            while j < len(order) and j - i < gs and frames[order[j]] <= max(t0 * max_pad_ratio, t0 + frame_quantum):
                 j += 1
             out.append(order[i:j])
             i = j
@@ -100,7 +105,7 @@ class TtsEngine:
             wavs[b] = self.dac.decode_time_major(zt, 1, T2)
 
     @torch.no_grad()
-    def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=8, max_pad_ratio=1.25,
+    def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=(2, 2, 4, 8), max_pad_ratio=2.0,
                   frame_quantum=32, overlap=True, poll_every=8) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
@@ -163,6 +168,7 @@ class TtsEngine:
         main = self._hi
         pending: List[int] = []
         seen = set()
+        issued = [0]
 
         def harvest(final):
             fin = self.llm.state[ST_FIN].tolist()
@@ -173,13 +179,17 @@ class TtsEngine:
                 toks[b] = self.llm.out_tokens[b, :n[b]].to(torch.int64)
                 pending.append(b)
             frames = {b: 2 * toks[b].numel() for b in pending}
-            groups = self._groups(pending, frames, group_size, max_pad_ratio, frame_quantum)
-            if not final and groups and len(groups[-1]) < group_size:
-                groups = groups[:-1]                             # keep a partial group open for later arrivals
+            groups = self._groups(pending, frames, group_size, max_pad_ratio, frame_quantum, first=issued[0])
+            sizes = group_size if isinstance(group_size, (list, tuple)) else [group_size]
+            if not final and groups:
+                want = sizes[min(issued[0] + len(groups) - 1, len(sizes) - 1)]
+                if len(groups[-1]) < want:
+                    groups = groups[:-1]                         # keep a partial group open for later arrivals
             for grp in groups:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 q.put((grp, ev))
+                issued[0] += 1
                 for b in grp:
                     pending.remove(b)
 
