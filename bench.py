@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="2,2,4,8", help="utterances per batched flow ODE solve (ramp: k-th group)")
     ap.add_argument("--pad-ratio", type=float, default=2.0, help="max length ratio inside one flow group")
+    ap.add_argument("--flow-workers", type=int, default=2, help="host threads / streams solving flow groups concurrently")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", 0))
@@ -158,7 +159,7 @@ def main():
     max_samples = 2 * max(lens_all) * eng.hop
 
     def step():
-        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio)
+        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers)
         if world > 1:
             gather_audio(wavs, mine, len(lens_all), max_samples)      # the path's one exchange step (RCCL all-gather)
         return sum(w.shape[-1] for w in wavs)

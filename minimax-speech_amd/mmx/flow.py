@@ -77,6 +77,14 @@ class FlowEngine:
         if "estimator" in parts:
             self._init_estimator(sd, f, lin, cv)
 
+    def clone_shared(self):
+        """A second engine over the SAME packed weights with its own plan / scratch buffers, for a second host
+        thread + stream (plans hold the static buffers of a recorded graph, so they cannot be shared)."""
+        import copy
+        c = copy.copy(self)
+        c._plans, c._pe = {}, {}
+        return c
+
     def set_noise(self, noise: torch.Tensor):
         """Replaces rand_noise (the drop-in CausalConditionalCFM owns its own tensor, flow_matching.py:321)."""
         if noise is not self.rand_noise and not torch.equal(noise.cpu(), self.rand_noise):

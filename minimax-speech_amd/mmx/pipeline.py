@@ -93,11 +93,12 @@ class TtsEngine:
             i = j
         return out
 
-    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum):
+    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum, flow=None):
+        flow = flow or self.flow
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
-        conds = [self.flow.conditions(toks[b].reshape(1, -1), z, zf, embs[b]) for b in grp]
-        xs = self.flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
+        conds = [flow.conditions(toks[b].reshape(1, -1), z, zf, embs[b]) for b in grp]
+        xs = flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
         for b, lat in zip(grp, xs):
             T2 = lat.shape[0]
             zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
@@ -106,7 +107,7 @@ class TtsEngine:
 
     @torch.no_grad()
     def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=(2, 2, 4, 8), max_pad_ratio=2.0,
-                  frame_quantum=32, overlap=True, poll_every=8) -> List[torch.Tensor]:
+                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
         conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
@@ -138,16 +139,20 @@ class TtsEngine:
                 self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum)
             return wavs
 
-        if not hasattr(self, "_side"):
+        if not hasattr(self, "_sides") or len(self._sides) != flow_workers:
             # the decode loop is a chain of short latency-bound kernels: give it the high-priority queue so its
-            # launches are not parked behind the flow's large grids
-            self._side = torch.cuda.Stream(device=self.dev, priority=0)
+            # launches are not parked behind the flow's large grids.  The flow stage itself is a chain of short
+            # kernels too, so `flow_workers` host threads, each with its own stream and its own plan buffers (the
+            # weights are shared), solve different groups concurrently.
+            self._sides = [torch.cuda.Stream(device=self.dev, priority=0) for _ in range(flow_workers)]
+            self._flows = [self.flow] + [self.flow.clone_shared() for _ in range(flow_workers - 1)]
             self._hi = torch.cuda.Stream(device=self.dev, priority=-1)
-        side, q, err = self._side, queue.Queue(), []
+        q, err = queue.Queue(), []
         caller = torch.cuda.current_stream()
         self._hi.wait_stream(caller)
 
-        def worker():
+        def worker(wi):
+            side, flow = self._sides[wi], self._flows[wi]
             try:
                 torch.cuda.set_device(self.dev)
                 with torch.cuda.stream(side):
@@ -157,14 +162,15 @@ class TtsEngine:
                             return
                         grp, ev = item
                         side.wait_event(ev)                      # the group's token ids were written on the LM stream
-                        self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum)
+                        self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow)
             except BaseException as e:                           # surfaced by the caller
                 err.append(e)
 
         import time as _time
         self._t0 = _time.perf_counter()
-        th = threading.Thread(target=worker, daemon=True)
-        th.start()
+        ths = [threading.Thread(target=worker, args=(wi,), daemon=True) for wi in range(flow_workers)]
+        for th in ths:
+            th.start()
         main = self._hi
         pending: List[int] = []
         seen = set()
@@ -212,14 +218,18 @@ class TtsEngine:
         if timing:
             main.synchronize()
             t_lm = time.perf_counter()
-        q.put(None)
-        th.join()
+        for _ in ths:
+            q.put(None)
+        for th in ths:
+            th.join()
         if err:
             raise err[0]
         if timing:
-            side.synchronize()
+            for sd in self._sides:
+                sd.synchronize()
             print(f"[tts_batch] LM loop done at {(t_lm - self._t0) * 1e3:.0f} ms, flow/DAC tail until {(time.perf_counter() - self._t0) * 1e3:.0f} ms, "
                   f"decode steps {done}", flush=True)
-        caller.wait_stream(side)
+        for sd in self._sides:
+            caller.wait_stream(sd)
         caller.wait_stream(main)
         return wavs

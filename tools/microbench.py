@@ -111,3 +111,28 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tiles":
     for (N, K, act, out) in ((1024, 256, "none", "act"), (1024, 256, "gelu", "act"), (256, 1024, "none", "f32"), (256, 512, "none", "f32"), (256, 768, "none", "f32")):
         gemm_graph_case(512, N, K, 16, act, out)
         gemm_graph_case(512, N, K, 2, act, out)
+
+
+def skinny_case(B, K, N, epi):
+    w = (torch.randn((2 * N if epi == 1 else N), K, device="cuda") / 30).bfloat16()
+    ws = [ops.pack_skinny(w, dtype=1, interleave_half=(N if epi == 1 else 0)) for _ in range(12)]
+    x = torch.randn(B, K, device="cuda").bfloat16()
+    outf = torch.zeros(B, N, device="cuda") if epi != 1 else None
+    outa = torch.empty(B, N, device="cuda", dtype=torch.bfloat16)
+    it = [0]
+
+    def fn():
+        it[0] += 1
+        ops.skinny_gemm(x, ws[it[0] % 12], B=B, K=K, N=N, dtype=1, rs=(epi != 2), epi=epi, out_f32=outf, out_act=outa)
+    us = graph_time(fn, reps=48)
+    nbytes = w.numel() * 2
+    print(f"skinny B={B:3d} K={K:5d} N={N:5d} epi={epi}: {us:7.2f} us  {nbytes / us / 1e3:8.1f} GB/s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "skinny":
+    for B in (1, 8, 16, 17, 32, 48, 64):
+        skinny_case(B, 896, 4864, 1)
+    for B in (1, 16, 32):
+        skinny_case(B, 896, 1152, 0)
+        skinny_case(B, 896, 896, 2)
+        skinny_case(B, 4864, 896, 2)
