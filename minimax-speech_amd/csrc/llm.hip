@@ -437,20 +437,28 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
     const float* __restrict__ rope_tab, const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc,
     const int32_t* __restrict__ block_table, int max_pages, int page, float scale, T* __restrict__ out, long ldo) {
-    constexpr int D = 64, HALF = 32;
+    // Single pass ("flash decoding" inside one workgroup): thread = (key group kg of 32, channel chunk dc of 8).
+    // For each of its keys a thread loads 16 B of the K row and 16 B of the V row (both in flight together), the 8
+    // threads of a key reduce q.k with 3 xor-shuffles, every key group keeps its own running (max, sum, acc[8]);
+    // the 32 groups are merged once through LDS.  Two workgroup barriers in total; the block-table row is staged
+    // in LDS up front so no load depends on another load except through `pos`.
+    constexpr int D = 64, HALF = 32, NG = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* qs = reinterpret_cast<float*>(smem);        // [D]
+    float* qs = reinterpret_cast<float*>(smem);        // [D] rope(q) * scale * log2(e)
     float* kn = qs + D;                                // [D] new key (rounded through T)
     float* vn = kn + D;                                // [D] new value
-    float* red = vn + D;                               // [16]
-    float* part = red + 16;                            // [32][D]
-    float* S = part + 32 * D;                          // [ctx]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* gm = vn + D;                                // [NG] group max
+    float* gl = gm + NG;                               // [NG] group sum
+    float* part = gl + NG;                             // [NG][D]
+    int* bts = reinterpret_cast<int*>(part + NG * D);  // [max_pages]
+    const int tid = threadIdx.x;
     const int h = blockIdx.x, b = blockIdx.y;
     const int group = Hq / Hkv, hk = h / group;
-    const int p = pos[b];
     const int32_t* bt = block_table + (long)b * max_pages;
+    for (int i = tid; i < max_pages; i += 256) bts[i] = bt[i];
+    const int p = pos[b];
     const float* src = qkv + (long)b * ldqkv;
+    const float sc2 = scale * 1.44269504088896341f;
     if (tid < 2 * HALF) {
         const int which = tid >> 5, d = tid & 31;      // 0: q head h, 1: k head hk
         const float* x = src + (which == 0 ? h * D : (Hq + hk) * D);
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             s = sinf(ang);
         }
         const float y0 = x[d] * c - x[d + HALF] * s, y1 = x[d + HALF] * c + x[d] * s;
-        if (which == 0) { qs[d] = y0; qs[d + HALF] = y1; }
+        if (which == 0) { qs[d] = y0 * sc2; qs[d + HALF] = y1 * sc2; }
         else { kn[d] = Cvt<T>::to_f(Cvt<T>::from_f(y0)); kn[d + HALF] = Cvt<T>::to_f(Cvt<T>::from_f(y1)); }
     } else if (tid < 2 * HALF + D) {
         const int d = tid - 2 * HALF;
@@ -472,69 +480,57 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     }
     __syncthreads();
     if (h % group == 0 && tid < D) {                   // one workgroup per kv head appends to the cache
-        const long o = (((long)bt[p / page] * Hkv + hk) * page + p % page) * D + tid;
+        const long o = (((long)bts[p / page] * Hkv + hk) * page + p % page) * D + tid;
         kc[o] = Cvt<T>::from_f(kn[tid]);
         vc[o] = Cvt<T>::from_f(vn[tid]);
     }
-    float mx = -INFINITY;
-    for (int j = tid; j <= p; j += 256) {
-        float s = 0.f;
-        if (j < p) {
-            const T* kp = kc + (((long)bt[j / page] * Hkv + hk) * page + j % page) * D;
-            float kv[8][8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) load8<T>(kp + c * 8, kv[c]);
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += qs[c * 8 + e] * kv[c][e];
-        } else {
-#pragma unroll
-            for (int d = 0; d < D; ++d) s += qs[d] * kn[d];
-        }
-        s *= scale;
-        S[j] = s;
-        mx = fmaxf(mx, s);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float l = 0.f;
-    for (int j = tid; j <= p; j += 256) {
-        float e = expf(S[j] - mx);
-        S[j] = e;
-        l += e;
-    }
-    l = wave_sum(l);
-    if (lane == 0) red[4 + wave] = l;
-    __syncthreads();
-    l = red[4] + red[5] + red[6] + red[7];
-    // PV: thread -> (key group kg of 32, channel chunk dc of 8)
     const int kg = tid >> 3, dc = tid & 7;
-    float acc[8];
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = qs[dc * 8 + e];
+    float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll 4
-    for (int j = kg; j <= p; j += 32) {
-        float v[8];
-        if (j < p) load8<T>(vc + (((long)bt[j / page] * Hkv + hk) * page + j % page) * D + dc * 8, v);
-        else {
+    for (int j = kg; j <= p; j += NG) {
+        float kv[8], vv[8];
+        if (j < p) {
+            const long o = (((long)bts[j / page] * Hkv + hk) * page + j % page) * D + dc * 8;
+            load8<T>(kc + o, kv);
+            load8<T>(vc + o, vv);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = vn[dc * 8 + e];
+            for (int e = 0; e < 8; ++e) { kv[e] = kn[dc * 8 + e]; vv[e] = vn[dc * 8 + e]; }
         }
-        const float pj = S[j];
+        float sdot = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += pj * v[e];
+        for (int e = 0; e < 8; ++e) sdot += qv[e] * kv[e];
+        sdot += __shfl_xor(sdot, 1, 64);
+        sdot += __shfl_xor(sdot, 2, 64);
+        sdot += __shfl_xor(sdot, 4, 64);
+        const float mn = fmaxf(m, sdot);
+        const float al = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sdot - mn);
+        l = l * al + pj;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * al + pj * vv[e];
+        m = mn;
     }
+    if (dc == 0) { gm[kg] = m; gl[kg] = l; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[kg * D + dc * 8 + e] = acc[e];
     __syncthreads();
     if (tid < D) {
-        float o = 0.f;
+        float M = -INFINITY;
 #pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) o += part[k2 * D + tid];
-        out[(long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / l);
+        for (int g2 = 0; g2 < NG; ++g2) M = fmaxf(M, gm[g2]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2) {
+            const float w = __builtin_amdgcn_exp2f(gm[g2] - M);      // empty groups: exp2(-inf) = 0
+            L += gl[g2] * w;
+            o += part[g2 * D + tid] * w;
+        }
+        out[(long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
     }
 }
 extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
@@ -542,7 +538,8 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
                                int page, float scale, void* out, int64_t ldo, int dtype, hipStream_t stream) {
     MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
     const size_t max_ctx = (size_t)max_pages * page;
-    size_t lds = (3 * 64 + 16 + 32 * 64 + max_ctx) * 4;
+    (void)max_ctx;
+    size_t lds = (3 * 64 + 2 * 32 + 32 * 64 + (size_t)max_pages) * 4;
     MMX_CHECK_ARG(lds <= 160 * 1024);
     dim3 grid(Hq, B);
     if (dtype == MMX_BF16) hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, page, scale, (bf16_t*)out, ldo);
