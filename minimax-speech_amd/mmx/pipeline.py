@@ -147,7 +147,7 @@ class TtsEngine:
             self._sides = [torch.cuda.Stream(device=self.dev, priority=0) for _ in range(flow_workers)]
             self._flows = [self.flow] + [self.flow.clone_shared() for _ in range(flow_workers - 1)]
             self._hi = torch.cuda.Stream(device=self.dev, priority=-1)
-        q, err = queue.Queue(), []
+        qs, err = [queue.Queue() for _ in range(flow_workers)], []     # group k -> worker k % W (deterministic plan reuse)
         caller = torch.cuda.current_stream()
         self._hi.wait_stream(caller)
 
@@ -157,7 +157,7 @@ class TtsEngine:
                 torch.cuda.set_device(self.dev)
                 with torch.cuda.stream(side):
                     while True:
-                        item = q.get()
+                        item = qs[wi].get()
                         if item is None:
                             return
                         grp, ev = item
@@ -194,7 +194,7 @@ class TtsEngine:
             for grp in groups:
                 ev = torch.cuda.Event()
                 ev.record(main)
-                q.put((grp, ev))
+                qs[issued[0] % flow_workers].put((grp, ev))
                 issued[0] += 1
                 for b in grp:
                     pending.remove(b)
@@ -218,8 +218,8 @@ class TtsEngine:
         if timing:
             main.synchronize()
             t_lm = time.perf_counter()
-        for _ in ths:
-            q.put(None)
+        for qq in qs:
+            qq.put(None)
         for th in ths:
             th.join()
         if err:
