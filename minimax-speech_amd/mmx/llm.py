@@ -26,13 +26,24 @@ ST_POS, ST_STEP, ST_NOUT, ST_FIN, ST_MINLEN, ST_MAXLEN, ST_SEQ, ST_ERR = range(8
 class LlmEngine:
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
-                 prefix="llm.model.model"):
+                 prefix="llm.model.model", share_from=None):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.Hq, self.Hkv, self.D, self.eps = heads, kv_heads, head_dim, eps
         self.page, self.use_graphs = page, use_graphs
         self.eos = speech_token_size
         self.V = speech_token_size + 3
         dt = dtype
+        if share_from is not None:
+            # a second engine of a different batch size over the SAME packed weights and the SAME paged KV cache
+            # (used to continue a partly finished batch at a smaller, cheaper batch size: see compact_from)
+            o = share_from
+            for k in ("n_layers", "H", "I", "layers", "wdec", "bdec", "embed_tokens", "speech_emb", "llm_emb", "inv_freq",
+                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page"):
+                setattr(self, k, getattr(o, k))
+            self.B = max_batch
+            self.block_table = torch.zeros(self.B, self.max_pages, dtype=torch.int32, device=self.dev)
+            self._alloc_state()
+            return
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         c = lambda t: t.to(self.tdt).contiguous()
         self.n_layers = len({k.split(".")[4] for k in sd if k.startswith(prefix + ".layers.")})
@@ -65,10 +76,14 @@ class LlmEngine:
         self.B = max_batch
         self.max_pages = (max_ctx + page - 1) // page
         npages = self.B * self.max_pages
-        self.kc = torch.zeros(self.n_layers, npages, kv_heads, page, head_dim, dtype=self.tdt, device=self.dev)
+        self.trash_page = npages                  # scratch page for unused slots of a compacted batch
+        self.kc = torch.zeros(self.n_layers, npages + 1, kv_heads, page, head_dim, dtype=self.tdt, device=self.dev)
         self.vc = torch.zeros_like(self.kc)
         self.block_table = torch.arange(npages, dtype=torch.int32, device=self.dev).reshape(self.B, self.max_pages).contiguous()
         self.max_out = max_ctx
+        self._alloc_state()
+
+    def _alloc_state(self):
         B = self.B
         self.state = torch.zeros(8, B, dtype=torch.int32, device=self.dev)
         self.out_tokens = torch.zeros(B, self.max_out, dtype=torch.int32, device=self.dev)
@@ -183,6 +198,30 @@ class LlmEngine:
 
     def step(self):
         self._decode()
+
+    def compact_from(self, big: "LlmEngine", idx: List[int]):
+        """Continue the still-active sequences `idx` of `big` in this (smaller-batch) engine: loop state, token
+        history, next input embedding and block-table rows are gathered into slots 0..len(idx)-1; the KV pages
+        themselves are shared and stay where they are.  Unused slots are marked finished."""
+        n = len(idx)
+        assert n <= self.B and big.kc is self.kc
+        ii = torch.tensor(idx, dtype=torch.long, device=self.dev)
+        st = torch.zeros(8, self.B, dtype=torch.int32, device=self.dev)
+        st[ST_FIN, n:] = 1
+        st[:, :n] = big.state[:, ii]
+        self.state.copy_(st)
+        self.out_tokens[:n].copy_(big.out_tokens[ii])
+        self.sampled[:n].copy_(big.sampled[ii])
+        self.x_in[:n].copy_(big.x_in[ii])
+        self.block_table.fill_(self.trash_page)           # idle slots append their (ignored) KV to the scratch page
+        self.block_table[:n].copy_(big.block_table[ii])
+        self.seed, self.want_logp = big.seed, False
+        self.top_p, self.top_k, self.win_size, self.tau_r = big.top_p, big.top_k, big.win_size, big.tau_r
+        self.forced = None
+        key = (True, False, self.seed)
+        if self._decode is None or getattr(self, "_graph_key", None) != key:
+            self._decode = Graphed(self._decode_step, self.use_graphs)
+        self._graph_key = key
 
     def run(self, max_steps: int, poll_every: int = 8) -> List[List[int]]:
         """Decode until every sequence finished or max_steps tokens were tried; returns accepted tokens per sequence."""

@@ -27,6 +27,10 @@ class TtsEngine:
             self.dev = torch.device("cuda", torch.cuda.current_device())
         device = self.dev
         self.llm = LlmEngine(llm_sd, dtype=dtype, device=device, max_batch=max_batch, max_ctx=max_ctx, use_graphs=use_graphs)
+        # the decode step costs ~40 % more at 17..32 rows than at <= 16 (two MFMA row tiles): once at most 16
+        # sequences are still running the batch continues in a 16-slot engine over the same weights and KV pages
+        self.llm_small = (LlmEngine(None, dtype=dtype, device=device, max_batch=16, max_ctx=max_ctx, use_graphs=use_graphs,
+                                    share_from=self.llm) if max_batch > 16 else None)
         self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs)
         self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device)
         self.hop = self.dac.hop
@@ -176,14 +180,25 @@ class TtsEngine:
         seen = set()
         issued = [0]
 
+        cur = [self.llm, list(range(B))]                            # active engine, slot -> utterance index
+
         def harvest(final):
-            fin = self.llm.state[ST_FIN].tolist()
-            n = self.llm.state[ST_NOUT].tolist()
-            new = sorted([b for b in range(B) if (fin[b] or final) and b not in seen], key=lambda b: (n[b], b))
-            for b in new:
+            eng, slots = cur
+            fin = eng.state[ST_FIN].tolist()
+            n = eng.state[ST_NOUT].tolist()
+            new = sorted([s_ for s_ in range(len(slots)) if (fin[s_] or final) and slots[s_] not in seen],
+                         key=lambda s_: (n[s_], slots[s_]))
+            for s_ in new:
+                b = slots[s_]
                 seen.add(b)
-                toks[b] = self.llm.out_tokens[b, :n[b]].to(torch.int64)
+                toks[b] = eng.out_tokens[s_, :n[s_]].to(torch.int64)
                 pending.append(b)
+            if (not final and self.llm_small is not None and eng is self.llm and B - len(seen) <= self.llm_small.B
+                    and B - len(seen) > 0):
+                act = [s_ for s_ in range(len(slots)) if slots[s_] not in seen]
+                with CAPTURE_LOCK:
+                    self.llm_small.compact_from(self.llm, act)
+                cur[0], cur[1] = self.llm_small, [slots[s_] for s_ in act]
             frames = {b: 2 * toks[b].numel() for b in pending}
             groups = self._groups(pending, frames, group_size, max_pad_ratio, frame_quantum, first=issued[0])
             sizes = group_size if isinstance(group_size, (list, tuple)) else [group_size]
@@ -207,7 +222,7 @@ class TtsEngine:
                 k = min(poll_every, max_steps - done)
                 with CAPTURE_LOCK:                               # never launch while the other thread records a graph
                     for _ in range(k):
-                        self.llm.step()
+                        cur[0].step()
                 done += k
                 harvest(False)
                 if len(seen) == B:

@@ -114,3 +114,38 @@ def test_overlapped_batch_pipeline_equals_sequential(golden_dir):
         torch.cuda.synchronize()
         for a, b in zip(got, ref):
             assert a.shape == b.shape and (a - b).abs().max().item() < 2e-2, (rep, (a - b).abs().max().item())
+
+
+def test_compaction_to_smaller_batch_preserves_tokens(llm_sd):
+    """A 20-sequence batch that continues in the 16-slot engine once <= 16 sequences are active produces the same
+    tokens as the same batch decoded without compaction (same weights, same KV pages, same Philox streams)."""
+    from mmx.llm import LlmEngine, ST_FIN, ST_NOUT
+    g = torch.Generator().manual_seed(8)
+    z = torch.zeros(1, 0, dtype=torch.long).cuda()
+    B = 20
+    lens = [6 + (i * 3) % 17 for i in range(B)]
+    big = LlmEngine(llm_sd, dtype=1, max_batch=B, max_ctx=128)
+    small = LlmEngine(None, dtype=1, max_batch=16, max_ctx=128, share_from=big)
+    texts = [torch.randint(0, 151936, (1, 5), generator=g).cuda() for _ in range(B)]
+    xs = [big.build_lm_input(t, z, z) for t in texts]
+    big.start(xs, lens, lens, seed=4)
+    ref = big.run(max(lens))
+    big.start(xs, lens, lens, seed=4)
+    out = [None] * B
+    eng, slots, done = big, list(range(B)), 1
+    while done < max(lens):
+        eng.step()
+        done += 1
+        fin, n = eng.state[ST_FIN].tolist(), eng.state[ST_NOUT].tolist()
+        for s_, b in enumerate(slots):
+            if fin[s_] and out[b] is None:
+                out[b] = eng.out_tokens[s_, :n[s_]].tolist()
+        active = [s_ for s_, b in enumerate(slots) if out[b] is None]
+        if eng is big and 0 < len(active) <= 16:
+            small.compact_from(big, active)
+            eng, slots = small, [slots[s_] for s_ in active]
+    n = eng.state[ST_NOUT].tolist()
+    for s_, b in enumerate(slots):
+        if out[b] is None:
+            out[b] = eng.out_tokens[s_, :n[s_]].tolist()
+    assert out == ref
