@@ -65,8 +65,8 @@ def measure_dominant_kernel(eng, iters=240):
     achieved = nbytes / (us * 1e-6) / 1e9
     traffic = None
     pj = os.path.join(ROOT, "profiles", "r01_pmc_skinny.json")
-    if os.path.exists(pj) and B == 1:
-        traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+    if os.path.exists(pj) and B in (1, 32):
+        traffic = json.load(open(pj)).get("hbm_bytes_per_launch" if B == 1 else "batch32_hbm_bytes_per_launch")
     return {"bound": "hbm", "kernel": f"skinny_gemm_kernel (LM gate/up + SwiGLU, K=896, N=2x4864, batch {B})",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
