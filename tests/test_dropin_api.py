@@ -166,3 +166,33 @@ def test_dropin_qwen2lm_inference_generator(golden_dir):
                              prompt_speech_token=z, prompt_speech_token_len=torch.tensor([0]).cuda(), embedding=torch.zeros(0, 192).cuda()))
     assert all(isinstance(t, int) and 0 <= t < 6561 for t in toks)
     assert 12 - 2 <= len(toks) <= 120                    # min_len = 2*6 steps (ids > 6561 are skipped), max_len = 20*6
+
+
+@pytest.mark.gpu
+def test_cosyvoice2model_tts_streaming_and_offline(golden_dir):
+    """CosyVoice2Model.tts drop-in (cli/model.py:321-386 schedule, DAC instead of HiFT): the non-streaming call and the
+    streaming call (hops of 25 tokens + 3 look-ahead, chunk-causal flow) both produce 480 samples per latent frame."""
+    from functools import partial
+    from cosyvoice.cli.model import CosyVoice2Model
+    from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM
+    from cosyvoice.utils.common import ras_sampling
+    from oracle import weights as W
+    from mmx import shapes
+    lm = Qwen2LM(896, 896, 6561, Qwen2Encoder({"num_hidden_layers": 2}), partial(ras_sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1))
+    lm.load_state_dict(W.synth_state_dict(shapes.llm_manifest(layers=2), 7), strict=True)
+    flow = build_flow()
+    flow.load_state_dict(W.synth_state_dict(_ref(golden_dir, "flow"), 7), strict=True)
+    dac = build_dac(80)
+    dac.load_state_dict(W.synth_state_dict(_ref(golden_dir, "dac80"), 7), strict=True)
+    model = CosyVoice2Model(lm.to("cuda"), flow.to("cuda"), dac.to("cuda"))
+    g = torch.Generator().manual_seed(5)
+    text = torch.randint(0, 151936, (1, 30), generator=g)
+    emb = torch.randn(1, 192, generator=g)
+    off = list(model.tts(text=text, flow_embedding=emb, llm_embedding=emb, stream=False))
+    assert len(off) == 1
+    n_off = off[0]["tts_speech"].shape[1]
+    assert n_off % 960 == 0 and n_off >= 60 * 960 - 2 * 960          # >= min_len = 2 * 30 tokens (minus skipped ids)
+    chunks = list(model.tts(text=text, flow_embedding=emb, llm_embedding=emb, stream=True))
+    n_str = sum(c["tts_speech"].shape[1] for c in chunks)
+    assert len(chunks) >= 2 and n_str == n_off                        # same tokens (same Philox stream) -> same length
+    assert all(torch.isfinite(c["tts_speech"]).all() for c in chunks)

@@ -87,3 +87,17 @@ def test_batched_masked_cfm_equals_single(engines, dt, tol):
         for a, b in zip(batch, single):
             assert a.shape == b.shape
             assert (a - b).abs().max().item() < tol, (dt, rep, (a - b).abs().max().item())
+
+
+def test_estimator_max_profile_length_bf16_vs_fp32(engines):
+    """T = 3000 frames (the reference's TensorRT profile maximum, cli/model.py:96-101), ragged (not a multiple of any
+    tile): the bf16 build (MFMA flash attention) agrees with the fp32 build (dense attention) within the bf16 bound."""
+    T = 3000
+    g = torch.Generator().manual_seed(2)
+    x, mu = torch.randn(2, 80, T, generator=g).cuda(), torch.randn(2, 80, T, generator=g).cuda()
+    cond, spks = torch.zeros(2, 80, T).cuda(), torch.randn(2, 80, generator=g).cuda()
+    t, mask = torch.tensor([0.5, 0.5]).cuda(), torch.ones(2, 1, T).cuda()
+    a = engines[0].estimator_channels_first(x, mask, mu, t, spks, cond, True)
+    b = engines[1].estimator_channels_first(x, mask, mu, t, spks, cond, True)
+    assert a.shape == (2, 80, T) and torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert (a - b).abs().max().item() < 0.15 and (a - b).abs().mean().item() < 0.01
