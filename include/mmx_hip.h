@@ -88,6 +88,11 @@ int mmx_rownorm(const float* x, int64_t ldx, int64_t x_bstride, int rows, int C,
                 float* out_f32, int64_t ldo_f, int64_t of_bstride,
                 void* out_act, int64_t ldo_a, int64_t oa_bstride, int dtype, hipStream_t stream);
 
+/* GroupNorm over a time-major fp32 tensor [B][T][C] (statistics per (batch, group) over C/groups channels x T),
+ * output in T.  Replaces arch_util.py:21-38 GroupNorm32 inside LearnableSpeakerEncoder (llm.py:34-96). */
+int mmx_groupnorm(const float* x, int B, int T, int C, int groups, const float* gamma, const float* beta, float eps,
+                  void* out, int dtype, hipStream_t stream);
+
 /* out[i][:] = table[ids[i]][:] * scale * (rowmask ? rowmask[i] : 1)   (ids < 0 are clamped to 0,
  * flow.py:477).  Replaces nn.Embedding lookups (flow.py:477, llm.py:694-700). */
 int mmx_gather_rows(const int64_t* ids, int n, const float* table, int C, float scale, const float* rowmask,
@@ -121,6 +126,8 @@ int mmx_cfg_euler(float* x, const float* d_cond, const float* d_uncond, float cf
  *   rows with no visible key output 0 (they are padding rows, masked by every consumer).
  *   rel-pos (pos != NULL): score = ((q+u).k + (q+v).pos[T-1-i+j]) * scale — attention.py:225-330 with
  *   rel_shift folded into the index; pos is [2T-1][H*D] T-typed, u/v fp32 [H][D].
+ *   head_stride: column distance between heads inside q/k/v (0 = D; 3*D for the head-interleaved qkv of
+ *   arch_util.py:58-77 QKVAttentionLegacy, whose q*s . k*s with s = D^-1/4 equals scale = D^-1/2).
  *   Replaces diffusers Attention (SDPA) of transformer.py:196-204 with the additive bias of
  *   decoder.py:441-445 / common.py:160-168, and RelPositionMultiHeadedAttention.
  * mmx_attn_flash_bf16: the MFMA flash-attention kernel for the same contract without rel-pos, bf16,
@@ -130,7 +137,7 @@ int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int6
                    const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
                    int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs, int chunk,
                    const void* pos, int64_t ldp, const float* pos_u, const float* pos_v,
-                   int dtype, hipStream_t stream);
+                   int head_stride, int dtype, hipStream_t stream);
 int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                         int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk,

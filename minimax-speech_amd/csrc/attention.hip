@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
     const T* __restrict__ q, long ldq, long q_bs, const T* __restrict__ k, long ldk, long k_bs,
     const T* __restrict__ v, long ldv, long v_bs, T* __restrict__ out, long ldo, long o_bs,
     int H, int Tq, int Tk, float scale, const float* __restrict__ keymask, long km_bs, int chunk,
-    const T* __restrict__ pos, long ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v) {
+    const T* __restrict__ pos, long ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v, int hs) {
     constexpr int D = 64, QT = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qu = reinterpret_cast<float*>(smem);        // [QT][D]  q (+u)
@@ -29,9 +29,9 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
     float* S = inv_l + QT;                             // [QT][Tk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QT;
-    q += (long)b * q_bs + h * D;
-    k += (long)b * k_bs + h * D;
-    v += (long)b * v_bs + h * D;
+    q += (long)b * q_bs + h * hs;                     // hs: column stride between heads of q/k/v (D, or 3D for the
+    k += (long)b * k_bs + h * hs;                     // head-interleaved qkv of arch_util.QKVAttentionLegacy)
+    v += (long)b * v_bs + h * hs;
     out += (long)b * o_bs + h * D;
     const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
 
@@ -109,8 +109,9 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
                               const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
                               int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs,
                               int chunk, const void* pos, int64_t ldp, const float* pos_u, const float* pos_v,
-                              int dtype, hipStream_t stream) {
+                              int head_stride, int dtype, hipStream_t stream) {
     MMX_CHECK_ARG(q && k && v && out && B > 0 && H > 0 && D == 64 && Tq > 0 && Tk > 0 && chunk >= 0);
+    const int hs = head_stride > 0 ? head_stride : D;
     MMX_CHECK_ARG(!pos || (pos_u && pos_v && Tq == Tk));
     size_t lds = (size_t)(2 * 8 * 64 + 8 + 8 * (size_t)Tk) * 4;
     MMX_CHECK_ARG(lds <= 160 * 1024);
@@ -118,11 +119,11 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
     if (dtype == MMX_BF16)
         hipLaunchKernelGGL(attn_dense_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
                            (const bf16_t*)v, ldv, v_bs, (bf16_t*)out, ldo, o_bs, H, Tq, Tk, scale, keymask, km_bs, chunk,
-                           (const bf16_t*)pos, ldp, pos_u, pos_v);
+                           (const bf16_t*)pos, ldp, pos_u, pos_v, hs);
     else if (dtype == MMX_F32)
         hipLaunchKernelGGL(attn_dense_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, ldq, q_bs, (const float*)k, ldk, k_bs,
                            (const float*)v, ldv, v_bs, (float*)out, ldo, o_bs, H, Tq, Tk, scale, keymask, km_bs, chunk,
-                           (const float*)pos, ldp, pos_u, pos_v);
+                           (const float*)pos, ldp, pos_u, pos_v, hs);
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;

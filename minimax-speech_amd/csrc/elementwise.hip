@@ -266,4 +266,49 @@ extern "C" int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* 
     return MMX_OK;
 }
 
+// ---------------------------------------------------------------------------- GroupNorm over time-major [B][T][C]
+// one workgroup per (group, batch): statistics over (C/groups channels) x T, two-pass in fp32 (mean, then variance),
+// like torch.nn.GroupNorm on x.float() (arch_util.GroupNorm32).  T is a few hundred frames: a reference mel crop.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x, int Tn, int C, int cpg,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, T* __restrict__ out) {
+    __shared__ float sh[8];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (long)b * Tn * C + g * cpg;
+    T* ob = out + (long)b * Tn * C + g * cpg;
+    const int n = Tn * cpg;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return sh[0] + sh[1] + sh[2] + sh[3];
+    };
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += xb[(long)(i / cpg) * C + i % cpg];
+    const float mean = block_sum(s) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float d = xb[(long)(i / cpg) * C + i % cpg] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(q) / (float)n + eps);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i % cpg;
+        const long o = (long)(i / cpg) * C + c;
+        ob[o] = Cvt<T>::from_f((xb[o] - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c]);
+    }
+}
+extern "C" int mmx_groupnorm(const float* x, int B, int T_, int C, int groups, const float* gamma, const float* beta,
+                             float eps, void* out, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(x && gamma && beta && out && B > 0 && T_ > 0 && C > 0 && groups > 0 && C % groups == 0);
+    dim3 grid(groups, B);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(groupnorm_kernel<bf16_t>, grid, dim3(256), 0, stream, x, T_, C, C / groups, gamma, beta, eps, (bf16_t*)out);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(groupnorm_kernel<float>, grid, dim3(256), 0, stream, x, T_, C, C / groups, gamma, beta, eps, (float*)out);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
 extern "C" int mmx_abi_version(void) { return 1; }

@@ -72,6 +72,10 @@ class FlowEngine:
         self._pe, self._plans = {}, {}
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
+        self.spk_enc = None
+        if "speaker_encoder.init.weight" in sd:
+            from .spk import SpeakerEncoderEngine
+            self.spk_enc = SpeakerEncoderEngine(sd, dtype=dtype, device=device)
         if "encoder" in parts:
             self._init_encoder(sd, f, lin, cv)
         if "estimator" in parts:
@@ -458,19 +462,24 @@ class FlowEngine:
 
     # ------------------------------------------------------------------ flow.inference
     @torch.no_grad()
-    def inference_time_major(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):
+    def inference_time_major(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True,
+                             reference_mels=None):
         """token [1,Lt], prompt_token [1,Lp] ints; prompt_feat [1,Tp,80]; embedding [1,192] (device tensors).
         Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped)."""
-        mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize)
+        mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels)
         x = self.cfm(mu, spks, cond, streaming)
         return x[mel_len1:]
 
     @torch.no_grad()
-    def conditions(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):
+    def conditions(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True, reference_mels=None):
         """Everything of flow.inference ahead of the ODE solve (flow.py:455-498): speaker projection, token
-        embedding + conformer encoder -> mu, prompt condition.  Returns (mu [T,80], spks [1,80], cond [T,80], Tp)."""
+        embedding + conformer encoder -> mu, prompt condition.  Returns (mu [T,80], spks [1,80], cond [T,80], Tp).
+        reference_mels ([1,N,80,T] or [1,80,T]) selects the learnable speaker encoder (flow.py:456-462)."""
         dt = self.dtype
-        emb = embedding.to(self.dev, torch.float32).contiguous()
+        if reference_mels is not None and self.spk_enc is not None:
+            emb = self.spk_enc.reference_embedding(reference_mels)
+        else:
+            emb = embedding.to(self.dev, torch.float32).contiguous()
         en = self._new(1, self.spk_dim)
         # F.normalize(embedding, dim=1) == rmsnorm with gamma 1/sqrt(d) and eps -> 0
         ops.rownorm(emb, self.spk_gamma, None, 1e-30, rows=1, C_=self.spk_dim, rms=True, out_act=en, dtype=dt)
@@ -486,9 +495,9 @@ class FlowEngine:
         return mu, spks, cond, mel_len1
 
     @torch.no_grad()
-    def inference(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True):
+    def inference(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True, reference_mels=None):
         """Reference layout: returns feat [1, 80, T2] fp32 (flow.py:509-511)."""
-        x = self.inference_time_major(token, prompt_token, prompt_feat, embedding, streaming, finalize)
+        x = self.inference_time_major(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels)
         T2 = x.shape[0]
         out = torch.empty(1, 80, T2, dtype=torch.float32, device=self.dev)
         ops.copy2d(x, F32, 0, 80, 1, out, F32, 0, 1, T2, rows=T2, cols=80)

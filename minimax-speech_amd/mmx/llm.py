@@ -143,18 +143,33 @@ class LlmEngine:
         self._tail(B)
 
     # ------------------------------------------------------------------ request setup
-    def build_lm_input(self, text, prompt_text, prompt_speech_token):
-        """llm.py:691-703: [sos | embed(prompt_text ++ text) | task_id | speech_emb(prompt_speech)] fp32 [L, H]."""
+    def build_lm_input(self, text, prompt_text, prompt_speech_token, speaker_embed=None):
+        """llm.py:691-703: [sos | embed(prompt_text ++ text) | task_id | speech_emb(prompt_speech)] fp32 [L, H];
+        with speaker_embed ([1, H], inference_spk, llm.py:663): [sos | speaker_embed | text | task_id | prompt speech]."""
         tok = torch.cat([prompt_text.reshape(-1), text.reshape(-1)]).to(self.dev, torch.int64)
-        L = 2 + tok.numel() + prompt_speech_token.numel()
+        s = 0 if speaker_embed is None else 1
+        L = 2 + s + tok.numel() + prompt_speech_token.numel()
         x = torch.empty(L, self.H, device=self.dev)
         x[0].copy_(self.llm_emb[0])
-        ops.gather_rows(tok, self.embed_tokens, out_f32=x[1:1 + tok.numel()], dtype=F32)
-        x[1 + tok.numel()].copy_(self.llm_emb[1])
+        if s:
+            x[1].copy_(speaker_embed.reshape(-1))
+        ops.gather_rows(tok, self.embed_tokens, out_f32=x[1 + s:1 + s + tok.numel()], dtype=F32)
+        x[1 + s + tok.numel()].copy_(self.llm_emb[1])
         if prompt_speech_token.numel():
             ops.gather_rows(prompt_speech_token.reshape(-1).to(self.dev, torch.int64), self.speech_emb,
-                            out_f32=x[2 + tok.numel():], dtype=F32)
+                            out_f32=x[2 + s + tok.numel():], dtype=F32)
         return x
+
+    def speaker_conditioning(self, sd_linear_w, sd_linear_b, emb192):
+        """normalize -> spk_embed_affine_layer (llm.py:184-186 / :650-653): [1,192] -> [1,H] fp32."""
+        import math
+        d = emb192.shape[1]
+        g = torch.full((d,), 1.0 / math.sqrt(d), device=self.dev)
+        en = torch.empty(1, d, dtype=self.tdt, device=self.dev)
+        ops.rownorm(emb192.to(self.dev, torch.float32).contiguous(), g, None, 1e-30, rows=1, C_=d, rms=True, out_act=en, dtype=self.dtype)
+        out = torch.empty(1, self.H, device=self.dev)
+        ops.linear(en, sd_linear_w, d, dtype=self.dtype, bias=sd_linear_b, out_f32=out)
+        return out
 
     def start(self, lm_inputs: List[torch.Tensor], min_lens: List[int], max_lens: List[int], seed=0, seq_ids=None,
               forced: Optional[torch.Tensor] = None, want_logp=False):

@@ -110,6 +110,11 @@ def rownorm(x, gamma, beta, eps, *, rows, C_, batch=1, x_bstride=None, rms=False
                              dtype, stream()), "mmx_rownorm")
 
 
+def groupnorm(x, gamma, beta, out, *, B, T, C_, groups, dtype, eps=1e-5):
+    check(load().mmx_groupnorm(_p(x), B, T, C_, groups, _p(gamma), _p(beta), C.c_float(eps), _p(out), dtype, stream()),
+          "mmx_groupnorm")
+
+
 def gather_rows(ids, table, *, scale=1.0, rowmask=None, out_f32=None, out_act=None, dtype=F32):
     n, C_ = ids.numel(), table.shape[1]
     check(load().mmx_gather_rows(_p(ids), n, _p(table), C_, C.c_float(scale), _p(rowmask), _p(out_f32), i64(C_),
@@ -143,10 +148,10 @@ def conv_cout1_tanh(act, w, bias, out, *, T, C_, k, batch, dtype, slope=0.1, use
 
 # ----------------------------------------------------------------------------- attention
 def attn_dense(q, k, v, out, *, B, H, Tq, Tk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, dtype,
-               keymask=None, chunk=0, pos=None, ldp=0, pos_u=None, pos_v=None):
+               keymask=None, chunk=0, pos=None, ldp=0, pos_u=None, pos_v=None, head_stride=0):
     check(load().mmx_attn_dense(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(v), i64(ldv), i64(v_bs),
                                 _p(out), i64(ldo), i64(o_bs), B, H, 64, Tq, Tk, C.c_float(scale), _p(keymask),
-                                i64(Tk), chunk, _p(pos), i64(ldp), _p(pos_u), _p(pos_v), dtype, stream()),
+                                i64(Tk), chunk, _p(pos), i64(ldp), _p(pos_u), _p(pos_v), head_stride, dtype, stream()),
           "mmx_attn_dense")
 
 

@@ -41,9 +41,25 @@ def dac_decoder_manifest(latent_dim=80, decoder_dim=1536, rates=(5, 4, 4, 3, 2),
     return m
 
 
+def speaker_encoder_manifest(prefix="speaker_encoder", mel_dim=80, model_dim=512, output_dim=192, num_blocks=6) -> Manifest:
+    """LearnableSpeakerEncoder (speech/cosyvoice/llm/llm.py:34-63) with AttentionBlock (arch_util.py:87-115)."""
+    m: Manifest = {f"{prefix}.init.weight": (model_dim, mel_dim, 1), f"{prefix}.init.bias": (model_dim,)}
+    for i in range(num_blocks):
+        p = f"{prefix}.attn.{i}"
+        m[p + ".norm.weight"] = (model_dim,)
+        m[p + ".norm.bias"] = (model_dim,)
+        m[p + ".qkv.weight"] = (3 * model_dim, model_dim, 1)
+        m[p + ".qkv.bias"] = (3 * model_dim,)
+        m[p + ".proj_out.weight"] = (model_dim, model_dim, 1)
+        m[p + ".proj_out.bias"] = (model_dim,)
+    m[f"{prefix}.output_proj.weight"] = (output_dim, model_dim)
+    m[f"{prefix}.output_proj.bias"] = (output_dim,)
+    return m
+
+
 def flow_manifest(vocab=6561, input_size=512, output_size=80, spk_embed_dim=192, heads=8, linear_units=2048,
                   num_blocks=6, num_up_blocks=4, est_in=320, est_ch=256, n_blocks=4, num_mid_blocks=12, est_heads=8,
-                  head_dim=64, pre_lookahead_len=3) -> Manifest:
+                  head_dim=64, pre_lookahead_len=3, use_speaker_encoder=False) -> Manifest:
     """speech/config.yaml:60-116 -> CausalMaskedDiffWithXvec(UpsampleConformerEncoder, CausalConditionalCFM(
     CausalConditionalDecoder)) with use_speaker_encoder=False."""
     m: Manifest = {}
@@ -63,6 +79,8 @@ def flow_manifest(vocab=6561, input_size=512, output_size=80, spk_embed_dim=192,
         m[p + ".bias"] = (o,)
 
     m["input_embedding.weight"] = (vocab, d)
+    if use_speaker_encoder:
+        m.update(speaker_encoder_manifest(output_dim=spk_embed_dim))
     lin("spk_embed_affine_layer", output_size, spk_embed_dim)
     for e in ("encoder.embed", "encoder.up_embed"):
         lin(e + ".out.0", d, d)
@@ -124,7 +142,7 @@ def flow_manifest(vocab=6561, input_size=512, output_size=80, spk_embed_dim=192,
 
 
 def llm_manifest(vocab=151936, hidden=896, inter=4864, layers=24, heads=14, kv_heads=2, head_dim=64,
-                 speech_token_size=6561, spk_embed_dim=192, tie_lm_head=True) -> Manifest:
+                 speech_token_size=6561, spk_embed_dim=192, tie_lm_head=True, use_speaker_encoder=False) -> Manifest:
     """Qwen2LM (llm.py:375-436) around Qwen2Encoder(HF Qwen2ForCausalLM, CosyVoice-BlankEN == Qwen2.5-0.5B shape).
     `llm.model.lm_head.weight` is tied to embed_tokens and not listed (it is never read on the hot path)."""
     m: Manifest = {"llm_embedding.weight": (2, hidden), "llm.model.model.embed_tokens.weight": (vocab, hidden)}
@@ -143,6 +161,8 @@ def llm_manifest(vocab=151936, hidden=896, inter=4864, layers=24, heads=14, kv_h
     m["llm_decoder.weight"] = (speech_token_size + 3, hidden)
     m["llm_decoder.bias"] = (speech_token_size + 3,)
     m["speech_embedding.weight"] = (speech_token_size + 3, hidden)
+    if use_speaker_encoder:
+        m.update(speaker_encoder_manifest(output_dim=spk_embed_dim))
     m["spk_embed_affine_layer.weight"] = (hidden, spk_embed_dim)
     m["spk_embed_affine_layer.bias"] = (hidden,)
     return m

@@ -44,6 +44,9 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
         if n.endswith("weight"):
             return _randn(shape, g, 0.1, 1.0)
         return _randn(shape, g, 0.05)
+    if n.endswith("proj_out.weight"):                  # AttentionBlock output (zero-init in the reference): damped residual
+        fan_in = shape[1] * (shape[2] if len(shape) > 2 else 1)
+        return _randn(shape, g, 0.5 / math.sqrt(fan_in))
     if n.endswith("pos_bias_u") or n.endswith("pos_bias_v"):
         return _randn(shape, g, 0.2)
     if n.endswith("bias"):

@@ -17,8 +17,6 @@ class CausalMaskedDiffWithXvec(EngineHost):
                  speaker_encoder_path: str = None, encoder: nn.Module = None, decoder: nn.Module = None,
                  decoder_conf: Dict = None, mel_feat_conf: Dict = None):
         super().__init__()
-        if use_speaker_encoder:
-            raise NotImplementedError("LearnableSpeakerEncoder is SURVEY.md §8f 'next', not built yet")
         self.input_size, self.output_size, self.vocab_size = input_size, output_size, vocab_size
         self.output_type, self.input_frame_rate = output_type, input_frame_rate
         self.spk_embed_dim = spk_embed_dim
@@ -30,6 +28,11 @@ class CausalMaskedDiffWithXvec(EngineHost):
         self.only_mask_loss = only_mask_loss
         man = shapes.flow_manifest(vocab=vocab_size, input_size=input_size, output_size=output_size, spk_embed_dim=spk_embed_dim)
         register(self, {k: v for k, v in man.items() if not k.startswith(("encoder.", "decoder."))})
+        if use_speaker_encoder:
+            from cosyvoice.llm.llm import LearnableSpeakerEncoder
+            self.speaker_encoder = LearnableSpeakerEncoder(mel_dim=80, model_dim=512, output_dim=spk_embed_dim,
+                                                           num_blocks=6, num_heads=8)
+        self.freeze_speaker_encoder = freeze_speaker_encoder
         self.encoder = encoder
         self.decoder = decoder
 
@@ -52,4 +55,5 @@ class CausalMaskedDiffWithXvec(EngineHost):
         assert token.shape[0] == 1
         if embedding is None:
             embedding = torch.zeros(1, self.spk_embed_dim, device=token.device)
-        return self._eng().inference(token, prompt_token, prompt_feat, embedding, streaming, finalize), None
+        ref = reference_mels if self.use_speaker_encoder else None
+        return self._eng().inference(token, prompt_token, prompt_feat, embedding, streaming, finalize, ref), None

@@ -35,6 +35,31 @@ def _qwen_cfg(pretrain_path):
     return cfg
 
 
+class LearnableSpeakerEncoder(EngineHost):
+    """llm.py:34-96 (Tortoise-style conditioning encoder): mel [B,80,T] -> L2-normalised [B,output_dim]."""
+
+    def __init__(self, mel_dim: int = 80, model_dim: int = 512, output_dim: int = 192, num_blocks: int = 6,
+                 num_heads: int = 8, dropout: float = 0.0, mean_pooling: bool = False):
+        super().__init__()
+        if mean_pooling or model_dim // num_heads != 64:
+            raise NotImplementedError("first-frame pooling and 64-d heads (the reference's instantiation) only")
+        self.dim, self.mean_pooling, self.num_heads = model_dim, mean_pooling, num_heads
+        register(self, shapes.speaker_encoder_manifest("speaker_encoder", mel_dim, model_dim, output_dim, num_blocks),
+                 prefix="speaker_encoder.")
+
+    def _eng(self):
+        from mmx.spk import SpeakerEncoderEngine
+        dev = self._device()
+        if self._engine is None:
+            sd = {"speaker_encoder." + k: v for k, v in self.state_dict().items()}
+            self._engine = SpeakerEncoderEngine(sd, dtype=self.compute_dtype, device=dev, heads=self.num_heads)
+        return self._engine
+
+    @torch.inference_mode()
+    def forward(self, x, mask=None):
+        return self._eng().encode(x)
+
+
 class Qwen2Encoder(nn.Module):
     def __init__(self, pretrain_path):
         super().__init__()
@@ -54,8 +79,6 @@ class Qwen2LM(EngineHost):
                  mix_ratio: List[int] = [5, 15], use_speaker_encoder: bool = False, spk_embed_dim: int = 192,
                  max_conditioning_inputs: int = 2):
         super().__init__()
-        if use_speaker_encoder:
-            raise NotImplementedError("LearnableSpeakerEncoder (llm.py:34-96) is SURVEY.md §8f 'next', not built yet")
         self.llm_input_size, self.llm_output_size = llm_input_size, llm_output_size
         self.speech_token_size = speech_token_size
         self.use_speaker_encoder, self.spk_embed_dim = use_speaker_encoder, spk_embed_dim
@@ -68,6 +91,9 @@ class Qwen2LM(EngineHost):
                                   kv_heads=c["num_key_value_heads"], head_dim=c["hidden_size"] // c["num_attention_heads"],
                                   speech_token_size=speech_token_size, spk_embed_dim=spk_embed_dim)
         register(self, {k: v for k, v in man.items() if not k.startswith("llm.")})
+        if use_speaker_encoder:
+            self.speaker_encoder = LearnableSpeakerEncoder(mel_dim=80, model_dim=512, output_dim=spk_embed_dim, num_blocks=6,
+                                                           num_heads=8)
         self.sampling = sampling
         self.mix_ratio = mix_ratio
         self.stop_token_ids = [speech_token_size + i for i in range(3)]
@@ -94,6 +120,34 @@ class Qwen2LM(EngineHost):
         return self._engine
 
     @torch.inference_mode()
+    def inference_spk(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len,
+                      embedding=None, reference_mels=None, reference_mel_lengths=None, reference_mel_masks=None,
+                      sampling: int = 25, max_token_text_ratio: float = 20, min_token_text_ratio: float = 2,
+                      uuid: str = "") -> Generator[int, None, None]:
+        """llm.py:616-674: like `inference` with a speaker-conditioning row after <sos>: from the learnable speaker
+        encoder on `reference_mels` [1,N,80,T], else from `embedding` [1,192], else zeros."""
+        eng = self.engine(1)
+        tl = int(text.shape[1])
+        text_len += prompt_text_len
+        if self.use_speaker_encoder and reference_mels is not None:
+            e = self.speaker_encoder._eng().reference_embedding(reference_mels)
+        elif embedding is not None and embedding.shape[0] != 0:
+            e = embedding
+        else:
+            e = None
+        if e is not None:
+            from mmx import ops as _ops
+            if getattr(self, "_spk_w", None) is None or self._engine_spk is not eng:
+                self._spk_w = _ops.pack_linear(self.spk_embed_affine_layer.weight.detach().float(), eng.dtype)
+                self._spk_b = self.spk_embed_affine_layer.bias.detach().float().contiguous()
+                self._engine_spk = eng
+            spk = eng.speaker_conditioning(self._spk_w, self._spk_b, e)
+        else:
+            spk = torch.zeros(1, self.llm_input_size, device=eng.dev)
+        x = eng.build_lm_input(text, prompt_text, prompt_speech_token, speaker_embed=spk)
+        yield from self._decode_loop(eng, x, int(tl * min_token_text_ratio), int(tl * max_token_text_ratio))
+
+    @torch.inference_mode()
     def inference(self, text: torch.Tensor, text_len: torch.Tensor, prompt_text: torch.Tensor,
                   prompt_text_len: torch.Tensor, prompt_speech_token: torch.Tensor,
                   prompt_speech_token_len: torch.Tensor, embedding: torch.Tensor, sampling: int = 25,
@@ -104,7 +158,9 @@ class Qwen2LM(EngineHost):
         tl = int(text.shape[1])
         text_len += prompt_text_len                      # the reference mutates text_len in place (llm.py:693)
         x = eng.build_lm_input(text, prompt_text, prompt_speech_token)
-        min_len, max_len = int(tl * min_token_text_ratio), int(tl * max_token_text_ratio)
+        yield from self._decode_loop(eng, x, int(tl * min_token_text_ratio), int(tl * max_token_text_ratio))
+
+    def _decode_loop(self, eng, x, min_len, max_len):
         eng.start([x], [min_len], [max_len], seed=self.seed)
         sent = 0
         done = 1

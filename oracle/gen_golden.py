@@ -204,6 +204,50 @@ def gen_llm():
     np.savez_compressed(os.path.join(GOLD, "llm.npz"), **out)
 
 
+def gen_spk():
+    """LearnableSpeakerEncoder alone, flow.inference with reference_mels (use_speaker_encoder=True) and the lm_input of
+    Qwen2LM.inference_spk."""
+    R.import_cosyvoice()
+    from cosyvoice.llm.llm import LearnableSpeakerEncoder
+    torch.manual_seed(0)
+    enc = LearnableSpeakerEncoder(mel_dim=80, model_dim=512, output_dim=192, num_blocks=6, num_heads=8).eval()
+    sd = {"speaker_encoder." + k: v for k, v in enc.state_dict().items()}
+    W.save_manifest(sd, os.path.join(GOLD, "manifest_spk.json"))
+    syn = W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED)
+    enc.load_state_dict({k[len("speaker_encoder."):]: v for k, v in syn.items()}, strict=True)
+    g = torch.Generator().manual_seed(41)
+    out = {}
+    for T in (37, 150):
+        mel = torch.randn(2, 80, T, generator=g)
+        out[f"mel_T{T}"] = np_(mel)
+        out[f"emb_T{T}"] = np_(enc(mel))
+        print(f"spk T={T}: emb {tuple(out[f'emb_T{T}'].shape)} norm {np.linalg.norm(out[f'emb_T{T}'], axis=1)}")
+    # flow with the speaker encoder enabled and two reference crops
+    import cosyvoice.flow.flow as FL
+    flow = build_flow_spk()
+    fsd = flow.state_dict()
+    W.save_manifest(fsd, os.path.join(GOLD, "manifest_flow_spk.json"))
+    flow.load_state_dict(W.synth_state_dict({k: v.shape for k, v in fsd.items()}, SEED), strict=True)
+    tok = torch.randint(0, 6561, (1, 20), generator=g)
+    refs = torch.randn(1, 2, 80, 60, generator=g)
+    y, _ = flow.inference(token=tok, token_len=torch.tensor([20]), prompt_token=torch.zeros(1, 0, dtype=torch.long),
+                          prompt_token_len=torch.tensor([0]), prompt_feat=torch.zeros(1, 0, 80), prompt_feat_len=torch.tensor([0]),
+                          embedding=None, reference_mels=refs, reference_mel_lengths=torch.tensor([[60, 60]]),
+                          reference_mel_masks=torch.ones(1, 2, 60), streaming=False, finalize=True)
+    out.update(flow_tok=np_(tok), flow_refs=np_(refs), flow_out=np_(y))
+    print("flow with speaker encoder:", tuple(y.shape), float(y.std()))
+    np.savez_compressed(os.path.join(GOLD, "spk.npz"), **out)
+
+
+def build_flow_spk():
+    from cosyvoice.flow.flow import CausalMaskedDiffWithXvec
+    base = build_flow()
+    return CausalMaskedDiffWithXvec(input_size=512, output_size=80, spk_embed_dim=192, output_type="mel", vocab_size=6561,
+                                    input_frame_rate=25, only_mask_loss=True, token_latent_ratio=2, pre_lookahead_len=3,
+                                    use_speaker_encoder=True, freeze_speaker_encoder=True, encoder=base.encoder,
+                                    decoder=base.decoder).eval()
+
+
 def gen_sampler():
     R.import_cosyvoice()
     from cosyvoice.utils.common import ras_sampling, nucleus_sampling, random_sampling
@@ -222,8 +266,8 @@ def gen_sampler():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["dac", "flow", "llm", "sampler"]
+    which = sys.argv[1:] or ["dac", "flow", "llm", "sampler", "spk"]
     for w in which:
         t0 = time.time()
-        {"dac": gen_dac, "flow": gen_flow, "llm": gen_llm, "sampler": gen_sampler}[w]()
+        {"dac": gen_dac, "flow": gen_flow, "llm": gen_llm, "sampler": gen_sampler, "spk": gen_spk}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f}s")

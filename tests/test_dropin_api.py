@@ -196,3 +196,47 @@ def test_cosyvoice2model_tts_streaming_and_offline(golden_dir):
     n_str = sum(c["tts_speech"].shape[1] for c in chunks)
     assert len(chunks) >= 2 and n_str == n_off                        # same tokens (same Philox stream) -> same length
     assert all(torch.isfinite(c["tts_speech"]).all() for c in chunks)
+
+
+def test_speaker_encoder_state_dict_keys(golden_dir):
+    """use_speaker_encoder=True (speech/config.yaml:16): the flow and the LM carry `speaker_encoder.*` like the reference."""
+    from cosyvoice.llm.llm import LearnableSpeakerEncoder
+    enc = LearnableSpeakerEncoder()
+    got = {"speaker_encoder." + k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert got == _ref(golden_dir, "spk")
+    from cosyvoice.flow.flow import CausalMaskedDiffWithXvec
+    base = build_flow()
+    flow = CausalMaskedDiffWithXvec(input_size=512, output_size=80, spk_embed_dim=192, vocab_size=6561, input_frame_rate=25,
+                                    token_latent_ratio=2, pre_lookahead_len=3, use_speaker_encoder=True,
+                                    freeze_speaker_encoder=True, encoder=base.encoder, decoder=base.decoder)
+    assert {k: tuple(v.shape) for k, v in flow.state_dict().items()} == _ref(golden_dir, "flow_spk")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol_e,tol_f", [(0, 2e-5, 1e-3), (1, 2e-2, 0.3)])
+def test_speaker_encoder_and_flow_with_reference_mels(golden_dir, dt, tol_e, tol_f):
+    import numpy as np
+    from cosyvoice.flow.flow import CausalMaskedDiffWithXvec
+    from cosyvoice.llm.llm import LearnableSpeakerEncoder
+    from oracle import weights as W
+    g = np.load(os.path.join(golden_dir, "spk.npz"))
+    enc = LearnableSpeakerEncoder()
+    syn = W.synth_state_dict(_ref(golden_dir, "spk"), 7)
+    enc.load_state_dict({k[len("speaker_encoder."):]: v for k, v in syn.items()}, strict=True)
+    enc.to("cuda").float_parity(dt == 0)
+    for T in (37, 150):
+        e = enc(torch.from_numpy(g[f"mel_T{T}"]).cuda())
+        assert (e.cpu() - torch.from_numpy(g[f"emb_T{T}"])).abs().max().item() < tol_e
+    base = build_flow()
+    flow = CausalMaskedDiffWithXvec(input_size=512, output_size=80, spk_embed_dim=192, vocab_size=6561, input_frame_rate=25,
+                                    token_latent_ratio=2, pre_lookahead_len=3, use_speaker_encoder=True,
+                                    freeze_speaker_encoder=True, encoder=base.encoder, decoder=base.decoder)
+    flow.load_state_dict(W.synth_state_dict(_ref(golden_dir, "flow_spk"), 7), strict=True)
+    flow.to("cuda").float_parity(dt == 0)
+    tok = torch.from_numpy(g["flow_tok"]).cuda()
+    z = torch.zeros(1, 0, dtype=torch.long).cuda()
+    y, _ = flow.inference(token=tok, token_len=torch.tensor([20]).cuda(), prompt_token=z, prompt_token_len=torch.tensor([0]).cuda(),
+                          prompt_feat=torch.zeros(1, 0, 80).cuda(), prompt_feat_len=torch.tensor([0]).cuda(), embedding=None,
+                          reference_mels=torch.from_numpy(g["flow_refs"]).cuda(), reference_mel_masks=torch.ones(1, 2, 60).cuda(),
+                          streaming=False, finalize=True)
+    assert (y.cpu() - torch.from_numpy(g["flow_out"])).abs().max().item() < tol_f

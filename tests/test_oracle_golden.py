@@ -131,3 +131,17 @@ def test_multinomial_is_exponential_race():
         a = int(p.multinomial(1, replacement=True))
         torch.manual_seed(s)
         assert OLLM.multinomial_e(p, OLLM.torch_noise(0, n)) == a
+
+
+def test_speaker_encoder_matches_reference(golden_dir):
+    """LearnableSpeakerEncoder and flow.inference with reference mels (use_speaker_encoder=True)."""
+    from oracle import spk as OSPK
+    g = _load(golden_dir, "spk.npz")
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_spk.json")), SEED)
+    for T in (37, 150):
+        e = OSPK.speaker_encoder(sd, torch.from_numpy(g[f"mel_T{T}"]))
+        assert (e - torch.from_numpy(g[f"emb_T{T}"])).abs().max() < 2e-5
+    fsd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_flow_spk.json")), SEED)
+    emb = OSPK.reference_embedding(fsd, torch.from_numpy(g["flow_refs"]))
+    y = OFLOW.flow_inference(fsd, torch.from_numpy(g["flow_tok"]), torch.zeros(1, 0, dtype=torch.long), torch.zeros(1, 0, 80), emb)
+    assert (y - torch.from_numpy(g["flow_out"])).abs().max() < 1e-4
