@@ -149,3 +149,21 @@ def test_compaction_to_smaller_batch_preserves_tokens(llm_sd):
         if out[b] is None:
             out[b] = eng.out_tokens[s_, :n[s_]].tolist()
     assert out == ref
+
+
+def test_inference_spk_lm_input_matches_oracle(llm_sd):
+    """llm.py:634-665: [sos | spk_embed_affine(normalize(e)) | text | task_id | prompt speech] (fp32 build)."""
+    from mmx import ops
+    from mmx.llm import LlmEngine
+    from oracle import spk as OSPK
+    import torch.nn.functional as F
+    eng = LlmEngine(llm_sd, dtype=0, max_batch=1, max_ctx=128)
+    g = torch.Generator().manual_seed(6)
+    text, ptext = torch.randint(0, 151936, (1, 7), generator=g), torch.randint(0, 151936, (1, 3), generator=g)
+    pspeech = torch.randint(0, 6561, (1, 4), generator=g)
+    e = torch.randn(1, 192, generator=g)
+    w, b = llm_sd["spk_embed_affine_layer.weight"], llm_sd["spk_embed_affine_layer.bias"]
+    spk = eng.speaker_conditioning(ops.pack_linear(w.cuda(), 0), b.cuda().contiguous(), e.cuda())
+    x = eng.build_lm_input(text.cuda(), ptext.cuda(), pspeech.cuda(), speaker_embed=spk)
+    ref = OSPK.build_lm_input_spk(llm_sd, text, ptext, pspeech, F.linear(F.normalize(e, dim=1), w, b).unsqueeze(1))
+    assert x.shape == ref.shape[1:] and (x.cpu() - ref[0]).abs().max().item() < 1e-5
