@@ -5,6 +5,8 @@
 //                       (the flow's dominant FLOPs: SURVEY.md §8d, 57.3 of 189.5 GFLOP per call).
 #include "common.h"
 #include "../../include/mmx_hip.h"
+#include <type_traits>
+#include <utility>
 
 __device__ __forceinline__ bool key_visible(int i, int j, int Tk, const float* km, int chunk) {
     if (j >= Tk) return false;
@@ -239,27 +241,20 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
             }
         }
         const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);       // uniform per tile
-        float kmv[4][4];
-        if (km) {
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = j0 + nf * 16 + 4 * g + r;
-                    kmv[nf][r] = j < Tn ? km[j] : 0.f;
-                }
-        }
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
+        // softmax of one query fragment; MASK is a compile-time flag so interior tiles carry no compare/select code
+        auto softmax_tile = [&](auto mask_c, auto mf_c) {
+            constexpr bool MASK = decltype(mask_c)::value;
+            constexpr int mf = decltype(mf_c)::value;
             float mx = -INFINITY;
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = s[mf][nf][r] * sc2;
-                    if (need_mask) {
-                        bool vis = (j0 + nf * 16 + 4 * g + r) < lim[mf];
-                        if (km) vis = vis && kmv[nf][r] != 0.f;
+                    if constexpr (MASK) {
+                        const int j = j0 + nf * 16 + 4 * g + r;
+                        bool vis = j < lim[mf];
+                        if (km) vis = vis && (j < Tn) && km[j] != 0.f;
                         x = vis ? x : -INFINITY;
                     }
                     s[mf][nf][r] = x;
@@ -267,14 +262,28 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[mf], mx);
-            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[mf] - m_safe);   // m_run = -inf -> 0
+            // lazy rescale (cdna_hip_programming.md T13): keep the old running max while it is at most 2^6 below the
+            // new one for EVERY query of the wave; p then reaches at most 64 (fine in bf16 / fp32 sums) and the O
+            // accumulators (AGPRs: a rescale costs a read + multiply + write per value) are left alone.
+            float m_use = m_run[mf];
+            const bool grow = (mx - m_run[mf]) > 6.0f || m_run[mf] == -INFINITY;
+            if (__any(grow)) {
+                const float m_new = fmaxf(m_run[mf], mx);
+                const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[mf] - m_safe);   // m_run = -inf -> 0
+                l_run[mf] *= alpha;
+#pragma unroll
+                for (int df = 0; df < 4; ++df)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[mf][df][r] *= alpha;
+                m_run[mf] = m_new;
+                m_use = m_safe;
+            }
             float rs = 0.f;
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                float p0 = __builtin_amdgcn_exp2f(s[mf][nf][0] - m_safe), p1 = __builtin_amdgcn_exp2f(s[mf][nf][1] - m_safe);
-                float p2 = __builtin_amdgcn_exp2f(s[mf][nf][2] - m_safe), p3 = __builtin_amdgcn_exp2f(s[mf][nf][3] - m_safe);
+                float p0 = __builtin_amdgcn_exp2f(s[mf][nf][0] - m_use), p1 = __builtin_amdgcn_exp2f(s[mf][nf][1] - m_use);
+                float p2 = __builtin_amdgcn_exp2f(s[mf][nf][2] - m_use), p3 = __builtin_amdgcn_exp2f(s[mf][nf][3] - m_use);
                 rs += (p0 + p1) + (p2 + p3);
                 // 4 consecutive keys of query l16 -> one 8-byte write into the row-major [q][key] patch
                 uint2 pk;
@@ -284,12 +293,14 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
             }
             rs += __shfl_xor(rs, 16, 64);
             rs += __shfl_xor(rs, 32, 64);
-            l_run[mf] = l_run[mf] * alpha + rs;
-            m_run[mf] = m_new;
-#pragma unroll
-            for (int df = 0; df < 4; ++df)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[mf][df][r] *= alpha;
+            l_run[mf] += rs;
+        };
+        if (need_mask) {
+            softmax_tile(std::true_type{}, std::integral_constant<int, 0>{});
+            softmax_tile(std::true_type{}, std::integral_constant<int, 1>{});
+        } else {
+            softmax_tile(std::false_type{}, std::integral_constant<int, 0>{});
+            softmax_tile(std::false_type{}, std::integral_constant<int, 1>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
