@@ -241,6 +241,16 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
             }
         }
         const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);       // uniform per tile
+        bool kvis[4][4];                               // key-side visibility of this lane's 16 keys, once per tile
+        if (need_mask) {
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + nf * 16 + 4 * g + r;
+                    kvis[nf][r] = j < Tn && (!km || km[j] != 0.f);
+                }
+        }
         // softmax of one query fragment; MASK is a compile-time flag so interior tiles carry no compare/select code
         auto softmax_tile = [&](auto mask_c, auto mf_c) {
             constexpr bool MASK = decltype(mask_c)::value;
@@ -253,9 +263,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                     float x = s[mf][nf][r] * sc2;
                     if constexpr (MASK) {
                         const int j = j0 + nf * 16 + 4 * g + r;
-                        bool vis = j < lim[mf];
-                        if (km) vis = vis && (j < Tn) && km[j] != 0.f;
-                        x = vis ? x : -INFINITY;
+                        x = (j < lim[mf] && kvis[nf][r]) ? x : -INFINITY;
                     }
                     s[mf][nf][r] = x;
                     mx = fmaxf(mx, x);
