@@ -45,7 +45,7 @@ typedef struct ihipStream_t* hipStream_t;
 int mmx_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
- * Windowed GEMM:  C[b][m][n] = sum_tap sum_c A[b][m + tap*dil + row_off][c] * W[b][n][tap*cin + c]
+ * Windowed GEMM:  C[b][m][n] = sum_tap sum_c A[b][m*row_stride + tap*dil + row_off][c] * W[b][n][tap*cin + c]
  * Replaces torch Linear / Conv1d / ConvTranspose1d (+ the elementwise ops fused in its epilogue):
  *   dac-vae/model.py:107-143,237-323,342-371 (WNConv1d+LeakyReLU, Snake, WNConvTranspose1d, residual add)
  *   speech/cosyvoice/flow/decoder.py:36-85 (CausalConv1d), speech/matcha/models/components/transformer.py:243-316
@@ -65,13 +65,14 @@ typedef struct MmxGemmParams {
     void* out_act;          /* T output or NULL */
     int64_t lda, ldw, ldr, ldo_f, ldo_a;
     int64_t a_bstride, w_bstride, r_bstride, rm_bstride, of_bstride, oa_bstride;   /* per batch, in elements */
-    int64_t row_off, row_lo, row_hi;   /* A row = m + tap*dil + row_off, rows outside [row_lo,row_hi) read 0 */
+    int64_t row_off, row_lo, row_hi;   /* A row = m*row_stride + tap*dil + row_off, rows outside [row_lo,row_hi) read 0 */
     int64_t out_off, out_len;
     int32_t M, N, batch;
     int32_t ntaps, cin, dil;
     int32_t bias_mod, alpha_mod, bias_per_row;
     int32_t act, act2;
     float slope;
+    int32_t row_stride;                /* 1 for Linear / stride-1 convs; s for a stride-s Conv1d (DAC-VAE encoder) */
 } MmxGemmParams;
 int mmx_gemm_win(const MmxGemmParams* p, int dtype, hipStream_t stream);
 
@@ -142,6 +143,15 @@ int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                         int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk,
                         hipStream_t stream);
+
+/* DAC-VAE encoder head: Conv1d(1 -> C, k) + LeakyReLU (dac-vae/model.py:208 with :509-514) on a mono waveform
+ * x fp32 [B][T]; w fp32 [C][k]; out_f32 [B][T][C] (optional) and out_act T [B][T][C] = snake(v, alpha) (alpha optional). */
+int mmx_conv_cin1(const float* x, int64_t x_bs, int T, int C, int k, const float* w, const float* bias, float slope,
+                  const float* alpha, float* out_f32, void* out_act, int batch, int dtype, hipStream_t stream);
+/* VAE head (dac-vae/model.py:476-481): ml fp32 [rows][2D] = (m | logs); logs clamped to [-14, 14];
+ * z = m + noise * exp(logs).  All outputs fp32 [rows][D]. */
+int mmx_vae_sample(const float* ml, const float* noise, int64_t rows, int D, float* z, float* m, float* logs,
+                   hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DAC tail: Conv1d(C -> 1, k) + LeakyReLU(0.1) + tanh (dac-vae/model.py:364-370,509-514).

@@ -246,6 +246,83 @@ extern "C" int mmx_conv_cout1_tanh(const void* act, int64_t a_bs, int T_, int C,
     return MMX_OK;
 }
 
+// ---------------------------------------------------------------------------- DAC-VAE encoder head / VAE sampling
+// Conv1d(1 -> C, k) + LeakyReLU: thread = (sample t, 8 channels); the k+255 input samples of a block sit in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict__ x, long x_bs, int Tn, int C, int k,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, float slope,
+                                                        const float* __restrict__ alpha, float* __restrict__ outf, T* __restrict__ outa) {
+    constexpr bool PRECISE = sizeof(T) == 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);            // [TB + k - 1]
+    float* ws = xs + (256 + k - 1);                        // [C][k]
+    const int b = blockIdx.y, t0 = blockIdx.x * 256, pad = (k - 1) / 2;
+    const float* xb = x + (long)b * x_bs;
+    for (int i = threadIdx.x; i < 256 + k - 1; i += 256) {
+        long t = (long)t0 + i - pad;
+        xs[i] = (t >= 0 && t < Tn) ? xb[t] : 0.f;
+    }
+    for (int i = threadIdx.x; i < C * k; i += 256) ws[i] = w[i];
+    __syncthreads();
+    // 256 threads cover 256 samples x C channels in passes: thread -> (sample tid / (C/8) ..., 8 channels)
+    const int cg = C / 8;                                  // channel groups of 8 per sample
+    for (int item = threadIdx.x; item < 256 * cg; item += 256) {
+        const int ts = item / cg, c0 = (item % cg) * 8;
+        const int t = t0 + ts;
+        if (t >= Tn) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = bias ? bias[c0 + e] : 0.f;
+            for (int j = 0; j < k; ++j) a += ws[(c0 + e) * k + j] * xs[ts + j];
+            a = a > 0.f ? a : a * slope;
+            v[e] = a;
+        }
+        const long o = ((long)b * Tn + t) * C + c0;
+        if (outf) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) outf[o + e] = v[e];
+        }
+        if (outa) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) outa[o + e] = Cvt<T>::from_f(alpha ? snake_apply<PRECISE>(v[e], alpha[c0 + e]) : v[e]);
+        }
+    }
+}
+extern "C" int mmx_conv_cin1(const float* x, int64_t x_bs, int T_, int C, int k, const float* w, const float* bias, float slope,
+                             const float* alpha, float* out_f32, void* out_act, int batch, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(x && w && (out_f32 || out_act) && T_ > 0 && C > 0 && C % 8 == 0 && k > 0 && (k & 1) && batch > 0);
+    dim3 grid((T_ + 255) / 256, batch);
+    size_t lds = (size_t)(256 + k - 1 + C * k) * 4;
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(conv_cin1_kernel<bf16_t>, grid, dim3(256), lds, stream, x, x_bs, T_, C, k, w, bias, slope, alpha, out_f32, (bf16_t*)out_act);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(conv_cin1_kernel<float>, grid, dim3(256), lds, stream, x, x_bs, T_, C, k, w, bias, slope, alpha, out_f32, (float*)out_act);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+__global__ void vae_sample_kernel(const float* __restrict__ ml, const float* __restrict__ noise, long n, int D,
+                                  float* __restrict__ z, float* __restrict__ m, float* __restrict__ logs) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long r = i / D;
+    const int c = i % D;
+    const float mu = ml[r * 2 * D + c];
+    float lg = ml[r * 2 * D + D + c];
+    lg = fminf(fmaxf(lg, -14.f), 14.f);
+    m[i] = mu;
+    logs[i] = lg;
+    z[i] = mu + noise[i] * expf(lg);
+}
+extern "C" int mmx_vae_sample(const float* ml, const float* noise, int64_t rows, int D, float* z, float* m, float* logs,
+                              hipStream_t stream) {
+    MMX_CHECK_ARG(ml && noise && z && m && logs && rows > 0 && D > 0);
+    const long n = rows * D;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ml, noise, n, D, z, m, logs);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
 // ---------------------------------------------------------------------------- SwiGLU (prefill)
 template <typename T>
 __global__ void swiglu_kernel(const float* __restrict__ gu, long ldgu, int I, T* __restrict__ out, long ldo) {

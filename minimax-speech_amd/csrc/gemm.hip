@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         const int m = m0 + r;
         a_tap[i] = k / p.cin;
         a_c[i] = k % p.cin;
-        a_srow[i] = (long)m + (long)a_tap[i] * p.dil + p.row_off;
+        a_srow[i] = (long)m * p.row_stride + (long)a_tap[i] * p.dil + p.row_off;
         a_ptr[i] = A + a_srow[i] * p.lda + a_c[i];
         a_mok[i] = (m < p.M) && (A_FULL || id < BM * CPR);
     }
@@ -336,7 +336,7 @@ static int launch_T(const GemmParams& p, hipStream_t s) {
     MMX_CHECK_ARG(p.cin % CH == 0 && p.lda % CH == 0 && p.ldw % CH == 0);
     MMX_CHECK_ARG(p.a_bstride % CH == 0 && p.w_bstride % CH == 0);
     MMX_CHECK_ARG(p.ldw >= ((p.ntaps * p.cin + 31) / 32) * 32);
-    MMX_CHECK_ARG(p.bias_mod > 0 && p.alpha_mod > 0);
+    MMX_CHECK_ARG(p.bias_mod > 0 && p.alpha_mod > 0 && p.row_stride >= 1);
     MMX_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0);
     MMX_CHECK_ARG(p.out_f32 || p.out_act);
     MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use

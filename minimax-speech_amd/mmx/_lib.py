@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")
 
 SYMBOLS = [
     "mmx_abi_version", "mmx_gemm_win", "mmx_rownorm", "mmx_groupnorm", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
-    "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_conv_cout1_tanh",
+    "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_conv_cout1_tanh", "mmx_conv_cin1", "mmx_vae_sample",
     "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_decode_attn", "mmx_swiglu", "mmx_sample_step",
 ]
 
@@ -31,7 +31,7 @@ class GemmParams(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("batch", C.c_int32),
         ("ntaps", C.c_int32), ("cin", C.c_int32), ("dil", C.c_int32),
         ("bias_mod", C.c_int32), ("alpha_mod", C.c_int32), ("bias_per_row", C.c_int32),
-        ("act", C.c_int32), ("act2", C.c_int32), ("slope", C.c_float),
+        ("act", C.c_int32), ("act2", C.c_int32), ("slope", C.c_float), ("row_stride", C.c_int32),
     ]
 
 
@@ -91,6 +91,7 @@ def gemm_params(**kw):
     p.row_lo = 0
     p.out_len = 1 << 62
     p.slope = 0.1
+    p.row_stride = 1
     for k, v in kw.items():
         if k in ("A", "W", "bias", "residual", "rowmask", "alpha", "out_f32", "out_act"):
             v = None if v is None else (v if isinstance(v, int) else v.data_ptr())

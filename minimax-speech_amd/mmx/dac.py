@@ -1,4 +1,5 @@
-"""DAC-VAE decoder engine: latents [B, D, T] -> 24 kHz waveform [B, 1, T*hop] on libmmx_hip kernels.
+"""DAC-VAE engines on libmmx_hip kernels: decoder (latents [B, D, T] -> 24 kHz waveform [B, 1, T*hop]) and encoder
+(waveform [B, 1, T] -> (z, mu, logs) [B, D, T/hop]; SURVEY.md §8f row 3, the prompt-audio side of the path).
 
 Reference op sequence: dac-vae/model.py:485-488 (DACVAE.decode), :326-379 (Decoder), :237-323 (DecoderBlock),
 :107-143 (ResidualUnit), :509-514 (every Conv1d is followed by LeakyReLU(0.1)), layers.py:18-24 (Snake).
@@ -109,3 +110,122 @@ class DacDecoderEngine:
         ops.conv_cout1_tanh(a, self.w_final, self.b_final, wav, T=T, C_=self.blocks[-1]["cout"], k=self.k_final,
                             batch=B, dtype=dt, use_tanh=self.use_tanh)
         return wav
+
+
+class DacEncoderEngine:
+    """DACVAE.encode (dac-vae/model.py:469-483): Encoder (:195-234) -> leaky_relu(0.01) -> en_conv_post -> (m | logs) -> z.
+
+    Same mapping as the decoder: one windowed-GEMM launch per Conv1d, the strided down-sampling convs
+    (EncoderBlock, :182-188: k=2s, stride s, pad ceil(s/2)) through MmxGemmParams.row_stride; the d_in=1 head is its
+    own kernel (K=7 is no GEMM).  31 GEMM launches + head + VAE-sampling kernel + 3 layout copies."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], rates: List[int], dtype=BF16, device="cuda"):
+        self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.rates = list(rates)
+        self.hop = int(math.prod(rates))
+        f = lambda k: sd[k].detach().to(self.dev, torch.float32)
+        wn = lambda p: ops.fold_weight_norm(f(p + ".weight_g"), f(p + ".weight_v"))
+        bias = lambda p: f(p + ".bias").contiguous()
+        alpha = lambda k: f(k).reshape(-1).contiguous()
+        p = "encoder.block"
+        w0 = wn(p + ".0.0")                                     # [C0, 1, 7]
+        assert w0.shape[1] == 1, "d_in != 1 is outside the hot path (configx2.yml: d_in 1)"
+        self.C0, self.k0 = w0.shape[0], w0.shape[2]
+        self.w0 = w0.reshape(self.C0, self.k0).contiguous()
+        self.b0 = bias(p + ".0.0")
+        self.blocks = []
+        c = self.C0
+        for i, s in enumerate(rates):
+            q = f"{p}.{1 + i}.block"
+            blk = dict(stride=s, c=c, rus=[], alpha_out=alpha(q + ".3.alpha"), wd=ops.pack_conv1d(wn(q + ".4.0"), dtype),
+                       bd=bias(q + ".4.0"))
+            for j, d in enumerate((1, 3, 9)):
+                r = f"{q}.{j}.block"
+                blk["rus"].append(dict(dil=d, a0=alpha(r + ".0.alpha"), w7=ops.pack_conv1d(wn(r + ".1.0"), dtype),
+                                       b7=bias(r + ".1.0"), a2=alpha(r + ".2.alpha"),
+                                       w1=ops.pack_conv1d(wn(r + ".3.0"), dtype), b1=bias(r + ".3.0")))
+            self.blocks.append(blk)
+            c *= 2
+        n = len(rates)
+        self.C_last = c
+        self.alpha_final = alpha(f"{p}.{n + 1}.alpha")
+        self.w_final = ops.pack_conv1d(wn(f"{p}.{n + 2}.0"), dtype)   # [D, 3*C]
+        self.b_final = bias(f"{p}.{n + 2}.0")
+        self.D = self.w_final.shape[0]
+        self.w_post = ops.pack_conv1d(wn("en_conv_post.0"), dtype)    # [2D, D]
+        self.b_post = bias("en_conv_post.0")
+
+    @staticmethod
+    def _down(T, s):
+        """Output length of Conv1d(k=2s, stride=s, padding=ceil(s/2)) (model.py:182-188)."""
+        return (T + 2 * math.ceil(s / 2) - 2 * s) // s + 1
+
+    def frames(self, T: int) -> int:
+        """Latent frames for T input samples."""
+        for s in self.rates:
+            T = self._down(T, s)
+            if T < 1:
+                return 0
+        return T
+
+    @torch.no_grad()
+    def encode(self, audio: torch.Tensor, noise: torch.Tensor = None, generator: torch.Generator = None):
+        """audio [B, 1, T] fp32 cuda -> (z, mu, logs), each [B, D, T'] fp32; T' = T/hop for a hop multiple
+        (DACVAE.preprocess), else each stride-s conv floors as torch's Conv1d does (extract_dac_latents.py:20-36
+        encodes unpadded audio).  `noise` [B, D, T'] stands for the reference's torch.randn_like(m); drawn on the
+        device when absent."""
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3 and audio.shape[1] == 1
+        B, _, T = audio.shape
+        if self.frames(T) < 1:
+            raise ValueError(f"audio of {T} samples is shorter than one latent frame")
+        dt, tdt, dev = self.dtype, self.tdt, self.dev
+        new = lambda t, c, d=None: torch.empty(B, t, c, dtype=(d or tdt), device=dev)
+        audio = audio.contiguous()
+        x = new(T, self.C0, torch.float32)
+        a = new(T, self.C0)
+        ops.conv_cin1(audio, self.w0, self.b0, T=T, C_=self.C0, k=self.k0, batch=B, dtype=dt,
+                      alpha=self.blocks[0]["rus"][0]["a0"], out_f32=x, out_act=a)
+        for bi, blk in enumerate(self.blocks):
+            s, c = blk["stride"], blk["c"]
+            for j, ru in enumerate(blk["rus"]):
+                d = ru["dil"]
+                hmid = new(T, c)
+                ops.conv1d(a, ru["w7"], T=T, Cin=c, k=7, dil=d, pad_left=3 * d, dtype=dt, batch=B, bias=ru["b7"],
+                           act="lrelu", alpha=ru["a2"], out_act=hmid)
+                last = j == 2
+                nxt = blk["alpha_out"] if last else blk["rus"][j + 1]["a0"]
+                x2 = None if last else new(T, c, torch.float32)
+                a3 = new(T, c)
+                ops.conv1d(hmid, ru["w1"], T=T, Cin=c, k=1, dtype=dt, batch=B, bias=ru["b1"], act="lrelu",
+                           residual=x, alpha=nxt, out_f32=x2, out_act=a3)
+                x, a = x2, a3
+            T2 = self._down(T, s)
+            nxt = self.blocks[bi + 1]["rus"][0]["a0"] if bi + 1 < len(self.blocks) else self.alpha_final
+            last_blk = bi + 1 == len(self.blocks)
+            x = None if last_blk else new(T2, 2 * c, torch.float32)
+            a2 = new(T2, 2 * c)
+            ops.conv1d(a, blk["wd"], T=T, Cin=c, k=2 * s, pad_left=math.ceil(s / 2), stride=s, T_out=T2, dtype=dt,
+                       batch=B, bias=blk["bd"], act="lrelu", alpha=nxt, out_f32=x, out_act=a2)
+            T, a = T2, a2
+        # conv k3 + LeakyReLU(0.1), then F.leaky_relu(0.01) (model.py:475): one LeakyReLU of slope 0.1*0.01
+        h = new(T, self.D)
+        ops.conv1d(a, self.w_final, T=T, Cin=self.C_last, k=3, pad_left=1, dtype=dt, batch=B, bias=self.b_final,
+                   act="lrelu", slope=0.1 * 0.01, out_act=h)
+        ml = new(T, 2 * self.D, torch.float32)
+        ops.conv1d(h, self.w_post, T=T, Cin=self.D, k=1, dtype=dt, batch=B, bias=self.b_post, act="lrelu", out_f32=ml)
+        D = self.D
+        if noise is None:
+            noise_t = torch.randn(B, T, D, dtype=torch.float32, device=dev, generator=generator)
+        else:
+            assert noise.shape == (B, D, T)
+            noise_t = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+            noise = noise.to(dev, torch.float32).contiguous()
+            ops.copy2d(noise, F32, D * T, 1, T, noise_t, F32, T * D, D, 1, rows=T, cols=D, batch=B)
+        zt, mt, lt = (torch.empty(B, T, D, dtype=torch.float32, device=dev) for _ in range(3))
+        ops.vae_sample(ml, noise_t, zt, mt, lt, rows=B * T, D=D)
+        outs = []
+        for src in (zt, mt, lt):                               # -> the reference's channels-first [B, D, T]
+            o = torch.empty(B, D, T, dtype=torch.float32, device=dev)
+            ops.copy2d(src, F32, T * D, D, 1, o, F32, D * T, 1, T, rows=T, cols=D, batch=B)
+            outs.append(o)
+        return tuple(outs)

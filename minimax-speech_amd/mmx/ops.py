@@ -53,7 +53,7 @@ def fold_weight_norm(g, v):
 def gemm(A, W, M, N, *, dtype, lda=None, cin=None, ntaps=1, dil=1, row_off=0, row_lo=0, row_hi=None, batch=1,
          a_bstride=0, w_bstride=0, bias=None, bias_mod=None, bias_per_row=False, act="none", act2="none", slope=0.1,
          residual=None, ldr=0, r_bstride=0, rowmask=None, rm_bstride=0, alpha=None, alpha_mod=None,
-         out_f32=None, ldo_f=0, of_bstride=0, out_act=None, ldo_a=0, oa_bstride=0, out_off=0, out_len=None):
+         out_f32=None, ldo_f=0, of_bstride=0, out_act=None, ldo_a=0, oa_bstride=0, out_off=0, out_len=None, row_stride=1):
     """Launches mmx_gemm_win. A/W/out_* may be tensors or raw device addresses (ints)."""
     ldw = W.shape[-1] if hasattr(W, "shape") else None
     assert ldw is not None
@@ -64,7 +64,7 @@ def gemm(A, W, M, N, *, dtype, lda=None, cin=None, ntaps=1, dil=1, row_off=0, ro
                       row_hi=(row_hi if row_hi is not None else (1 << 40)), out_off=out_off,
                       out_len=(out_len if out_len is not None else (1 << 62)), M=M, N=N, batch=batch,
                       ntaps=ntaps, cin=cin, dil=dil, bias_mod=(bias_mod or N), alpha_mod=(alpha_mod or N),
-                      bias_per_row=int(bias_per_row), act=ACT[act], act2=ACT[act2], slope=slope)
+                      bias_per_row=int(bias_per_row), act=ACT[act], act2=ACT[act2], slope=slope, row_stride=row_stride)
     L.gemm_win(p, dtype)
 
 
@@ -78,11 +78,11 @@ def linear(x, Wp, K, *, dtype, bias=None, act="none", act2="none", residual=None
 
 
 def conv1d(x, Wp, *, T, Cin, k, dtype, dil=1, pad_left=0, batch=1, bias=None, act="none", slope=0.1, residual=None,
-           rowmask=None, alpha=None, out_f32=None, out_act=None, T_out=None, act2="none"):
-    """Stride-1 Conv1d over time-major x [B, T, Cin] -> [B, T_out, Cout]; zero padding is virtual."""
+           rowmask=None, alpha=None, out_f32=None, out_act=None, T_out=None, act2="none", stride=1):
+    """Conv1d over time-major x [B, T, Cin] -> [B, T_out, Cout]; zero padding is virtual; stride via row_stride."""
     Cout = Wp.shape[0]
     T_out = T if T_out is None else T_out
-    gemm(x, Wp, T_out, Cout, dtype=dtype, lda=Cin, cin=Cin, ntaps=k, dil=dil, row_off=-pad_left, row_lo=0, row_hi=T,
+    gemm(x, Wp, T_out, Cout, dtype=dtype, lda=Cin, cin=Cin, ntaps=k, dil=dil, row_off=-pad_left, row_lo=0, row_hi=T, row_stride=stride,
          batch=batch, a_bstride=T * Cin, bias=bias, act=act, act2=act2, slope=slope,
          residual=residual, ldr=Cout, r_bstride=T_out * Cout, rowmask=rowmask, rm_bstride=T_out,
          alpha=alpha, out_f32=out_f32, ldo_f=Cout, of_bstride=T_out * Cout,
@@ -139,6 +139,15 @@ def sinusoidal_emb(t, out, *, dim, dtype, scale=1000.0):
 def cfg_euler(x, d_cond, d_uncond, cfg, dt, n):
     check(load().mmx_cfg_euler(_p(x), _p(d_cond), _p(d_uncond), C.c_float(cfg), C.c_float(dt), i64(n), stream()),
           "mmx_cfg_euler")
+
+
+def conv_cin1(x, w, bias, *, T, C_, k, batch, dtype, slope=0.1, alpha=None, out_f32=None, out_act=None):
+    check(load().mmx_conv_cin1(_p(x), i64(T), T, C_, k, _p(w), _p(bias), C.c_float(slope), _p(alpha), _p(out_f32), _p(out_act),
+                               batch, dtype, stream()), "mmx_conv_cin1")
+
+
+def vae_sample(ml, noise, z, m, logs, *, rows, D):
+    check(load().mmx_vae_sample(_p(ml), _p(noise), i64(rows), D, _p(z), _p(m), _p(logs), stream()), "mmx_vae_sample")
 
 
 def conv_cout1_tanh(act, w, bias, out, *, T, C_, k, batch, dtype, slope=0.1, use_tanh=True):

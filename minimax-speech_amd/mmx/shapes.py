@@ -41,6 +41,35 @@ def dac_decoder_manifest(latent_dim=80, decoder_dim=1536, rates=(5, 4, 4, 3, 2),
     return m
 
 
+def dac_encoder_manifest(latent_dim=80, encoder_dim=64, rates=(2, 3, 4, 4, 5), d_in=1) -> Manifest:
+    """dac-vae/model.py: Encoder (:195-234) + EncoderBlock (:146-192) + en_conv_post (:459-461)."""
+    m: Manifest = {}
+
+    def wn(p, cout, cin, k):
+        m[p + ".bias"] = (cout,)
+        m[p + ".weight_g"] = (cout, 1, 1)
+        m[p + ".weight_v"] = (cout, cin, k)
+
+    wn("encoder.block.0.0", encoder_dim, d_in, 7)
+    c = encoder_dim
+    for i, s in enumerate(rates):
+        q = f"encoder.block.{1 + i}.block"
+        for j in range(3):
+            r = f"{q}.{j}.block"
+            m[r + ".0.alpha"] = (1, c, 1)
+            wn(r + ".1.0", c, c, 7)
+            m[r + ".2.alpha"] = (1, c, 1)
+            wn(r + ".3.0", c, c, 1)
+        m[q + ".3.alpha"] = (1, c, 1)
+        wn(q + ".4.0", 2 * c, c, 2 * s)
+        c *= 2
+    n = len(rates)
+    m[f"encoder.block.{n + 1}.alpha"] = (1, c, 1)
+    wn(f"encoder.block.{n + 2}.0", latent_dim, c, 3)
+    wn("en_conv_post.0", 2 * latent_dim, latent_dim, 1)
+    return m
+
+
 def speaker_encoder_manifest(prefix="speaker_encoder", mel_dim=80, model_dim=512, output_dim=192, num_blocks=6) -> Manifest:
     """LearnableSpeakerEncoder (speech/cosyvoice/llm/llm.py:34-63) with AttentionBlock (arch_util.py:87-115)."""
     m: Manifest = {f"{prefix}.init.weight": (model_dim, mel_dim, 1), f"{prefix}.init.bias": (model_dim,)}

@@ -13,6 +13,11 @@ Follows (reference, read-only):
   dac-vae/layers.py:13-14    WNConvTranspose1d (no activation)
   dac-vae/layers.py:18-24    snake(x, a) = x + (a + 1e-9)^-1 * sin(a x)^2
   torch weight_norm (dim=0): w = g * v / ||v||_{dims 1..}
+and the encoder side:
+  dac-vae/model.py:469-483   DACVAE.encode  = Encoder -> F.leaky_relu(0.01) -> en_conv_post -> (m | logs) -> z
+  dac-vae/model.py:195-234   Encoder        (conv k7, 5 EncoderBlocks, Snake, conv k3)
+  dac-vae/model.py:146-192   EncoderBlock   (3 ResidualUnits dil 1/3/9 at dim/2, Snake, Conv1d k=2s stride s pad ceil(s/2))
+  dac-vae/model.py:457-467   DACVAE.preprocess (right-pad to a hop multiple)
 """
 import math
 
@@ -85,3 +90,50 @@ def decode(sd, z, rates, use_tanh=True):
     """DACVAE.decode (model.py:485-488): z [B, D_lat, T] -> waveform [B, d_out, T*hop]."""
     z = wnconv1d_act(sd, "de_conv_pre", z)
     return decoder_forward(sd, z, rates, "decoder", use_tanh)
+
+
+def wnconv1d_strided_act(sd, p, x, stride, padding):
+    w, b = _wn(sd, p + ".0")
+    return F.leaky_relu(F.conv1d(x, w, b, stride=stride, padding=padding), LRELU)
+
+
+def encoder_block(sd, p, x, stride):
+    # model.py:159-192
+    for i, d in enumerate((1, 3, 9)):
+        x = residual_unit(sd, f"{p}.block.{i}", x, d)
+    x = snake(x, sd[p + ".block.3.alpha"])
+    return wnconv1d_strided_act(sd, p + ".block.4", x, stride, math.ceil(stride / 2))
+
+
+def encoder_forward(sd, x, rates, prefix="encoder", return_stages=False):
+    """Encoder.forward (model.py:233-234). `sd` holds keys '<prefix>.block.N...'; x [B, d_in, T]."""
+    stages = []
+    p = prefix + ".block"
+    x = wnconv1d_act(sd, p + ".0", x, padding=3)
+    stages.append(x)
+    for i, s in enumerate(rates):
+        x = encoder_block(sd, f"{p}.{1 + i}", x, s)
+        stages.append(x)
+    n = len(rates)
+    x = snake(x, sd[f"{p}.{n + 1}.alpha"])
+    x = wnconv1d_act(sd, f"{p}.{n + 2}", x, padding=1)
+    return (x, stages) if return_stages else x
+
+
+def preprocess(audio, hop):
+    """DACVAE.preprocess (model.py:457-467): zero right-pad to a multiple of the hop length."""
+    length = audio.shape[-1]
+    return F.pad(audio, (0, math.ceil(length / hop) * hop - length))
+
+
+def encode(sd, audio, rates, noise):
+    """DACVAE.encode (model.py:469-483): audio [B, d_in, T] -> (z, m, logs) each [B, D_lat, T/hop].
+    `noise` stands for the reference's torch.randn_like(m) draw."""
+    x = encoder_forward(sd, audio, rates, "encoder")
+    x = F.leaky_relu(x)                                   # default slope 0.01 (model.py:475)
+    x = wnconv1d_act(sd, "en_conv_post", x)
+    lat = x.shape[1] // 2
+    m, logs = torch.split(x, lat, dim=1)
+    logs = torch.clamp(logs, min=-14.0, max=14.0)
+    z = m + noise * torch.exp(logs)
+    return z, m, logs

@@ -5,9 +5,10 @@ Generates the golden vectors under tests/golden/ by importing the reference's ow
 oracle/weights.py into them, and recording inputs + outputs.  Only data is written: no reference source
 or bytecode enters the repo (sys.dont_write_bytecode is set by ref_shims).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [dac] [flow] [llm] [sampler]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [dac] [dacenc] [flow] [llm] [sampler] [spk]
 """
 import json
+import math
 import os
 import sys
 import tempfile
@@ -62,6 +63,59 @@ def gen_dac():
             if i < 3:
                 out[f"stage{i}_T8"] = np_(h)
         np.savez_compressed(os.path.join(GOLD, f"dac{lat}.npz"), **out)
+
+
+def gen_dac_enc():
+    """DACVAE.encode / forward goldens."""
+    import contextlib
+    import io
+    m = R.import_dac()
+    lat = 80
+    torch.manual_seed(0)
+    d = m.DACVAE(encoder_dim=64, encoder_rates=[2, 3, 4, 4, 5], latent_dim=lat, decoder_dim=1536,
+                 decoder_rates=[5, 4, 4, 3, 2], sample_rate=24000, d_in=1, d_out=1, weight_init="xavier",
+                 activation="snake", gain=1.0).eval()
+    full = d.state_dict()
+    sd = {k: v for k, v in full.items() if k.startswith("encoder.") or k.startswith("en_conv_post.")}
+    W.save_manifest(sd, os.path.join(GOLD, "manifest_dacenc.json"))
+    syn = W.synth_state_dict({k: v.shape for k, v in full.items()}, SEED)
+    d.load_state_dict(syn, strict=True)
+    out = {}
+    for n in (4800, 11000):                                # 10 and ~23 latent frames; 11000 is not a hop multiple
+        g = torch.Generator().manual_seed(200 + n)
+        t = torch.arange(n) / 24000.0
+        wav = (0.3 * torch.sin(2 * math.pi * 220 * t) + 0.1 * torch.randn(n, generator=g)).reshape(1, 1, n)
+        x = d.preprocess(wav, 24000)
+        with contextlib.redirect_stdout(io.StringIO()):    # encode() prints shapes
+            torch.manual_seed(300 + n)
+            z, mu, logs = d.encode(x)
+            torch.manual_seed(300 + n)
+            noise = torch.randn_like(mu)                   # the draw encode() made
+            torch.manual_seed(300 + n)
+            fw = d(wav, 24000)
+        out[f"wav_{n}"] = np_(wav)
+        out[f"noise_{n}"] = np_(noise)
+        out[f"z_{n}"], out[f"mu_{n}"], out[f"logs_{n}"] = np_(z), np_(mu), np_(logs)
+        out[f"recon_{n}"] = np_(fw["audio"])
+        if n % 480:                                        # extract_dac_latents.py:20-36 encodes WITHOUT padding
+            with contextlib.redirect_stdout(io.StringIO()):
+                torch.manual_seed(400 + n)
+                zr, mur, logsr = d.encode(torch.clamp(wav, -1.0, 1.0), 24000)
+                torch.manual_seed(400 + n)
+                out[f"noise_raw_{n}"] = np_(torch.randn_like(mur))
+            out[f"z_raw_{n}"], out[f"mu_raw_{n}"], out[f"logs_raw_{n}"] = np_(zr), np_(mur), np_(logsr)
+            print(f"   unpadded: z {tuple(zr.shape)}")
+        assert torch.equal(fw["z"], z)
+        print(f"dacenc n={n}: z {tuple(z.shape)} mu std {mu.std():.3f} logs [{logs.min():.2f},{logs.max():.2f}] "
+              f"recon absmax {fw['audio'].abs().max():.3f}")
+    h = d.preprocess(torch.from_numpy(out["wav_4800"]), 24000)
+    for i, layer in enumerate(d.encoder.block):
+        h = layer(h)
+        if i < 7:
+            print(f"   stage{i}: {tuple(h.shape)} std {h.std():.3f}")
+        if i in (0, 1, 5):
+            out[f"stage{i}_4800"] = np_(h[..., :160])      # leading frames only: keeps the fixture small
+    np.savez_compressed(os.path.join(GOLD, "dacenc.npz"), **out)
 
 
 def build_flow():
@@ -266,8 +320,8 @@ def gen_sampler():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["dac", "flow", "llm", "sampler", "spk"]
+    which = sys.argv[1:] or ["dac", "dacenc", "flow", "llm", "sampler", "spk"]
     for w in which:
         t0 = time.time()
-        {"dac": gen_dac, "flow": gen_flow, "llm": gen_llm, "sampler": gen_sampler, "spk": gen_spk}[w]()
+        {"dac": gen_dac, "dacenc": gen_dac_enc, "flow": gen_flow, "llm": gen_llm, "sampler": gen_sampler, "spk": gen_spk}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f}s")

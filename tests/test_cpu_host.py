@@ -46,6 +46,7 @@ def test_gemm_params_struct_matches_header_layout():
 
 
 @pytest.mark.parametrize("name,fn", [("dac80", lambda s: s.dac_decoder_manifest(80)), ("dac128", lambda s: s.dac_decoder_manifest(128)),
+                                     ("dacenc", lambda s: s.dac_encoder_manifest(80)),
                                      ("flow", lambda s: s.flow_manifest()), ("llm", lambda s: s.llm_manifest())])
 def test_manifests_equal_reference_state_dicts(golden_dir, name, fn):
     from mmx import shapes

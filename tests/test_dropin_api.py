@@ -84,11 +84,17 @@ def test_llm_state_dict_keys_match_reference(golden_dir):
 def test_dac_state_dict_keys_match_reference(golden_dir, lat):
     dac = build_dac(lat)
     got = {k: tuple(v.shape) for k, v in dac.state_dict().items()}
-    assert got == _ref(golden_dir, f"dac{lat}")
-    # a reference checkpoint also carries encoder.* / en_conv_post.*: accepted, ignored
-    sd = dict(dac.state_dict())
-    sd["encoder.block.0.0.weight_g"] = torch.zeros(3)
-    dac.load_state_dict(sd, strict=True)
+    # the whole generator state dict of the reference: decoder + de_conv_pre + encoder + en_conv_post
+    dec = {k: v for k, v in got.items() if k.startswith(("decoder.", "de_conv_pre."))}
+    assert dec == _ref(golden_dir, f"dac{lat}")
+    if lat == 80:
+        enc = {k: v for k, v in got.items() if k.startswith(("encoder.", "en_conv_post."))}
+        assert enc == _ref(golden_dir, "dacenc")
+    assert set(got) == {k for k in got if k.startswith(("decoder.", "de_conv_pre.", "encoder.", "en_conv_post."))}
+    dac.load_state_dict(dict(dac.state_dict()), strict=True)
+    assert dac.encoder.enc_dim == 2048 and dac.hop_length == 480
+    x = dac.preprocess(torch.zeros(1, 1, 1000), 24000)
+    assert x.shape[-1] == 1440
 
 
 def test_no_cpu_fallback_in_dropin_classes():
@@ -141,7 +147,7 @@ def test_dropin_modules_match_reference_goldens(golden_dir):
     d = est(t("est_x"), torch.ones(2, 1, 64).cuda(), t("est_mu"), t("est_t"), t("est_spks"), t("est_cond"), streaming=False)
     assert (d - t("est_full")).abs().max().item() < 2e-4
     dac = build_dac(80)
-    dac.load_state_dict(W.synth_state_dict(_ref(golden_dir, "dac80"), 7), strict=True)
+    dac.load_state_dict(W.synth_state_dict({**_ref(golden_dir, "dac80"), **_ref(golden_dir, "dacenc")}, 7), strict=True)
     dac.to("cuda").float_parity()
     gd = np.load(os.path.join(golden_dir, "dac80.npz"))
     wav = dac.decode(torch.from_numpy(gd["z_T8"]).cuda())
@@ -149,6 +155,17 @@ def test_dropin_modules_match_reference_goldens(golden_dir):
     pre = torch.from_numpy(gd["pre_T8"]).cuda()
     wav2 = dac.decoder(pre)                                # Decoder.forward on de_conv_pre's output
     assert (wav2.cpu() - torch.from_numpy(gd["wav_T8"])).abs().max().item() < 1e-4
+    # DACVAE.preprocess / encode / forward (model.py:457-506) on the reference's own outputs
+    ge = np.load(os.path.join(golden_dir, "dacenc.npz"))
+    wav_in = torch.from_numpy(ge["wav_11000"]).cuda()
+    z, mu, logs = dac.encode(dac.preprocess(wav_in, 24000), noise=torch.from_numpy(ge["noise_11000"]).cuda())
+    assert z.shape == mu.shape == logs.shape == (1, 80, 23)
+    assert (mu.cpu() - torch.from_numpy(ge["mu_11000"])).abs().max().item() < 2e-4
+    assert (logs.cpu() - torch.from_numpy(ge["logs_11000"])).abs().max().item() < 2e-4
+    out = dac(wav_in, 24000)                               # own VAE draw: shapes + self-consistency
+    assert out["audio"].shape == (1, 1, 11000) and out["z"].shape == (1, 80, 23)
+    assert (out["mu"] - mu).abs().max().item() < 1e-5
+    assert (dac.decode(out["z"])[..., :11000] - out["audio"]).abs().max().item() < 1e-5
 
 
 @pytest.mark.gpu
@@ -183,7 +200,7 @@ def test_cosyvoice2model_tts_streaming_and_offline(golden_dir):
     flow = build_flow()
     flow.load_state_dict(W.synth_state_dict(_ref(golden_dir, "flow"), 7), strict=True)
     dac = build_dac(80)
-    dac.load_state_dict(W.synth_state_dict(_ref(golden_dir, "dac80"), 7), strict=True)
+    dac.load_state_dict(W.synth_state_dict({**_ref(golden_dir, "dac80"), **_ref(golden_dir, "dacenc")}, 7), strict=True)
     model = CosyVoice2Model(lm.to("cuda"), flow.to("cuda"), dac.to("cuda"))
     g = torch.Generator().manual_seed(5)
     text = torch.randint(0, 151936, (1, 30), generator=g)
@@ -240,3 +257,44 @@ def test_speaker_encoder_and_flow_with_reference_mels(golden_dir, dt, tol_e, tol
                           reference_mels=torch.from_numpy(g["flow_refs"]).cuda(), reference_mel_masks=torch.ones(1, 2, 60).cuda(),
                           streaming=False, finalize=True)
     assert (y.cpu() - torch.from_numpy(g["flow_out"])).abs().max().item() < tol_f
+
+
+def test_latent_file_format_reader_side(tmp_path):
+    """`*_latent2x.pt` naming and the reader's trim rule (extract_dac_latents.py:166-196, processor.py:149-159)."""
+    import latents
+    assert latents.latent_path("a/b/c/d.wav") == "a/b/c/d_latent2x.pt"
+    z = torch.arange(80 * 23, dtype=torch.float32).reshape(80, 23)
+    p = str(tmp_path / "u_latent2x.pt")
+    torch.save({"z": z, "mu": z, "logs": z, "sample_rate": 24000, "compression_ratio": 478, "original_duration": 0.458,
+                "original_samples": 11000, "latent_shape": [80, 23], "original_path": "u.wav"}, p)
+    lat, tok = latents.load_speech_latent(p, list(range(30)), 2)
+    assert lat.shape == (22, 80) and len(tok) == 11 and torch.equal(lat, z.t()[:22])
+    lat, tok = latents.load_speech_latent(p, list(range(5)), 2)
+    assert lat.shape == (10, 80) and tok == list(range(5))
+    lat, _ = latents.load_speech_latent(p, None, 0)
+    assert lat.shape == (23, 80)
+
+
+@pytest.mark.gpu
+def test_latent_file_writer_roundtrip(golden_dir, tmp_path):
+    """latents.save_latent writes the reference's dict; mu equals the reference's unpadded encode; the file feeds
+    flow.inference's prompt_feat layout ([T, 80])."""
+    import numpy as np
+    import latents
+    from oracle import weights as W
+    dac = build_dac(80)
+    dac.load_state_dict(W.synth_state_dict({**_ref(golden_dir, "dac80"), **_ref(golden_dir, "dacenc")}, 7), strict=True)
+    dac.to("cuda").float_parity()
+    ge = np.load(os.path.join(golden_dir, "dacenc.npz"))
+    wav = ge["wav_11000"].reshape(-1)
+    out = latents.save_latent(dac, wav, 24000, str(tmp_path / "spk1" / "utt.wav"))
+    assert out.endswith("spk1/utt_latent2x.pt")
+    rec = torch.load(out, map_location="cpu", weights_only=False)
+    assert set(rec) == {"z", "mu", "logs", "sample_rate", "compression_ratio", "original_duration", "original_samples",
+                        "latent_shape", "original_path"}
+    assert rec["latent_shape"] == [80, 23] and rec["original_samples"] == 11000 and rec["compression_ratio"] == 11000 // 23
+    assert (rec["mu"] - torch.from_numpy(ge["mu_raw_11000"][0])).abs().max().item() < 2e-4
+    lat, tok = latents.load_speech_latent(out, list(range(11)), 2)
+    assert lat.shape == (22, 80) and len(tok) == 11
+    with pytest.raises(ValueError, match="resampled"):
+        latents.latent_record(dac, wav, 16000)

@@ -1,5 +1,5 @@
-"""DAC-VAE decoder on the HIP path vs the golden vectors produced by the reference's own Decoder
-(tests/golden/dac*.npz) and vs the CPU oracle at the full BASELINE size."""
+"""DAC-VAE decoder and encoder on the HIP path vs the golden vectors produced by the reference's own DACVAE
+(tests/golden/dac*.npz, dacenc.npz) and vs the CPU oracle at the full BASELINE size."""
 import os
 
 import numpy as np
@@ -43,3 +43,83 @@ def test_dac_decode_full_size_vs_oracle(golden_dir):
     assert wav.shape == (2, 1, 240000)
     ref = ODAC.decode(sd, z, RATES)
     assert (wav.cpu() - ref).abs().max().item() < 2e-4
+
+
+# ----------------------------------------------------------------------------- encoder
+ENC_RATES = [2, 3, 4, 4, 5]
+
+
+def _enc_engine(golden_dir, dt):
+    from mmx.dac import DacEncoderEngine
+    from oracle import weights as W
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_dacenc.json")), SEED)
+    return DacEncoderEngine(sd, ENC_RATES, dtype=dt), sd
+
+
+@pytest.mark.parametrize("dt,tol", [(0, 2e-4), (1, 8e-2)])
+def test_dac_encode_vs_reference_golden(golden_dir, dt, tol):
+    """DACVAE.encode (dac-vae/model.py:469-483): mu / logs / z against the reference's outputs, with the reference's
+    own randn draw as the noise.  fp32 build 2e-4 abs; bf16 build: operand rounding through 32 convs (bound here)."""
+    from oracle import dac as ODAC
+    eng, _ = _enc_engine(golden_dir, dt)
+    g = np.load(os.path.join(golden_dir, "dacenc.npz"))
+    for n in (4800, 11000):
+        x = ODAC.preprocess(torch.from_numpy(g[f"wav_{n}"]), 480).cuda()
+        z, mu, logs = eng.encode(x, noise=torch.from_numpy(g[f"noise_{n}"]).cuda())
+        for name, v in (("mu", mu), ("logs", logs)):
+            ref = torch.from_numpy(g[f"{name}_{n}"])
+            assert v.shape == ref.shape
+            err = (v.cpu() - ref).abs().max().item()
+            assert err < tol, (name, n, dt, err)
+        zr = torch.from_numpy(g[f"z_{n}"])
+        rel = ((z.cpu() - zr).abs() / (1 + zr.abs())).max().item()       # z = mu + noise*exp(logs), |z| up to ~1e2
+        assert rel < (2e-4 if dt == 0 else 0.3), (n, dt, rel)
+
+
+def test_dac_encode_full_size_vs_oracle(golden_dir):
+    """10 s of audio (240000 samples -> 500 frames), batch 2, fp32 build vs the CPU oracle; ragged second row is
+    right-padded the way DACVAE.preprocess does."""
+    from oracle import dac as ODAC
+    eng, sd = _enc_engine(golden_dir, 0)
+    g = torch.Generator().manual_seed(5)
+    wav = 0.3 * torch.randn(2, 1, 240000, generator=g)
+    wav[1, :, 200000:] = 0
+    noise = torch.randn(2, 80, 500, generator=g)
+    z, mu, logs = eng.encode(wav.cuda(), noise=noise.cuda())
+    assert z.shape == (2, 80, 500)
+    zr, mr, lr = ODAC.encode(sd, wav, ENC_RATES, noise)
+    assert (mu.cpu() - mr).abs().max().item() < 3e-4
+    assert (logs.cpu() - lr).abs().max().item() < 3e-4
+    assert ((z.cpu() - zr).abs() / (1 + zr.abs())).max().item() < 3e-4
+
+
+def test_dac_encode_unpadded_audio_vs_reference_golden(golden_dir):
+    """dac-vae/extract_dac_latents.py:20-36 encodes clamped, UNPADDED audio: every strided conv floors its length."""
+    eng, _ = _enc_engine(golden_dir, 0)
+    g = np.load(os.path.join(golden_dir, "dacenc.npz"))
+    x = torch.from_numpy(g["wav_11000"]).clamp(-1.0, 1.0).cuda()
+    assert eng.frames(11000) == g["mu_raw_11000"].shape[-1]
+    z, mu, logs = eng.encode(x, noise=torch.from_numpy(g["noise_raw_11000"]).cuda())
+    assert (mu.cpu() - torch.from_numpy(g["mu_raw_11000"])).abs().max().item() < 2e-4
+    assert (logs.cpu() - torch.from_numpy(g["logs_raw_11000"])).abs().max().item() < 2e-4
+    zr = torch.from_numpy(g["z_raw_11000"])
+    assert ((z.cpu() - zr).abs() / (1 + zr.abs())).max().item() < 2e-4
+    with pytest.raises(ValueError, match="shorter than one latent frame"):
+        eng.encode(torch.zeros(1, 1, 100, device="cuda"))
+
+
+def test_strided_windowed_gemm_matches_conv1d():
+    """MmxGemmParams.row_stride: Conv1d(k=2s, stride s, pad ceil(s/2)) for the encoder strides, fp32 build, vs torch."""
+    import math
+    from mmx import ops
+    g = torch.Generator().manual_seed(9)
+    for s, cin, cout, T in ((2, 64, 128, 960), (3, 16, 40, 33 * 3), (5, 24, 48, 5 * 41)):
+        w = torch.randn(cout, cin, 2 * s, generator=g) / math.sqrt(cin * 2 * s)
+        b = torch.randn(cout, generator=g)
+        x = torch.randn(2, cin, T, generator=g)
+        ref = torch.nn.functional.conv1d(x, w, b, stride=s, padding=math.ceil(s / 2))
+        out = torch.empty(2, T // s, cout, device="cuda")
+        ops.conv1d(x.transpose(1, 2).contiguous().cuda(), ops.pack_conv1d(w.cuda(), 0), T=T, Cin=cin, k=2 * s,
+                   pad_left=math.ceil(s / 2), stride=s, T_out=T // s, dtype=0, batch=2, bias=b.cuda(), out_f32=out)
+        assert ref.shape[-1] == T // s
+        assert (out.cpu().transpose(1, 2) - ref).abs().max().item() < 1e-4, s

@@ -37,6 +37,31 @@ def test_dac_decode_matches_reference(golden_dir, lat):
         assert torch.allclose(st[i], torch.from_numpy(g[f"stage{i}_T8"]), atol=2e-5), i
 
 
+def test_dac_encode_matches_reference(golden_dir):
+    """DACVAE.encode / forward (dac-vae/model.py:469-506) on the reference's own outputs."""
+    g = _load(golden_dir, "dacenc.npz")
+    man = W.load_manifest(os.path.join(golden_dir, "manifest_dacenc.json"))
+    man.update(W.load_manifest(os.path.join(golden_dir, "manifest_dac80.json")))
+    sd = W.synth_state_dict(man, SEED)
+    enc_rates = [2, 3, 4, 4, 5]
+    for n in (4800, 11000):
+        wav = torch.from_numpy(g[f"wav_{n}"])
+        x = ODAC.preprocess(wav, 480)
+        assert x.shape[-1] % 480 == 0
+        z, mu, logs = ODAC.encode(sd, x, enc_rates, torch.from_numpy(g[f"noise_{n}"]))
+        for name, v in (("mu", mu), ("logs", logs)):
+            assert (v - torch.from_numpy(g[f"{name}_{n}"])).abs().max() < 2e-5, name
+        zr = torch.from_numpy(g[f"z_{n}"])
+        assert ((z - zr).abs() / (1 + zr.abs())).max() < 2e-5
+        recon = ODAC.decode(sd, z, RATES)[..., :n]
+        assert (recon - torch.from_numpy(g[f"recon_{n}"])).abs().max() < 5e-5
+    zr, mur, _ = ODAC.encode(sd, torch.from_numpy(g["wav_11000"]).clamp(-1, 1), enc_rates, torch.from_numpy(g["noise_raw_11000"]))
+    assert mur.shape == g["mu_raw_11000"].shape and (mur - torch.from_numpy(g["mu_raw_11000"])).abs().max() < 2e-5
+    _, st = ODAC.encoder_forward(sd, ODAC.preprocess(torch.from_numpy(g["wav_4800"]), 480), enc_rates, return_stages=True)
+    for i in (0, 1, 5):
+        assert torch.allclose(st[i][..., :160], torch.from_numpy(g[f"stage{i}_4800"]), atol=2e-5), i
+
+
 @pytest.fixture(scope="module")
 def flow_sd(golden_dir):
     return W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_flow.json")), SEED)
