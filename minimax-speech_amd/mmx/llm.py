@@ -250,6 +250,87 @@ class LlmEngine:
                 break
         return self.tokens()
 
+    # ------------------------------------------------------------------ host-driven stream (bistream decode, llm.py:762-870)
+    def open_stream(self, seed=0, seq_id=0, want_logp=False):
+        """One sequence (slot 0) whose LM passes are issued one at a time by the host: text rows and speech-token rows
+        arrive interleaved, so the loop of llm.py:786-870 stays on the host; every pass still runs on the HIP kernels and
+        the sampler stays on the device.  The loop state (fields of include/mmx_hip.h) is mirrored on the host and
+        uploaded before each pass."""
+        assert self.B == 1, "bistream decode is single-sequence (cli/model.py:105-112)"
+        self.seed, self.want_logp, self.forced = int(seed), bool(want_logp), None
+        self._st = dict(rows=0, calls=0, hist=0, seq=int(seq_id), last=None)
+        self.sampled.fill_(-1)
+        key = (True, self.want_logp, self.seed)
+        if self._decode is None or getattr(self, "_graph_key", None) != key:
+            self._decode = Graphed(self._decode_step, self.use_graphs)
+        self._graph_key = key
+
+    def embed_text(self, tok: torch.Tensor) -> torch.Tensor:
+        """llm.model.model.embed_tokens rows, fp32 [n, H]."""
+        tok = tok.reshape(-1).to(self.dev, torch.int64)
+        x = torch.empty(tok.numel(), self.H, device=self.dev)
+        if tok.numel():
+            ops.gather_rows(tok, self.embed_tokens, out_f32=x, dtype=F32)
+        return x
+
+    def embed_speech(self, tok: torch.Tensor) -> torch.Tensor:
+        tok = tok.reshape(-1).to(self.dev, torch.int64)
+        x = torch.empty(tok.numel(), self.H, device=self.dev)
+        if tok.numel():
+            ops.gather_rows(tok, self.speech_emb, out_f32=x, dtype=F32)
+        return x
+
+    def _upload_state(self, pos, ignore_eos):
+        s = self._st
+        st = torch.tensor([pos, s["calls"], s["hist"], 0, (1 << 30) if ignore_eos else 0, 1 << 30, s["seq"], 0],
+                          dtype=torch.int32).reshape(8, 1)
+        self.state.copy_(st)
+
+    def feed(self, x: Optional[torch.Tensor], ignore_eos: bool) -> int:
+        """One LM pass: appends the rows x [n, H] (None: the embedding of the last accepted token, graph replay) to
+        the KV cache and samples from the last row's logits (RAS on the device; ignore_eos as llm.py:259-274).
+        Returns the sampled id; call commit() with the id the caller settles on."""
+        s = self._st
+        n = 1 if x is None else x.shape[0]
+        if s["rows"] + n > self.max_pages * self.page or s["calls"] >= self.max_out:
+            raise RuntimeError("bistream: sequence exceeds the KV cache (no fill token / eos was produced)")
+        if x is None:
+            self._upload_state(s["rows"], ignore_eos)
+            self._decode()
+        else:
+            x = x.to(self.dev, torch.float32).contiguous()
+            for c0 in range(0, n, 64):
+                c1 = min(n, c0 + 64)
+                hc = x[c0:c1].clone()
+                hca = hc.to(self.tdt)
+                pos = torch.tensor([s["rows"] + c0], dtype=torch.int32, device=self.dev)
+                self._layers(hc, hca, 1, c1 - c0, pos, self.block_table[0:1])
+            self.h[0].copy_(hc[-1])
+            self.h_act[0].copy_(hca[-1])
+            self._upload_state(s["rows"] + n - 1, ignore_eos)
+            self._tail(1)
+        tok = int(self.sampled[0, s["calls"]].item())
+        if int(self.state[7, 0].item()):
+            raise RuntimeError("sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!")
+        s["rows"] += n
+        s["calls"] += 1
+        self._last_sampled = tok
+        return tok
+
+    def commit(self, token: int):
+        """Appends `token` to the decoded history the repetition window reads (bistream keeps fill / eos ids in it,
+        llm.py:831) and makes its embedding the next single-row input when it is a speech id."""
+        s = self._st
+        if token != self._last_sampled or token >= self.eos:
+            self.out_tokens[0, s["hist"]] = token
+            if token < self.eos:
+                self.x_in[0].copy_(self.speech_emb[token])
+            elif self._last_sampled < self.eos and s["last"] is not None:
+                self.x_in[0].copy_(self.speech_emb[s["last"]])     # the device draw that was overruled moved x_in
+        if token < self.eos:
+            s["last"] = token
+        s["hist"] += 1
+
     def tokens(self) -> List[List[int]]:
         n = self.state[ST_NOUT].tolist()
         t = self.out_tokens.cpu()

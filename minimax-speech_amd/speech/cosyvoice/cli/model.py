@@ -42,13 +42,20 @@ class CosyVoice2Model:
 
     def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid_):
         i32 = lambda t: torch.tensor([t.shape[1]], dtype=torch.int32, device=self.device)
-        for tok in self.llm.inference(text=text.to(self.device), text_len=i32(text), prompt_text=prompt_text.to(self.device),
-                                      prompt_text_len=i32(prompt_text),
-                                      prompt_speech_token=llm_prompt_speech_token.to(self.device),
-                                      prompt_speech_token_len=i32(llm_prompt_speech_token),
-                                      embedding=llm_embedding.to(self.device), uuid=uuid_):
-            self.tts_speech_token_dict[uuid_].append(tok)
-        self.llm_end_dict[uuid_] = True
+        common = dict(prompt_text=prompt_text.to(self.device), prompt_text_len=i32(prompt_text),
+                      prompt_speech_token=llm_prompt_speech_token.to(self.device),
+                      prompt_speech_token_len=i32(llm_prompt_speech_token), embedding=llm_embedding.to(self.device))
+        try:
+            if isinstance(text, Generator):               # streaming input text (cli/model.py:105-112)
+                gen = self.llm.inference_bistream(text=(t.to(self.device) for t in text), **common)
+            else:
+                gen = self.llm.inference(text=text.to(self.device), text_len=i32(text), uuid=uuid_, **common)
+            for tok in gen:
+                self.tts_speech_token_dict[uuid_].append(tok)
+        except BaseException as e:                        # surface LM errors in tts() instead of spinning forever
+            self.llm_error_dict[uuid_] = e
+        finally:
+            self.llm_end_dict[uuid_] = True
 
     def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False,
                   speed=1.0):
@@ -81,6 +88,8 @@ class CosyVoice2Model:
         with self.lock:
             self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
             self.hift_cache_dict[this_uuid] = None
+        if not hasattr(self, "llm_error_dict"):
+            self.llm_error_dict = {}
         if source_speech_token.shape[1] == 0:
             p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
         else:
@@ -107,12 +116,16 @@ class CosyVoice2Model:
                 if self.llm_end_dict[this_uuid] and len(toks) - token_offset < hop + L:
                     break
             p.join()
+            if this_uuid in self.llm_error_dict:
+                raise self.llm_error_dict.pop(this_uuid)
             t = torch.tensor(toks).unsqueeze(0)
             wav = self.token2wav(t, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, token_offset, this_uuid,
                                  finalize=True)
             yield {"tts_speech": wav.cpu()}
         else:
             p.join()
+            if this_uuid in self.llm_error_dict:
+                raise self.llm_error_dict.pop(this_uuid)
             t = torch.tensor(toks).unsqueeze(0)
             wav = self.token2wav(t, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, 0, this_uuid, finalize=True,
                                  speed=speed)

@@ -160,6 +160,105 @@ class Qwen2LM(EngineHost):
         x = eng.build_lm_input(text, prompt_text, prompt_speech_token)
         yield from self._decode_loop(eng, x, int(tl * min_token_text_ratio), int(tl * max_token_text_ratio))
 
+    def _is_device_sampler(self):
+        from cosyvoice.utils.common import ras_sampling
+        return getattr(self.sampling, "func", self.sampling) is ras_sampling
+
+    def sampling_ids(self, weighted_scores: torch.Tensor, decoded_tokens: List, sampling: int, ignore_eos: bool = True):
+        """llm.py:259-274 around a host `sampling` callable (used by inference_bistream when `sampling` is not RAS)."""
+        num_trials, max_trials = 0, 100
+        while True:
+            top_ids = self.sampling(weighted_scores, decoded_tokens, sampling)
+            if (not ignore_eos) or (self.speech_token_size not in top_ids):
+                break
+            num_trials += 1
+            if num_trials > max_trials:
+                raise RuntimeError("sampling reaches max_trials {} and still get eos when ignore_eos is True, check your "
+                                   "input!".format(max_trials))
+        return top_ids
+
+    @torch.inference_mode()
+    def inference_bistream(self, text: Generator, prompt_text: torch.Tensor, prompt_text_len: torch.Tensor,
+                           prompt_speech_token: torch.Tensor, prompt_speech_token_len: torch.Tensor,
+                           embedding: torch.Tensor, sampling: int = 25, max_token_text_ratio: float = 20,
+                           min_token_text_ratio: float = 2) -> Generator[int, None, None]:
+        """llm.py:762-870: text arrives as a generator of id tensors and is interleaved with speech tokens
+        mix_ratio[0] : mix_ratio[1]; the fill token (speech_token_size + 2) asks for the next text block.  The
+        interleaving loop is host logic (it waits on the caller's generator); every LM pass, log-softmax and the RAS
+        draw run on the device.  A `sampling` callable other than ras_sampling is honoured on the host from the
+        device log-probs, as the reference would call it."""
+        eng = self.engine(1)
+        dev_sampler = self._is_device_sampler()
+        eng.open_stream(seed=self.seed, want_logp=not dev_sampler)
+        fill, n_speech = self.speech_token_size + 2, self.speech_token_size
+        mix = self.mix_ratio
+
+        def step(x, ignore_eos, out_tokens, forced=None):
+            tok = eng.feed(x, ignore_eos)
+            if forced is not None:                        # llm.py:824-826: the pass runs, its draw is not used
+                return forced
+            if not dev_sampler:
+                tok = int(self.sampling_ids(eng.logp[0], out_tokens, sampling, ignore_eos=ignore_eos))
+            return tok
+
+        sos = eng.llm_emb[0:1]
+        task = eng.llm_emb[1:2]
+        pse = eng.embed_speech(prompt_speech_token) if int(prompt_speech_token_len) != 0 else torch.zeros(0, eng.H, device=eng.dev)
+        lm_input = sos
+        pending = False                                   # lm_input is exactly the last accepted token's embedding
+        out_tokens: List[int] = []
+        text_cache = eng.embed_text(prompt_text)
+        next_fill_index = -1
+        for this_text in text:
+            text_cache = torch.cat([text_cache, eng.embed_text(this_text)], dim=0)
+            while pse.shape[0] != 0:
+                if text_cache.shape[0] >= mix[0]:
+                    lm_input = torch.cat([lm_input, text_cache[:mix[0]], pse[:mix[1]]], dim=0)
+                    pending = False
+                    text_cache, pse = text_cache[mix[0]:], pse[mix[1]:]
+                else:
+                    break
+            if pse.shape[0] == 0:
+                if (len(out_tokens) != 0 and out_tokens[-1] == fill) or (len(out_tokens) == 0 and lm_input.shape[0] == 1):
+                    if text_cache.shape[0] >= mix[0]:
+                        lm_input_text = text_cache[:mix[0]]
+                        if len(out_tokens) != 0 and out_tokens[-1] == fill:
+                            lm_input = lm_input_text
+                        else:
+                            lm_input = torch.cat([lm_input, lm_input_text], dim=0)
+                        pending = False
+                        text_cache = text_cache[mix[0]:]
+                    else:
+                        continue
+                while True:
+                    force = next_fill_index != -1 and len(out_tokens) == next_fill_index
+                    top_ids = step(None if pending else lm_input, True, out_tokens, fill if force else None)
+                    if force:
+                        next_fill_index += mix[1] + 1
+                    if top_ids == fill:
+                        next_fill_index = len(out_tokens) + mix[1] + 1
+                    out_tokens.append(top_ids)
+                    eng.commit(top_ids)
+                    if top_ids >= n_speech:
+                        if top_ids == fill:
+                            break
+                        raise ValueError("should not get token {}".format(top_ids))
+                    yield top_ids
+                    lm_input, pending = eng.x_in[0:1], True
+        # final decode: the remaining text, then <task_id>, until eos (llm.py:848-870)
+        lm_input = torch.cat([lm_input.clone(), text_cache, task], dim=0)
+        pending = False
+        while True:
+            top_ids = step(None if pending else lm_input, False, out_tokens)
+            out_tokens.append(top_ids)
+            eng.commit(top_ids)
+            if top_ids >= n_speech:
+                if top_ids == n_speech:
+                    break
+                raise ValueError("should not get token {}".format(top_ids))
+            yield top_ids
+            lm_input, pending = eng.x_in[0:1], True
+
     def _decode_loop(self, eng, x, min_len, max_len):
         eng.start([x], [min_len], [max_len], seed=self.seed)
         sent = 0

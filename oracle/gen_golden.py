@@ -258,6 +258,52 @@ def gen_llm():
     np.savez_compressed(os.path.join(GOLD, "llm.npz"), **out)
 
 
+def gen_bistream():
+    """Qwen2LM.inference_bistream (llm.py:762-870) of the reference on a 2-layer Qwen2 shape with a scripted
+    `sampling` callable: the yielded tokens and the log-probs of every sampling call pin the interleaving logic."""
+    R.import_cosyvoice()
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM
+    from oracle.llm import ScriptedSampling
+    cfg = Qwen2Config(vocab_size=151936, hidden_size=896, intermediate_size=4864, num_hidden_layers=2,
+                      num_attention_heads=14, num_key_value_heads=2, rope_theta=1e6, rms_norm_eps=1e-6,
+                      tie_word_embeddings=True, max_position_embeddings=32768)
+    d = tempfile.mkdtemp()
+    Qwen2ForCausalLM(cfg).save_pretrained(d)
+    out = {}
+    cases = {
+        # name: (prompt_text len, prompt_speech len, text chunk lens, fill_at, eos_from)
+        "a": (5, 20, (3, 4, 6, 2), (12,), 40),     # prompt speech interleaved 15 + 5, sampled fill, forced fill later
+        "b": (0, 0, (2, 2, 3, 5, 1), (15,), 38),   # no prompt: "not enough text, wait for more" branches
+        "c": (2, 0, (2,), (), 12),                 # never 5 text tokens: everything happens in the final decode
+    }
+    for name, (npt, nps, chunks, fill_at, eos_from) in cases.items():
+        rec = []
+        samp = ScriptedSampling(fill_at, eos_from, record=rec)
+        lm = Qwen2LM(896, 896, 6561, Qwen2Encoder(d), samp, True, 0, [5, 15], use_speaker_encoder=False).eval()
+        sd = {k: v for k, v in lm.state_dict().items() if k != "llm.model.lm_head.weight"}
+        syn = W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED)
+        syn["llm.model.lm_head.weight"] = syn["llm.model.model.embed_tokens.weight"]
+        lm.load_state_dict(syn, strict=True)
+        g = torch.Generator().manual_seed(61 + len(out))
+        ptext = torch.randint(0, 151936, (1, npt), generator=g)
+        pspeech = torch.randint(0, 6561, (1, nps), generator=g)
+        texts = [torch.randint(0, 151936, (1, n), generator=g) for n in chunks]
+        toks = list(lm.inference_bistream(text=(t for t in texts), prompt_text=ptext, prompt_text_len=torch.tensor([npt]),
+                                          prompt_speech_token=pspeech, prompt_speech_token_len=torch.tensor([nps]),
+                                          embedding=torch.zeros(0, 192)))
+        out[f"{name}_ptext"], out[f"{name}_pspeech"] = np_(ptext), np_(pspeech)
+        out[f"{name}_text"] = np_(torch.cat(texts, dim=1))
+        out[f"{name}_chunks"] = np.array(chunks)
+        out[f"{name}_fill_at"], out[f"{name}_eos_from"] = np.array(fill_at, dtype=np.int64), np.array(eos_from)
+        out[f"{name}_tokens"] = np.array([int(t) for t in toks])
+        lp = torch.stack(rec)
+        out[f"{name}_logp_head"] = np_(lp[:, :128])                       # leading ids + the maximum pin every call
+        out[f"{name}_logp_max"] = np_(lp.max(dim=1).values)
+        print(f"bistream {name}: {len(toks)} tokens yielded, {len(rec)} sampling calls")
+    np.savez_compressed(os.path.join(GOLD, "bistream.npz"), **out)
+
+
 def gen_spk():
     """LearnableSpeakerEncoder alone, flow.inference with reference_mels (use_speaker_encoder=True) and the lm_input of
     Qwen2LM.inference_spk."""
@@ -320,8 +366,8 @@ def gen_sampler():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["dac", "dacenc", "flow", "llm", "sampler", "spk"]
+    which = sys.argv[1:] or ["dac", "dacenc", "flow", "llm", "bistream", "sampler", "spk"]
     for w in which:
         t0 = time.time()
-        {"dac": gen_dac, "dacenc": gen_dac_enc, "flow": gen_flow, "llm": gen_llm, "sampler": gen_sampler, "spk": gen_spk}[w]()
+        {"dac": gen_dac, "dacenc": gen_dac_enc, "flow": gen_flow, "llm": gen_llm, "bistream": gen_bistream, "sampler": gen_sampler, "spk": gen_spk}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f}s")

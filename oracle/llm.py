@@ -192,3 +192,110 @@ def lm_inference(sd, cfg: QwenCfg, text, prompt_text, prompt_speech_token, seed:
         out.append(top)
         lm_input = sd["speech_embedding.weight"][top].reshape(1, 1, -1)
     return sampled if forced is not None else out
+
+
+def lm_inference_bistream(sd, cfg: QwenCfg, text_chunks, prompt_text, prompt_speech_token,
+                          sampling_ids: Callable[[torch.Tensor, List[int], int, bool], int],
+                          mix_ratio=(5, 15), speech_token_size=6561, record: Optional[list] = None,
+                          max_calls: int = 4096):
+    """Qwen2LM.inference_bistream (speech/cosyvoice/llm/llm.py:762-870): text arrives in chunks and is interleaved
+    with speech tokens mix_ratio[0] : mix_ratio[1]; the model asks for more text with the fill token
+    (speech_token_size + 2), which is also forced every mix_ratio[1]+1 tokens once it has been seen.
+
+    `sampling_ids(logp, out_tokens, call_index, ignore_eos)` stands for self.sampling_ids (llm.py:259-274);
+    call_index counts LM forward passes (the forced-fill passes included, llm.py:824-827).
+    Returns (yielded tokens, out_tokens incl. fill / eos).  `record` collects the logp of every pass."""
+    fill, eos = speech_token_size + 2, speech_token_size
+    emb = lambda ids: F.embedding(ids, sd["llm.model.model.embed_tokens.weight"])
+    sos = sd["llm_embedding.weight"][0].reshape(1, 1, -1)
+    task = sd["llm_embedding.weight"][1].reshape(1, 1, -1)
+    H = sos.shape[-1]
+    pse = F.embedding(prompt_speech_token, sd["speech_embedding.weight"]) if prompt_speech_token.shape[1] else torch.zeros(1, 0, H)
+    lm_input = sos
+    out_tokens, yielded, cache = [], [], None
+    text_cache = emb(prompt_text)
+    next_fill_index = -1
+    calls = 0
+
+    def forward(x):
+        nonlocal cache, calls
+        y, cache = qwen2_forward(sd, cfg, x, cache)
+        logp = F.linear(y[:, -1], sd["llm_decoder.weight"], sd["llm_decoder.bias"]).log_softmax(dim=-1).squeeze(0)
+        if record is not None:
+            record.append(logp.clone())
+        calls += 1
+        if calls > max_calls:
+            raise RuntimeError("bistream: no fill token / eos within max_calls")
+        return logp
+
+    for this_text in text_chunks:
+        text_cache = torch.cat([text_cache, emb(this_text)], dim=1)
+        while pse.shape[1] != 0:                                       # llm.py:796-805
+            if text_cache.shape[1] >= mix_ratio[0]:
+                lm_input = torch.cat([lm_input, text_cache[:, :mix_ratio[0]], pse[:, :mix_ratio[1]]], dim=1)
+                text_cache, pse = text_cache[:, mix_ratio[0]:], pse[:, mix_ratio[1]:]
+            else:
+                break
+        if pse.shape[1] == 0:                                          # llm.py:807-845
+            if (len(out_tokens) != 0 and out_tokens[-1] == fill) or (len(out_tokens) == 0 and lm_input.shape[1] == 1):
+                if text_cache.shape[1] >= mix_ratio[0]:
+                    lm_input_text = text_cache[:, :mix_ratio[0]]
+                    if len(out_tokens) != 0 and out_tokens[-1] == fill:
+                        lm_input = lm_input_text
+                    else:
+                        lm_input = torch.cat([lm_input, lm_input_text], dim=1)
+                    text_cache = text_cache[:, mix_ratio[0]:]
+                else:
+                    continue
+            while True:
+                logp = forward(lm_input)
+                if next_fill_index != -1 and len(out_tokens) == next_fill_index:
+                    top = fill
+                    next_fill_index += mix_ratio[1] + 1
+                else:
+                    top = sampling_ids(logp, out_tokens, calls - 1, True)
+                if top == fill:
+                    next_fill_index = len(out_tokens) + mix_ratio[1] + 1
+                out_tokens.append(top)
+                if top >= speech_token_size:
+                    if top == fill:
+                        break
+                    raise ValueError(f"should not get token {top}")
+                yielded.append(top)
+                lm_input = sd["speech_embedding.weight"][top].reshape(1, 1, -1)
+    lm_input = torch.cat([lm_input, text_cache, task], dim=1)           # llm.py:848-870
+    while True:
+        logp = forward(lm_input)
+        top = sampling_ids(logp, out_tokens, calls - 1, False)
+        out_tokens.append(top)
+        if top >= speech_token_size:
+            if top == eos:
+                break
+            raise ValueError(f"should not get token {top}")
+        yielded.append(top)
+        lm_input = sd["speech_embedding.weight"][top].reshape(1, 1, -1)
+    return yielded, out_tokens
+
+
+class ScriptedSampling:
+    """A deterministic `sampling` callable (the constructor argument of Qwen2LM, llm.py:381) used to pin the bistream
+    control flow against the reference: argmax over the speech ids, the fill token when len(decoded) is in `fill_at`,
+    eos once len(decoded) >= eos_from (and an argmax on the immediate retry that ignore_eos=True provokes)."""
+
+    def __init__(self, fill_at=(), eos_from=10 ** 9, speech_token_size=6561, record=None):
+        self.fill_at, self.eos_from, self.n = set(fill_at), eos_from, speech_token_size
+        self.record = record
+        self._last_eos_len = -1
+
+    def __call__(self, weighted_scores, decoded_tokens, sampling):
+        n = len(decoded_tokens)
+        if n > 1000:
+            raise RuntimeError("ScriptedSampling: runaway decode (no fill token / eos scheduled)")
+        if self.record is not None and self._last_eos_len != n:
+            self.record.append(weighted_scores.detach().float().cpu().clone())
+        if n in self.fill_at:
+            return torch.tensor(self.n + 2)
+        if n >= self.eos_from and self._last_eos_len != n:
+            self._last_eos_len = n
+            return torch.tensor(self.n)
+        return weighted_scores[:self.n].argmax()

@@ -223,4 +223,14 @@ def import_cosyvoice():
     import logging
     pl.get_pylogger = lambda name=__name__: logging.getLogger(name)
     sys.modules["matcha.utils.pylogger"] = pl
+    legacy_kv_cache_indexing()
     return matcha
+
+
+def legacy_kv_cache_indexing():
+    """The reference pins transformers 4.40 (speech/requirements.txt), whose KV cache indexes as cache[layer] ->
+    (key, value); llm.py:820 relies on it (`cache[0][0].size(2)`).  The installed transformers dropped
+    DynamicCache.__getitem__: restore that accessor (environment compatibility only, no reference logic)."""
+    from transformers import DynamicCache
+    if not hasattr(DynamicCache, "__getitem__"):
+        DynamicCache.__getitem__ = lambda self, i: (self.layers[i].keys, self.layers[i].values)

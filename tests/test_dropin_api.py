@@ -213,6 +213,19 @@ def test_cosyvoice2model_tts_streaming_and_offline(golden_dir):
     n_str = sum(c["tts_speech"].shape[1] for c in chunks)
     assert len(chunks) >= 2 and n_str == n_off                        # same tokens (same Philox stream) -> same length
     assert all(torch.isfinite(c["tts_speech"]).all() for c in chunks)
+    # streaming INPUT text (a generator of id tensors -> inference_bistream, cli/model.py:105-112); the scripted sampler
+    # asks for more text with a fill token and ends the utterance, which random-init weights never would
+    from oracle.llm import ScriptedSampling
+    lm.sampling = ScriptedSampling((15,), 38)
+    parts = [text[:, :2], text[:, 2:4], text[:, 4:7], text[:, 7:12], text[:, 12:13]]
+    outs = list(model.tts(text=(p for p in parts), flow_embedding=emb, llm_embedding=emb, stream=True))
+    assert sum(c["tts_speech"].shape[1] for c in outs) == 36 * 960      # 38 ids decoded, 2 of them fill tokens
+    # an LM-side error reaches the caller
+    lm.sampling = ScriptedSampling((), 10 ** 9)
+    lm.max_ctx = 64
+    lm._invalidate()
+    with pytest.raises(RuntimeError, match="exceeds the KV cache"):
+        list(model.tts(text=(p for p in parts), flow_embedding=emb, llm_embedding=emb, stream=False))
 
 
 def test_speaker_encoder_state_dict_keys(golden_dir):
@@ -298,3 +311,81 @@ def test_latent_file_writer_roundtrip(golden_dir, tmp_path):
     assert lat.shape == (22, 80) and len(tok) == 11
     with pytest.raises(ValueError, match="resampled"):
         latents.latent_record(dac, wav, 16000)
+
+
+def _bistream_lm(sampling=None, fill_bias=0.0):
+    from oracle import weights as W
+    from mmx import shapes
+    lm = build_llm(2)
+    sd = W.synth_state_dict(shapes.llm_manifest(layers=2), 7)
+    if fill_bias:
+        sd["llm_decoder.bias"] = sd["llm_decoder.bias"].clone()
+        sd["llm_decoder.bias"][6563] += fill_bias
+    lm.load_state_dict(sd, strict=True)
+    if sampling is not None:
+        lm.sampling = sampling
+    return lm.to("cuda").float_parity(), sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_dropin_inference_bistream_vs_reference_golden(golden_dir, case):
+    """Qwen2LM.inference_bistream (llm.py:762-870) with the scripted `sampling` callable the reference was run with:
+    same yielded tokens, same log-probs at every sampling call (fp32 build)."""
+    import numpy as np
+    from oracle.llm import ScriptedSampling
+    g = np.load(os.path.join(golden_dir, "bistream.npz"))
+    rec = []
+    samp = ScriptedSampling(tuple(g[f"{case}_fill_at"].tolist()), int(g[f"{case}_eos_from"]), record=rec)
+    lm, _ = _bistream_lm(samp)
+    text = torch.from_numpy(g[f"{case}_text"]).cuda()
+    chunks, o = [], 0
+    for n in g[f"{case}_chunks"].tolist():
+        chunks.append(text[:, o:o + n])
+        o += n
+    ptext, psp = torch.from_numpy(g[f"{case}_ptext"]).cuda(), torch.from_numpy(g[f"{case}_pspeech"]).cuda()
+    toks = list(lm.inference_bistream(text=(t for t in chunks), prompt_text=ptext,
+                                      prompt_text_len=torch.tensor([ptext.shape[1]]).cuda(), prompt_speech_token=psp,
+                                      prompt_speech_token_len=torch.tensor([psp.shape[1]]).cuda(),
+                                      embedding=torch.zeros(0, 192).cuda()))
+    assert toks == g[f"{case}_tokens"].tolist()
+    lp = torch.stack(rec)
+    assert lp.shape[0] == g[f"{case}_logp_head"].shape[0]
+    assert (lp[:, :128] - torch.from_numpy(g[f"{case}_logp_head"])).abs().max().item() < 1e-3
+    assert (lp.max(dim=1).values - torch.from_numpy(g[f"{case}_logp_max"])).abs().max().item() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,ok", [(6, True), (0, False)])
+def test_dropin_inference_bistream_device_sampler_vs_oracle(seed, ok):
+    """Default RAS sampling stays on the device (Philox noise keyed by the LM pass index): token-for-token equal to the
+    CPU oracle of the same loop, including the ValueError the reference raises when a fill token shows up in the
+    final decode (llm.py:865-866).  The fill logit is biased so that the synthetic LM asks for text at all."""
+    from oracle import llm as O
+    lm, sd = _bistream_lm(fill_bias=5.0)
+    lm.seed = seed
+    g = torch.Generator().manual_seed(3)
+    ptext = torch.randint(0, 151936, (1, 5), generator=g)
+    psp = torch.randint(0, 6561, (1, 15), generator=g)
+    chunks = [torch.randint(0, 151936, (1, n), generator=g) for n in (6, 5, 7)]
+
+    def sid(logp, out, i, ign):
+        return O.sampling_ids_e(logp, out, lambda k: O.philox_noise(seed, 0, i, k), ignore_eos=ign, eos=6561)
+
+    want, err = [], None
+    try:
+        want, _ = O.lm_inference_bistream(sd, O.QwenCfg(layers=2), chunks, ptext, psp, sid, max_calls=400)
+    except ValueError as e:
+        err = str(e)
+    assert (err is None) == ok
+    got = []
+    gen = lm.inference_bistream(text=(t.cuda() for t in chunks), prompt_text=ptext.cuda(), prompt_text_len=torch.tensor([5]).cuda(),
+                                prompt_speech_token=psp.cuda(), prompt_speech_token_len=torch.tensor([15]).cuda(),
+                                embedding=torch.zeros(0, 192).cuda())
+    if ok:
+        got = list(gen)
+        assert got == want and len(got) > 20
+    else:
+        with pytest.raises(ValueError, match="should not get token 6563"):
+            for t in gen:
+                got.append(t)

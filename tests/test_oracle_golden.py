@@ -170,3 +170,39 @@ def test_speaker_encoder_matches_reference(golden_dir):
     emb = OSPK.reference_embedding(fsd, torch.from_numpy(g["flow_refs"]))
     y = OFLOW.flow_inference(fsd, torch.from_numpy(g["flow_tok"]), torch.zeros(1, 0, dtype=torch.long), torch.zeros(1, 0, 80), emb)
     assert (y - torch.from_numpy(g["flow_out"])).abs().max() < 1e-4
+
+
+def _scripted_ids(samp, eos=6561):
+    """sampling_ids (llm.py:259-274) around a `sampling` callable."""
+    def f(logp, out, call, ignore_eos):
+        for _ in range(101):
+            top = int(samp(logp, out, 25))
+            if (not ignore_eos) or top != eos:
+                return top
+        raise RuntimeError("max_trials")
+    return f
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_llm_bistream_matches_reference(golden_dir, case):
+    """Qwen2LM.inference_bistream (llm.py:762-870) run by the reference with a scripted sampler: yielded tokens and
+    the log-probs seen by every sampling call."""
+    from mmx import shapes
+    g = _load(golden_dir, "bistream.npz")
+    sd = W.synth_state_dict(shapes.llm_manifest(layers=2), SEED)
+    cfg = OLLM.QwenCfg(layers=2)
+    rec = []
+    samp = OLLM.ScriptedSampling(tuple(g[f"{case}_fill_at"].tolist()), int(g[f"{case}_eos_from"]), record=rec)
+    text = torch.from_numpy(g[f"{case}_text"])
+    chunks, o = [], 0
+    for n in g[f"{case}_chunks"].tolist():
+        chunks.append(text[:, o:o + n])
+        o += n
+    toks, hist = OLLM.lm_inference_bistream(sd, cfg, chunks, torch.from_numpy(g[f"{case}_ptext"]),
+                                            torch.from_numpy(g[f"{case}_pspeech"]), _scripted_ids(samp))
+    assert toks == g[f"{case}_tokens"].tolist()
+    assert hist[-1] == 6561 and [t for t in hist if t < 6561] == toks
+    lp = torch.stack(rec)
+    assert lp.shape[0] == g[f"{case}_logp_head"].shape[0]
+    assert (lp[:, :128] - torch.from_numpy(g[f"{case}_logp_head"])).abs().max() < 2e-4
+    assert (lp.max(dim=1).values - torch.from_numpy(g[f"{case}_logp_max"])).abs().max() < 2e-4
