@@ -42,12 +42,16 @@ def measure_dominant_kernel(eng, iters=240):
     from mmx import ops
     llm = eng.llm
     B, H, I = llm.B, llm.H, llm.I
+    pk = llm.packed                              # the activation layout the decode step uses at this batch size
     x = torch.randn(B, H, device=llm.dev).to(llm.tdt)
-    act = torch.empty(B, I, dtype=llm.tdt, device=llm.dev)
+    if pk:
+        x = ops.pack_act(x, llm.dtype)
+    act = torch.empty(ops.packed_rows(B), I, dtype=llm.tdt, device=llm.dev)
     esz = 2 if llm.dtype == 1 else 4
     nbytes = 2 * I * H * esz + B * H * esz + B * I * esz
     s = torch.cuda.current_stream()
-    run = lambda l: ops.skinny_gemm(x, llm.layers[l]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps, epi=1, out_act=act)
+    run = lambda l: ops.skinny_gemm(x, llm.layers[l]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps, epi=1, out_act=act,
+                                    x_packed=pk, out_packed=pk)
     for l in range(llm.n_layers):
         run(l)
     g = torch.cuda.CUDAGraph()                  # same launch mechanism as the decode step (hipGraph replay)
@@ -125,6 +129,7 @@ def main():
     ap.add_argument("--flow-group", default="2,2,4,8", help="utterances per batched flow ODE solve (ramp: k-th group)")
     ap.add_argument("--pad-ratio", type=float, default=2.0, help="max length ratio inside one flow group")
     ap.add_argument("--flow-workers", type=int, default=2, help="host threads / streams solving flow groups concurrently")
+    ap.add_argument("--hold-steps", type=int, default=48, help="decode steps a finished utterance waits for a fuller flow group")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", 0))
@@ -159,7 +164,7 @@ def main():
     max_samples = 2 * max(lens_all) * eng.hop
 
     def step():
-        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers)
+        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps)
         if world > 1:
             gather_audio(wavs, mine, len(lens_all), max_samples)      # the path's one exchange step (RCCL all-gather)
         return sum(w.shape[-1] for w in wavs)

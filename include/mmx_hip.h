@@ -168,12 +168,18 @@ int mmx_conv_cout1_tanh(const void* act, int64_t a_bs, int T, int C, int k, cons
  *   in-kernel (RMSNorm with its weight pre-folded into Wp).  epi: 0 store fp32 (+bias);
  *   1 SwiGLU: Wp rows are [gate tile | up tile] pairs, out_act[b][n] = T(silu(g)*u);
  *   2 residual: out_f32[b][n] += acc (in place).
+ *   flags: MMX_X_PACKED — x (type T) is in MFMA A-fragment order xp[m][kb][lane][E] (lane = g*16 + l16 holds
+ *   x[m*16 + l16][kb*KB + g*E + j]; E = 8 bf16 / 4 fp32, KB = 4E; ceil(B/16)*16 rows allocated, ldx ignored);
+ *   MMX_OUT_PACKED — out_act is written in that order for a consumer whose K is this N (N % 32 == 0, ldo_a ignored).
+ *   Pays at batch > 8, where every workgroup re-reads the whole activation matrix from L2.
  */
+#define MMX_X_PACKED 1
+#define MMX_OUT_PACKED 2
 int mmx_pack_skinny(const void* w, int64_t ldw, int N, int K, const float* kscale, int interleave_half,
                     void* wp, int dtype, hipStream_t stream);
 int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N, const void* wp,
                     const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
-                    void* out_act, int64_t ldo_a, int dtype, hipStream_t stream);
+                    void* out_act, int64_t ldo_a, int dtype, int flags, hipStream_t stream);
 
 /* RoPE (HF rotate_half; inv_freq[D/2] fp32 = 1/theta^(2i/D) as HF computes it) on q/k of
  * qkv[b][t][: (Hq+2Hkv)*D] at position pos[b] + t, K/V appended to the paged cache, q written as T.  Cache layout:
@@ -189,10 +195,10 @@ int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, in
 /* Single-token decode: RoPE(q), RoPE(k_new), KV append and causal GQA attention in ONE launch per layer
  * (same arithmetic as mmx_rope_kv_store + mmx_paged_attn with rows = 1).  qkv fp32 [B][ldqkv], out T [B][ldo].
  * rope_tab (optional, fp32 [max_pos][D] = cos | sin per position, as HF's rotary embedding computes them) replaces
- * the in-kernel cosf/sinf of pos * inv_freq. */
+ * the in-kernel cosf/sinf of pos * inv_freq.  out_packed: write out in the MMX_OUT_PACKED order (K = Hq*D). */
 int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                     const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
-                    float scale, void* out, int64_t ldo, int dtype, hipStream_t stream);
+                    float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream);
 /* SwiGLU for prefill: out = T(silu(gu[:, :I]) * gu[:, I:2I]) */
 int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* out, int64_t ldo, int dtype, hipStream_t stream);
 

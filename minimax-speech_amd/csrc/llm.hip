@@ -49,13 +49,27 @@ extern "C" int mmx_pack_skinny(const void* w, int64_t ldw, int N, int K, const f
     return MMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------ packed activations
+// At batch > 8 the <= 64 activation rows are kept in the A-fragment order of the MFMA as well,
+//   xp[m][kb][lane][E],  lane = g*16 + l16  <->  x[m*16 + l16][kb*KB + g*E + j]   (E = 8 bf16 / 4 fp32, KB = 4E),
+// so that a fragment load is one contiguous 1 KiB per wave-instruction instead of 16 row segments of 64 B: every
+// workgroup re-reads the whole activation matrix from L2, and at batch 32 those reads cost more than the weight
+// stream (tools/skinny_lab.hip: 10.6 -> 8.6 us gate/up, 15.2 -> 10.7 us down).  Producers (the GEMM epilogues
+// and the decode attention) write this layout directly.  At batch <= 8 row-major wins (only the valid rows move).
+template <typename T>
+__device__ __forceinline__ long act_packed_index(int row, int col, int K) {
+    constexpr int E = sizeof(T) == 2 ? 8 : 4, KB = 4 * E;
+    const int kb = col / KB, g = (col % KB) / E, j = col % E;
+    return ((((long)(row >> 4) * (K / KB) + kb) * 64) + g * 16 + (row & 15)) * E + j;
+}
+
 // ------------------------------------------------------------------------------------------ skinny GEMM
 // wave -> (output tile of 16 columns [x2 for SwiGLU], k slice); MT = row tiles of 16 (B <= 16*MT).
 // The whole problem is latency bound (a projection is 1.6 - 17 MB, a single HBM round trip is ~1-2 us), so
 // bandwidth comes from bytes in flight: every wave issues ALL the weight loads of its k slice (<= KS k-blocks,
 // 1 KiB per wave-instruction) back to back into registers before the first MFMA, and the k split is chosen so
 // that a slice fits (skinny_launch_mt below).
-template <typename T, typename TX, int MT, int EPI, int KS>
+template <typename T, typename TX, int MT, int EPI, int KS, bool XPK, bool OPK>
 __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__ x, long ldx, int B, int K, int N,
                                    const T* __restrict__ wp, const float* __restrict__ bias, int rs, float eps,
                                    float* __restrict__ outf, long ldo_f, T* __restrict__ outa, long ldo_a,
@@ -122,10 +136,16 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int v = 0; v < XV; ++v)
-                        xr[i][m][v] = (kc + i < kb1 && m * 16 + l16 < B)
-                                          ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(x + (long)(m * 16 + l16) * ldx + (kc + i) * KB + g * E) + v * 16)
-                                          : u32x4_t{0, 0, 0, 0};
+                    for (int v = 0; v < XV; ++v) {
+                        if constexpr (XPK)                       // packed activations: 1 KiB contiguous per fragment
+                            xr[i][m][v] = (kc + i < kb1)
+                                              ? *reinterpret_cast<const u32x4_t*>(x + (((long)m * nkb + kc + i) * 64 + lane) * E)
+                                              : u32x4_t{0, 0, 0, 0};
+                        else
+                            xr[i][m][v] = (kc + i < kb1 && m * 16 + l16 < B)
+                                              ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(x + (long)(m * 16 + l16) * ldx + (kc + i) * KB + g * E) + v * 16)
+                                              : u32x4_t{0, 0, 0, 0};
+                    }
 #pragma unroll
             for (int i = 0; i < KS; ++i) {
                 if (kc + i >= kb1) continue;
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
                 if (n < N) {
                     float gte = acc[0][m][r] * sc, up = acc[1][m][r] * sc;
                     float sl = gte / (1.f + expf(-gte));
-                    outa[(long)row * ldo_a + n] = Cvt<T>::from_f(sl * up);
+                    outa[OPK ? act_packed_index<T>(row, n, N) : (long)row * ldo_a + n] = Cvt<T>::from_f(sl * up);
                 }
             } else {
                 const int n = tile * 16 + l16;
@@ -232,14 +252,14 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
                     float v = acc[0][m][r] * sc + pre_bias;
                     if constexpr (EPI == 2) v += pre_res[m][r];
                     if (outf) outf[(long)row * ldo_f + n] = v;
-                    if (outa) outa[(long)row * ldo_a + n] = Cvt<T>::from_f(v);
+                    if (outa) outa[OPK ? act_packed_index<T>(row, n, N) : (long)row * ldo_a + n] = Cvt<T>::from_f(v);
                 }
             }
         }
     }
 }
 
-template <typename T, typename TX, int EPI>
+template <typename T, typename TX, int EPI, bool XPK, bool OPK>
 static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, int rs,
                             float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s) {
     constexpr int KB = sizeof(T) == 2 ? 32 : 16;
@@ -256,7 +276,7 @@ static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, con
     dim3 grid((ntiles + tpb - 1) / tpb), block(waves * 64);
     constexpr int NB = EPI == 1 ? 2 : 1;
     size_t lds = ksplit > 1 ? (size_t)waves * (NB * mt * 4 + mt) * 64 * 4 : 0;
-#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, (MT == 1 ? 10 : (MT == 2 ? 7 : 4))>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
+#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, (MT == 1 ? 10 : (MT == 2 ? 7 : 4)), XPK, OPK>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
         bias, rs, eps, outf, ldo_f, (T*)outa, ldo_a, ksplit, ntiles)
     switch (mt) {
         case 1: SK(1); break;
@@ -269,26 +289,43 @@ static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, con
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
-template <typename T, typename TX>
+template <typename T, typename TX, bool XPK, bool OPK>
 static int skinny_launch_epi(int epi, const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias,
                              int rs, float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s) {
-    if (epi == 0) return skinny_launch_mt<T, TX, 0>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
-    if (epi == 1) return skinny_launch_mt<T, TX, 1>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
-    if (epi == 2) return skinny_launch_mt<T, TX, 2>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    if (epi == 0) return skinny_launch_mt<T, TX, 0, XPK, OPK>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    if (epi == 1) return skinny_launch_mt<T, TX, 1, XPK, OPK>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    if (epi == 2) return skinny_launch_mt<T, TX, 2, XPK, OPK>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    return MMX_EARG;
+}
+// the activation layouts are compile-time (a runtime switch inside the unrolled load block cost ~1 us per launch at
+// batch 1); the combinations the decode step uses: row-major, packed x only, packed x and packed out_act
+template <typename T, typename TX>
+static int skinny_launch_layout(int flags, int epi, const void* x, int64_t ldx, int B, int K, int N, const void* wp,
+                                const float* bias, int rs, float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a,
+                                hipStream_t s) {
+    if constexpr (sizeof(T) == sizeof(TX)) {
+        if (flags == (MMX_X_PACKED | MMX_OUT_PACKED))
+            return skinny_launch_epi<T, TX, true, true>(epi, x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+        if (flags == MMX_X_PACKED)
+            return skinny_launch_epi<T, TX, true, false>(epi, x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
+    }
+    if (flags == 0) return skinny_launch_epi<T, TX, false, false>(epi, x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
     return MMX_EARG;
 }
 extern "C" int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N, const void* wp,
                                const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
-                               void* out_act, int64_t ldo_a, int dtype, hipStream_t stream) {
+                               void* out_act, int64_t ldo_a, int dtype, int flags, hipStream_t stream) {
     MMX_CHECK_ARG(x && wp && B > 0 && B <= 64 && K > 0 && K % 32 == 0 && N > 0);
+    MMX_CHECK_ARG((flags == 0 || flags == MMX_X_PACKED || flags == (MMX_X_PACKED | MMX_OUT_PACKED)) && (flags == 0 || x_dtype == dtype) &&
+                  (!(flags & MMX_OUT_PACKED) || N % 32 == 0));
     MMX_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0);
     MMX_CHECK_ARG(epi == 1 ? out_act != nullptr : (out_f32 != nullptr || (epi == 0 && out_act != nullptr)));
     MMX_CHECK_ARG(epi != 2 || out_f32 != nullptr);
     if (dtype == MMX_BF16) {
-        if (x_dtype == MMX_F32) return skinny_launch_epi<bf16_t, float>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
-        if (x_dtype == MMX_BF16) return skinny_launch_epi<bf16_t, bf16_t>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
+        if (x_dtype == MMX_F32) return skinny_launch_layout<bf16_t, float>(flags, epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
+        if (x_dtype == MMX_BF16) return skinny_launch_layout<bf16_t, bf16_t>(flags, epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
     } else if (dtype == MMX_F32 && x_dtype == MMX_F32) {
-        return skinny_launch_epi<float, float>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
+        return skinny_launch_layout<float, float>(flags, epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream);
     }
     return MMX_EARG;
 }
@@ -432,7 +469,7 @@ __device__ __forceinline__ void load8(const T* p, float o[8]) {
     }
 }
 
-template <typename T>
+template <typename T, bool OPK>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
     const float* __restrict__ rope_tab, const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc,
@@ -530,20 +567,22 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             L += gl[g2] * w;
             o += part[g2 * D + tid] * w;
         }
-        out[(long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
+        out[OPK ? act_packed_index<T>(b, h * D + tid, Hq * D) : (long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
     }
 }
 extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                                const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages,
-                               int page, float scale, void* out, int64_t ldo, int dtype, hipStream_t stream) {
+                               int page, float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream) {
     MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
+    MMX_CHECK_ARG(out_packed == 0 || out_packed == 1);
     const size_t max_ctx = (size_t)max_pages * page;
     (void)max_ctx;
     size_t lds = (3 * 64 + 2 * 32 + 32 * 64 + (size_t)max_pages) * 4;
     MMX_CHECK_ARG(lds <= 160 * 1024);
     dim3 grid(Hq, B);
-    if (dtype == MMX_BF16) hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, page, scale, (bf16_t*)out, ldo);
-    else if (dtype == MMX_F32) hipLaunchKernelGGL(decode_attn_kernel<float>, grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (float*)kc, (float*)vc, block_table, max_pages, page, scale, (float*)out, ldo);
+#define DA(T, OPK) hipLaunchKernelGGL((decode_attn_kernel<T, OPK>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo)
+    if (dtype == MMX_BF16) { if (out_packed) DA(bf16_t, true); else DA(bf16_t, false); }
+    else if (dtype == MMX_F32) { if (out_packed) DA(float, true); else DA(float, false); }
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;

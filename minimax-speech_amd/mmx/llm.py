@@ -91,7 +91,10 @@ class LlmEngine:
         self.forced, self._forced_buf = None, None
         self.x_in = torch.zeros(B, self.H, device=self.dev)         # next input embedding (written by the sampler)
         self.h = torch.zeros(B, self.H, device=self.dev)            # residual stream of the step
-        self.h_act = torch.zeros(B, self.H, dtype=self.tdt, device=self.dev)   # its compute-dtype copy
+        # its compute-dtype copy; at batch > 8 the decode step keeps it (and every other GEMM input) in the packed
+        # MFMA-fragment order of include/mmx_hip.h (whole 16-row tiles)
+        self.packed = B >= 4
+        self.h_act = torch.zeros(ops.packed_rows(B), self.H, dtype=self.tdt, device=self.dev)
         self.logits = torch.zeros(B, self.V, device=self.dev)
         self.logp = torch.zeros(B, self.V, device=self.dev)
         self.want_logp = False
@@ -100,36 +103,44 @@ class LlmEngine:
         self._decode = None
 
     # ------------------------------------------------------------------ one transformer pass over `rows` tokens/seq
-    def _layers(self, h, ha, B, rows, pos, block_table):
+    def _layers(self, h, ha, B, rows, pos, block_table, packed=False):
         """h fp32 [B*rows, H] residual stream (in place) and ha, its compute-dtype copy (kept in sync by the
         residual epilogues: it is the A operand of the next RMSNorm-folded projection).
-        pos int32 [B] device, block_table [B, max_pages]."""
+        pos int32 [B] device, block_table [B, max_pages].
+        packed (decode step, batch > 8): ha / att / act live in the packed fragment order; the first projection
+        reads the fp32 residual stream itself (row-major), so no packing pass is needed for the input embedding."""
         dt, H, I = self.dtype, self.H, self.I
         n = B * rows
-        assert n <= 64
+        assert n <= 64 and not (packed and rows != 1)
+        nr = ops.packed_rows(n) if packed else n
         qkv = torch.empty(n, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
         q = torch.empty(n, self.Hq * self.D, dtype=self.tdt, device=self.dev)
-        att = torch.empty(n, self.Hq * self.D, dtype=self.tdt, device=self.dev)
-        act = torch.empty(n, I, dtype=self.tdt, device=self.dev)
+        att = torch.empty(nr, self.Hq * self.D, dtype=self.tdt, device=self.dev)
+        act = torch.empty(nr, I, dtype=self.tdt, device=self.dev)
+        pk = packed
         for l, w in enumerate(self.layers):
-            ops.skinny_gemm(ha, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True, eps=self.eps,
-                            epi=0, out_f32=qkv)
+            first = packed and l == 0
+            ops.skinny_gemm(h if first else ha, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True,
+                            eps=self.eps, epi=0, out_f32=qkv, x_packed=pk and not first)
             if rows == 1:
                 ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
-                                Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab)
+                                Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, out_packed=pk)
             else:
                 ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=rows,
                                   Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
                 ops.paged_attn(q, pos, self.kc[l], self.vc[l], block_table, att, B=B, rows=rows, Hq=self.Hq,
                                Hkv=self.Hkv, page=self.page, dtype=dt)
-            ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha)
-            ops.skinny_gemm(ha, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act)
-            ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha)
+            ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha,
+                            x_packed=pk, out_packed=pk)
+            ops.skinny_gemm(ha, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act,
+                            x_packed=pk, out_packed=pk)
+            ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha,
+                            x_packed=pk, out_packed=pk)
 
-    def _tail(self, B):
+    def _tail(self, B, packed=False):
         """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences."""
         ops.skinny_gemm(self.h_act, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
-                        eps=self.eps, epi=0, out_f32=self.logits)
+                        eps=self.eps, epi=0, out_f32=self.logits, x_packed=packed)
         ops.sample_step(self.logits, self.state, self.out_tokens, self.speech_emb, self.x_in, V=self.V, B=B,
                         eos_id=self.eos, seed=self.seed, top_k=self.top_k, top_p=self.top_p, win_size=self.win_size,
                         tau_r=self.tau_r, sampled=self.sampled, forced=self.forced,
@@ -138,9 +149,10 @@ class LlmEngine:
     def _decode_step(self):
         B = self.B
         self.h.copy_(self.x_in)
-        self.h_act.copy_(self.x_in)
-        self._layers(self.h, self.h_act, B, 1, self.state[ST_POS], self.block_table)
-        self._tail(B)
+        if not self.packed:
+            self.h_act[:B].copy_(self.x_in)
+        self._layers(self.h, self.h_act, B, 1, self.state[ST_POS], self.block_table, packed=self.packed)
+        self._tail(B, packed=self.packed)
 
     # ------------------------------------------------------------------ request setup
     def build_lm_input(self, text, prompt_text, prompt_speech_token, speaker_embed=None):

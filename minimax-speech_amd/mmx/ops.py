@@ -183,12 +183,38 @@ def pack_skinny(w, *, dtype, kscale=None, interleave_half=0):
     return wp
 
 
+X_PACKED, OUT_PACKED = 1, 2
+
+
+def packed_rows(B):
+    """Rows a packed activation buffer holds for batch B (whole 16-row MFMA tiles)."""
+    return (B + 15) // 16 * 16
+
+
+def pack_act(x, dtype):
+    """Host-side statement of the packed activation layout of include/mmx_hip.h (tests / tools): x [B, K] -> flat
+    xp[m][kb][lane][E]."""
+    E = 8 if dtype == BF16 else 4
+    B, K = x.shape
+    R = packed_rows(B)
+    xp = torch.zeros(R, K, dtype=x.dtype, device=x.device)
+    xp[:B] = x
+    return xp.reshape(R // 16, 16, K // (4 * E), 4, E).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+def unpack_act(xp, B, K, dtype):
+    E = 8 if dtype == BF16 else 4
+    R = packed_rows(B)
+    return xp.reshape(R // 16, K // (4 * E), 4, 16, E).permute(0, 3, 1, 2, 4).reshape(R, K)[:B]
+
+
 def skinny_gemm(x, wp, *, B, K, N, dtype, bias=None, rs=False, eps=1e-6, epi=0, out_f32=None, out_act=None,
-                ldx=None, ldo_f=None, ldo_a=None):
+                ldx=None, ldo_f=None, ldo_a=None, x_packed=False, out_packed=False):
     xdt = L.dt_of(x)
+    flags = (X_PACKED if x_packed else 0) | (OUT_PACKED if out_packed else 0)
     check(load().mmx_skinny_gemm(_p(x), xdt, i64(ldx if ldx is not None else K), B, K, N, _p(wp), _p(bias), int(rs),
                                  C.c_float(eps), epi, _p(out_f32), i64(ldo_f if ldo_f is not None else N),
-                                 _p(out_act), i64(ldo_a if ldo_a is not None else N), dtype, stream()),
+                                 _p(out_act), i64(ldo_a if ldo_a is not None else N), dtype, flags, stream()),
           "mmx_skinny_gemm")
 
 
@@ -205,10 +231,10 @@ def paged_attn(q, pos, kc, vc, block_table, out, *, B, rows, Hq, Hkv, page, dtyp
                                 i64(Hq * 64), i64(rows * Hq * 64), dtype, stream()), "mmx_paged_attn")
 
 
-def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None):
+def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None, out_packed=False):
     check(load().mmx_decode_attn(_p(qkv), i64((Hq + 2 * Hkv) * 64), B, Hq, Hkv, 64, _p(inv_freq), _p(rope_tab), _p(pos), _p(kc),
                                  _p(vc), _p(block_table), block_table.shape[1], page, C.c_float(0.125), _p(out),
-                                 i64(Hq * 64), dtype, stream()), "mmx_decode_attn")
+                                 i64(Hq * 64), dtype, int(out_packed), stream()), "mmx_decode_attn")
 
 
 def swiglu(gu, out, *, rows, I, dtype):

@@ -101,23 +101,44 @@ class TtsEngine:
         flow = flow or self.flow
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
+        import os
+        import time
+        tr = os.environ.get("MMX_TIMING") == "3"
+        if tr:
+            torch.cuda.current_stream().synchronize()
+            t0 = time.perf_counter()
         conds = [flow.conditions(toks[b].reshape(1, -1), z, zf, embs[b]) for b in grp]
+        if tr:
+            torch.cuda.current_stream().synchronize()
+            t1 = time.perf_counter()
         xs = flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
+        if tr:
+            torch.cuda.current_stream().synchronize()
+            t2 = time.perf_counter()
         for b, lat in zip(grp, xs):
             T2 = lat.shape[0]
             zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
             ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
             wavs[b] = self.dac.decode_time_major(zt, 1, T2)
+        if tr:
+            torch.cuda.current_stream().synchronize()
+            t3 = time.perf_counter()
+            print(f"[flow_dac_group] n={len(grp)} frames={[2 * toks[b].numel() for b in grp]}: encoder {(t1 - t0) * 1e3:.1f} ms, "
+                  f"cfm {(t2 - t1) * 1e3:.1f} ms, dac {(t3 - t2) * 1e3:.1f} ms", flush=True)
 
     @torch.no_grad()
     def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=(2, 2, 4, 8), max_pad_ratio=2.0,
-                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2) -> List[torch.Tensor]:
+                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=48) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
         conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
         issued by a second host thread on a second HIP stream, so the latency-bound decode loop and the MFMA-bound
         flow overlap on the chip (the reference overlaps the same two stages with its llm_job thread,
-        cli/model.py:332-335).  overlap=False runs the stages back to back.  No prompts (synthetic load)."""
+        cli/model.py:332-335).  overlap=False runs the stages back to back.  No prompts (synthetic load).
+        hold_steps > 0: a finished utterance waits at most that many decode steps for companions of similar length;
+        then its (partial) group is issued, so the flow work of the long utterances is not left for after the last
+        token (the rule counts decode steps, not wall time: the schedule, and with it the set of captured plans, is
+        the same from run to run)."""
         import queue
         import threading
         from .flow import CAPTURE_LOCK
@@ -148,6 +169,8 @@ class TtsEngine:
             # launches are not parked behind the flow's large grids.  The flow stage itself is a chain of short
             # kernels too, so `flow_workers` host threads, each with its own stream and its own plan buffers (the
             # weights are shared), solve different groups concurrently.
+            # (CU-masked flow streams, hipExtStreamCreateWithCUMask, were tried to keep CUs free for the decode loop:
+            # the mask is not honoured on this pool — an 8192^3 GEMM takes the same time with 1/4 and 4/4 of the CUs)
             self._sides = [torch.cuda.Stream(device=self.dev, priority=0) for _ in range(flow_workers)]
             self._flows = [self.flow] + [self.flow.clone_shared() for _ in range(flow_workers - 1)]
             self._hi = torch.cuda.Stream(device=self.dev, priority=-1)
@@ -166,11 +189,18 @@ class TtsEngine:
                             return
                         grp, ev = item
                         side.wait_event(ev)                      # the group's token ids were written on the LM stream
+                        t_in = _time.perf_counter()
                         self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow)
+                        if _trace:
+                            side.synchronize()
+                            print(f"[tts_batch]   worker {wi}: group of {len(grp)} ({[2 * toks[b].numel() for b in grp]} frames) "
+                                  f"{(t_in - self._t0) * 1e3:.0f} -> {(_time.perf_counter() - self._t0) * 1e3:.0f} ms", flush=True)
             except BaseException as e:                           # surfaced by the caller
                 err.append(e)
 
+        import os as _os
         import time as _time
+        _trace = _os.environ.get("MMX_TIMING") == "2"
         self._t0 = _time.perf_counter()
         ths = [threading.Thread(target=worker, args=(wi,), daemon=True) for wi in range(flow_workers)]
         for th in ths:
@@ -179,6 +209,7 @@ class TtsEngine:
         pending: List[int] = []
         seen = set()
         issued = [0]
+        arrived, steps_done = {}, [1]
 
         cur = [self.llm, list(range(B))]                            # active engine, slot -> utterance index
 
@@ -193,6 +224,7 @@ class TtsEngine:
                 seen.add(b)
                 toks[b] = eng.out_tokens[s_, :n[s_]].to(torch.int64)
                 pending.append(b)
+                arrived[b] = steps_done[0]
             if (not final and self.llm_small is not None and eng is self.llm and B - len(seen) <= self.llm_small.B
                     and B - len(seen) > 0):
                 act = [s_ for s_ in range(len(slots)) if slots[s_] not in seen]
@@ -204,8 +236,12 @@ class TtsEngine:
             sizes = group_size if isinstance(group_size, (list, tuple)) else [group_size]
             if not final and groups:
                 want = sizes[min(issued[0] + len(groups) - 1, len(sizes) - 1)]
-                if len(groups[-1]) < want:
+                waited = steps_done[0] - min(arrived[b] for b in groups[-1])
+                if len(groups[-1]) < want and not (hold_steps > 0 and waited >= hold_steps):
                     groups = groups[:-1]                         # keep a partial group open for later arrivals
+            if final and hold_steps > 0 and len(groups) == 1 and len(groups[0]) >= 2 * flow_workers:
+                g0 = groups[0]                                   # last arrivals: one balanced share per worker
+                groups = [g0[w::flow_workers] for w in range(flow_workers)]
             for grp in groups:
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -224,6 +260,7 @@ class TtsEngine:
                     for _ in range(k):
                         cur[0].step()
                 done += k
+                steps_done[0] = done
                 harvest(False)
                 if len(seen) == B:
                     break

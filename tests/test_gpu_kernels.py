@@ -239,6 +239,47 @@ def test_skinny_gemm(env, dt, B, K, N, epi, rs):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,K,N,epi", [(9, 896, 1152, 0), (32, 896, 896, 2), (17, 4864, 896, 2), (32, 896, 4864, 1),
+                                       (64, 896, 4864, 1), (33, 896, 6564, 0)])
+def test_skinny_gemm_packed_activations(env, dt, B, K, N, epi):
+    """MMX_X_PACKED / MMX_OUT_PACKED (MFMA-fragment-ordered activations, batch > 8): bit-identical to the row-major
+    launch — the layout changes how x is fetched and where out_act lands, not the arithmetic."""
+    L, ops = env
+    g = torch.Generator().manual_seed(B * 13 + N)
+    rs = epi != 2
+    x = cast((torch.randn(B, K, generator=g) * 2).cuda(), dt).contiguous()
+    w = (torch.randn((2 * N if epi == 1 else N), K, generator=g) / math.sqrt(K)).cuda()
+    wp = ops.pack_skinny(cast(w, dt).contiguous(), dtype=dt, interleave_half=(N if epi == 1 else 0))
+    res = torch.randn(B, N, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda() if epi == 0 else None
+    tdt = torch.bfloat16 if dt else torch.float32
+    outs = []
+    for pk in (False, True):
+        opk = pk and N % 32 == 0
+        of = res.clone() if epi != 1 else None
+        oa = torch.full((ops.packed_rows(B) * N,), float("nan"), device="cuda", dtype=tdt)
+        ops.skinny_gemm(ops.pack_act(x, dt) if pk else x, wp, B=B, K=K, N=N, dtype=dt, bias=bias, rs=rs, eps=1e-6, epi=epi,
+                        out_f32=of, out_act=oa, x_packed=pk, out_packed=opk)
+        oa = ops.unpack_act(oa, B, N, dt) if opk else oa[:B * N].reshape(B, N)
+        outs.append((of.clone() if of is not None else None, oa.float().clone()))
+    if outs[0][0] is not None:
+        assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.isfinite(outs[1][1]).all()
+
+
+def test_pack_act_roundtrip_and_layout(env):
+    L, ops = env
+    for dt, E in ((1, 8), (0, 4)):
+        x = torch.arange(20 * 64, dtype=torch.float32).reshape(20, 64)
+        xp = ops.pack_act(x, dt)
+        assert torch.equal(ops.unpack_act(xp, 20, 64, dt), x)
+        KB = 4 * E
+        row, col = 17, 45                                   # include/mmx_hip.h: xp[m][kb][g*16 + l16][j]
+        idx = ((((row // 16) * (64 // KB) + col // KB) * 64) + ((col % KB) // E) * 16 + row % 16) * E + col % E
+        assert xp[idx] == x[row, col]
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_rope_kv_paged_attention_matches_oracle(env, dt):
     """prefill of 11 tokens + 3 decode steps through rope_kv_store / paged_attn vs the oracle's Qwen2 attention."""
     from oracle import llm as OL

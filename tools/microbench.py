@@ -113,20 +113,23 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tiles":
         gemm_graph_case(512, N, K, 2, act, out)
 
 
-def skinny_case(B, K, N, epi):
+def skinny_case(B, K, N, epi, packed=False):
     w = (torch.randn((2 * N if epi == 1 else N), K, device="cuda") / 30).bfloat16()
     ws = [ops.pack_skinny(w, dtype=1, interleave_half=(N if epi == 1 else 0)) for _ in range(12)]
     x = torch.randn(B, K, device="cuda").bfloat16()
+    if packed:
+        x = ops.pack_act(x, 1)
     outf = torch.zeros(B, N, device="cuda") if epi != 1 else None
-    outa = torch.empty(B, N, device="cuda", dtype=torch.bfloat16)
+    outa = torch.empty(ops.packed_rows(B), N, device="cuda", dtype=torch.bfloat16)
     it = [0]
 
     def fn():
         it[0] += 1
-        ops.skinny_gemm(x, ws[it[0] % 12], B=B, K=K, N=N, dtype=1, rs=(epi != 2), epi=epi, out_f32=outf, out_act=outa)
+        ops.skinny_gemm(x, ws[it[0] % 12], B=B, K=K, N=N, dtype=1, rs=(epi != 2), epi=epi, out_f32=outf, out_act=outa,
+                        x_packed=packed, out_packed=packed and N % 32 == 0)
     us = graph_time(fn, reps=48)
     nbytes = w.numel() * 2
-    print(f"skinny B={B:3d} K={K:5d} N={N:5d} epi={epi}: {us:7.2f} us  {nbytes / us / 1e3:8.1f} GB/s")
+    print(f"skinny B={B:3d} K={K:5d} N={N:5d} epi={epi} packed={int(packed)}: {us:7.2f} us  {nbytes / us / 1e3:8.1f} GB/s")
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "skinny":
@@ -136,3 +139,9 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "skinny":
         skinny_case(B, 896, 1152, 0)
         skinny_case(B, 896, 896, 2)
         skinny_case(B, 4864, 896, 2)
+    for B in (4, 8, 12, 16, 32, 64):
+        for pk in (False, True):
+            skinny_case(B, 896, 4864, 1, pk)
+            skinny_case(B, 896, 1152, 0, pk)
+            skinny_case(B, 896, 896, 2, pk)
+            skinny_case(B, 4864, 896, 2, pk)

@@ -11,9 +11,12 @@ from mmx import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 H, I, L = 896, 4864, 24
 ws = [ops.pack_skinny((torch.randn(2 * I, H, device="cuda") / 30).bfloat16(), dtype=1, interleave_half=I) for _ in range(L)]
+pk = B >= 4                                      # same activation layout as LlmEngine at this batch size
 x = torch.randn(B, H, device="cuda").bfloat16()
-act = torch.empty(B, I, device="cuda", dtype=torch.bfloat16)
+if pk:
+    x = ops.pack_act(x, 1)
+act = torch.empty(ops.packed_rows(B), I, device="cuda", dtype=torch.bfloat16)
 for it in range(4 * L):
-    ops.skinny_gemm(x, ws[it % L], B=B, K=H, N=I, dtype=1, rs=True, epi=1, out_act=act)
+    ops.skinny_gemm(x, ws[it % L], B=B, K=H, N=I, dtype=1, rs=True, epi=1, out_act=act, x_packed=pk, out_packed=pk)
 torch.cuda.synchronize()
 print("done")
