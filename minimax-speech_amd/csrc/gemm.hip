@@ -18,6 +18,7 @@
 // Fused epilogue: + bias -> activation -> + residual -> * row mask -> store fp32 (residual stream)
 // and/or store T after an optional Snake (the NEXT conv's input activation, dac-vae/layers.py:22),
 // so no elementwise kernel ever round-trips HBM between two convs.
+#include <algorithm>
 #include "common.h"
 #include "gemm.h"
 #include <utility>
@@ -62,11 +63,19 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     // straightforward form costs ~75 VALU instructions per 16-byte load and made the loop VALU-bound):
     // A: pointer + (tap, c) trackers, the pointer jumps by dil*lda - cin elements when c wraps into the next tap;
     // W: pointer += BK.  Row/column validity is decided from small integer trackers.
-    const T* a_ptr[A_CHUNKS];
+    // Loads go through buffer descriptors (base = this batch item's A / W, 2 GiB window): the per-lane part of an
+    // address is a 32-bit byte offset, and a chunk that is padding simply gets an offset outside the window - the
+    // hardware range check returns zeros.  No branch and no select around a load: a load under a branch makes the
+    // compiler lose count of the loads in flight, and it then drains them all (s_waitcnt vmcnt(0)) before every LDS
+    // store, which had collapsed the STAGES-deep prefetch to one k-tile (rocprofv3 PMC: waves parked 48 % of the time).
+    constexpr unsigned OOB = 0x80000000u;
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0, 0x7fffffff, 0x00020000);
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W), 0, 0x7fffffff, 0x00020000);
+    unsigned a_off[A_CHUNKS];
     int a_c[A_CHUNKS], a_tap[A_CHUNKS];
     long a_srow[A_CHUNKS];
     bool a_mok[A_CHUNKS];
-    const long tap_jump = (long)p.dil * p.lda - p.cin;
+    const unsigned tap_jump = (unsigned)(((long)p.dil * p.lda - p.cin) * (long)sizeof(T));
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
         const int id = tid + i * 256;
@@ -75,44 +84,47 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         a_tap[i] = k / p.cin;
         a_c[i] = k % p.cin;
         a_srow[i] = (long)m * p.row_stride + (long)a_tap[i] * p.dil + p.row_off;
-        a_ptr[i] = A + a_srow[i] * p.lda + a_c[i];
+        a_off[i] = (unsigned)((a_srow[i] * p.lda + a_c[i]) * (long)sizeof(T));     // mod 2^32; used only when in range
         a_mok[i] = (m < p.M) && (A_FULL || id < BM * CPR);
     }
-    const T* w_ptr[W_CHUNKS];
-    bool w_ok[W_CHUNKS];
+    unsigned w_off[W_CHUNKS];
 #pragma unroll
     for (int i = 0; i < W_CHUNKS; ++i) {
         const int id = tid + i * 256;
         const int r = id / CPR, kc = (id % CPR) * CH;
         const int n = n0 + r;
-        w_ok[i] = (n < p.N) && (W_FULL || id < BN * CPR);
-        w_ptr[i] = W + (long)(w_ok[i] ? n : 0) * p.ldw + kc;
+        const bool ok = (n < p.N) && (W_FULL || id < BN * CPR);
+        w_off[i] = ok ? (unsigned)(((long)n * p.ldw + kc) * (long)sizeof(T)) : OOB;
     }
     // register-staged prefetch ring: STAGES k-tiles of global loads in flight per workgroup (these GEMMs are
     // short-K and latency bound: M ~ 500-1000 rows, K = 256..1024), 2 LDS buffers, one barrier per k-tile
     constexpr int STAGES = sizeof(T) == 2 ? 4 : 2;
     uint4 a_reg[STAGES][A_CHUNKS], w_reg[STAGES][W_CHUNKS];
     const int K = p.ntaps * p.cin;
+    const int nk = (K + BK - 1) / BK;                  // W is zero padded to nk*BK columns (ldw >= nk*BK)
 
     auto load_tile = [&](int kt, auto slot_c) {       // must be called for kt = 0, 1, 2, ... in order
         constexpr int slot = decltype(slot_c)::value;
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             const bool ok = a_mok[i] && (a_tap[i] < p.ntaps) && (a_srow[i] >= p.row_lo) && (a_srow[i] < p.row_hi);
-            a_reg[slot][i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i]) : make_uint4(0, 0, 0, 0);
-            a_ptr[i] += BK;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, ok ? a_off[i] : OOB, 0, 0);
+            a_reg[slot][i] = make_uint4(v[0], v[1], v[2], v[3]);
+            a_off[i] += BK * (unsigned)sizeof(T);
             a_c[i] += BK;
             while (a_c[i] >= p.cin) {
                 a_c[i] -= p.cin;
                 a_tap[i]++;
                 a_srow[i] += p.dil;
-                a_ptr[i] += tap_jump;
+                a_off[i] += tap_jump;
             }
         }
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
-            w_reg[slot][i] = w_ok[i] ? *reinterpret_cast<const uint4*>(w_ptr[i]) : make_uint4(0, 0, 0, 0);
-            w_ptr[i] += BK;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, kt < nk ? w_off[i] : OOB, 0, 0);
+            w_reg[slot][i] = make_uint4(v[0], v[1], v[2], v[3]);
+            if (w_off[i] != OOB) w_off[i] += BK * (unsigned)sizeof(T);
         }
     };
     auto store_tile = [&](int stage, auto slot_c) {
@@ -137,7 +149,6 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (K + BK - 1) / BK;                  // W is zero padded to nk*BK columns (ldw >= nk*BK)
     auto compute = [&](int st) {
         const T* as = As + (st * BM + wm * (BM / WM) + l16) * LR;
         const T* ws = Ws + (st * BN + wn * (BN / WN) + l16) * LR;
@@ -174,20 +185,30 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         [&]<int... S>(std::integer_sequence<int, S...>) { (fn(std::integral_constant<int, S>{}), ...); }
         (std::make_integer_sequence<int, STAGES>{});
     };
-    // prologue: tiles 0 .. STAGES-1 in flight (load_tile advances the (tap, c) trackers in tile order)
-    for_each_slot([&](auto sc) { if (decltype(sc)::value < nk) load_tile(decltype(sc)::value, sc); });
-    for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+    // prologue: tiles 0 .. STAGES-1 in flight (load_tile advances the (tap, c) trackers in tile order; a tile index
+    // >= nk loads nothing: its offsets are out of the window).  The steady-state loop is branch free, every iteration
+    // issues and retires the same number of loads, so the compiler can wait for exactly the tile it stores
+    // (s_waitcnt vmcnt(2*(STAGES-1)) for 64x64) instead of draining the ring.
+    for_each_slot([&](auto sc) { load_tile(decltype(sc)::value, sc); });
+    int kt0 = 0;
+    for (; kt0 + STAGES <= nk; kt0 += STAGES) {
         for_each_slot([&](auto sc) {
             const int kt = kt0 + decltype(sc)::value;
-            if (kt < nk) {                             // uniform
-                // LDS[kt&1] was last read by compute(kt-2); every wave passed barrier(kt-1) after finishing it
-                store_tile(kt & 1, sc);
-                if (kt + STAGES < nk) load_tile(kt + STAGES, sc);
-                __syncthreads();
-                compute(kt & 1);
-            }
+            // LDS[kt&1] was last read by compute(kt-2); every wave passed barrier(kt-1) after finishing it
+            store_tile(decltype(sc)::value & 1, sc);
+            load_tile(kt + STAGES, sc);
+            __syncthreads();
+            compute(decltype(sc)::value & 1);
         });
     }
+    for_each_slot([&](auto sc) {                       // the last nk % STAGES tiles (already in flight)
+        const int kt = kt0 + decltype(sc)::value;
+        if (kt < nk) {                                 // uniform
+            store_tile(decltype(sc)::value & 1, sc);
+            __syncthreads();
+            compute(decltype(sc)::value & 1);
+        }
+    });
 
     // ------------------------------------------------------------------ fused epilogue
     // The MFMA C layout gives a lane 4 ROWS x 1 column per fragment: storing from it writes 32-64 B row
@@ -339,6 +360,10 @@ static int launch_T(const GemmParams& p, hipStream_t s) {
     MMX_CHECK_ARG(p.bias_mod > 0 && p.alpha_mod > 0 && p.row_stride >= 1);
     MMX_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0);
     MMX_CHECK_ARG(p.out_f32 || p.out_act);
+    // operands are addressed with 32-bit byte offsets inside a 2 GiB buffer window per batch item
+    const long a_rows = std::min<long>(p.row_hi, (long)(p.M - 1) * p.row_stride + (long)(p.ntaps - 1) * p.dil + p.row_off + 1);
+    MMX_CHECK_ARG((double)a_rows * (double)p.lda * sizeof(T) < 2147483000.0 &&
+                  (double)p.N * (double)p.ldw * sizeof(T) < 2147483000.0);
     MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use
     // largest tile that still gives every CU a workgroup (256 CUs); short-K GEMMs want many MFMAs per barrier
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch; };

@@ -468,6 +468,30 @@ __device__ __forceinline__ void load8(const T* p, float o[8]) {
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     }
 }
+// 8 consecutive elements kept RAW in registers (16 B for bf16, 32 B for fp32): a thread holds the K and V chunks of
+// many keys in flight and only converts a chunk when it consumes it
+template <typename T>
+struct Raw8 {
+    uint4 a, b;                                        // b is unused for 2-byte T (the compiler drops it)
+    __device__ __forceinline__ void load(const T* p) {
+        a = *reinterpret_cast<const uint4*>(p);
+        if constexpr (sizeof(T) == 4) b = *reinterpret_cast<const uint4*>(p + 4);
+    }
+    __device__ __forceinline__ void to_float(float o[8]) const {
+        const unsigned w[4] = {a.x, a.y, a.z, a.w};
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[2 * i] = __uint_as_float(w[i] << 16);
+                o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            }
+        } else {
+            const unsigned w2[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i] = __uint_as_float(w[i]); o[4 + i] = __uint_as_float(w2[i]); }
+        }
+    }
+};
 
 template <typename T, bool OPK>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
@@ -528,17 +552,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll 4
-    for (int j = kg; j <= p; j += NG) {
-        float kv[8], vv[8];
-        if (j < p) {
-            const long o = (((long)bts[j / page] * Hkv + hk) * page + j % page) * D + dc * 8;
-            load8<T>(kc + o, kv);
-            load8<T>(vc + o, vv);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kv[e] = kn[dc * 8 + e]; vv[e] = vn[dc * 8 + e]; }
-        }
+    auto consume = [&](const float kv[8], const float vv[8]) {
         float sdot = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) sdot += qv[e] * kv[e];
@@ -551,6 +565,36 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = acc[e] * al + pj * vv[e];
         m = mn;
+    };
+    // cached keys: U keys per thread in flight at a time (the loop is a chain of memory round trips otherwise:
+    // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys
+    constexpr int U = sizeof(T) == 2 ? 12 : 6;
+    for (int j0 = kg; j0 < p; j0 += NG * U) {
+        Raw8<T> rk[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * NG;
+            if (j < p) {
+                const long o = (((long)bts[j / page] * Hkv + hk) * page + j % page) * D + dc * 8;
+                rk[u].load(kc + o);
+                rv[u].load(vc + o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j0 + u * NG < p) {
+                float kv[8], vv[8];
+                rk[u].to_float(kv);
+                rv[u].to_float(vv);
+                consume(kv, vv);
+            }
+        }
+    }
+    if (kg == p % NG) {                                // the new token itself (still in LDS)
+        float kv[8], vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kv[e] = kn[dc * 8 + e]; vv[e] = vn[dc * 8 + e]; }
+        consume(kv, vv);
     }
     if (dc == 0) { gm[kg] = m; gl[kg] = l; }
 #pragma unroll

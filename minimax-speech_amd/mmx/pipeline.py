@@ -239,9 +239,9 @@ class TtsEngine:
                 waited = steps_done[0] - min(arrived[b] for b in groups[-1])
                 if len(groups[-1]) < want and not (hold_steps > 0 and waited >= hold_steps):
                     groups = groups[:-1]                         # keep a partial group open for later arrivals
-            if final and hold_steps > 0 and len(groups) == 1 and len(groups[0]) >= 2 * flow_workers:
+            if final and hold_steps > 0 and len(groups) == 1 and len(groups[0]) >= 2:
                 g0 = groups[0]                                   # last arrivals: one balanced share per worker
-                groups = [g0[w::flow_workers] for w in range(flow_workers)]
+                groups = [g for g in (g0[w::flow_workers] for w in range(flow_workers)) if g]
             for grp in groups:
                 ev = torch.cuda.Event()
                 ev.record(main)

@@ -145,3 +145,33 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "skinny":
             skinny_case(B, 896, 1152, 0, pk)
             skinny_case(B, 896, 896, 2, pk)
             skinny_case(B, 4864, 896, 2, pk)
+
+
+def decode_attn_case(B, ctx, layers=6):
+    """mmx_decode_attn (RoPE + KV append + GQA attention of one new token) at context length ctx, rotating over layers."""
+    Hq, Hkv, D, page = 14, 2, 64, 16
+    max_pages = 2048 // page
+    kc = (torch.randn(layers, B * max_pages + 1, Hkv, page, D, device="cuda") * 0.5).bfloat16()
+    vc = torch.randn_like(kc)
+    bt = torch.arange(B * max_pages, dtype=torch.int32, device="cuda").reshape(B, max_pages).contiguous()
+    pos = torch.full((B,), ctx, dtype=torch.int32, device="cuda")
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device="cuda")
+    inv_freq = (1.0 / (1e6 ** (torch.arange(0, D, 2).float() / D))).cuda()
+    ang = torch.arange(2048, dtype=torch.float32)[:, None] * inv_freq.cpu()[None, :]
+    tab = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous().cuda()
+    out = torch.empty(ops.packed_rows(B), Hq * D, device="cuda", dtype=torch.bfloat16)
+    it = [0]
+
+    def fn():
+        it[0] += 1
+        l = it[0] % layers
+        ops.decode_attn(qkv, inv_freq, pos, kc[l], vc[l], bt, out, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=1, rope_tab=tab,
+                        out_packed=B >= 4)
+    us = graph_time(fn, reps=48)
+    print(f"decode_attn B={B:3d} ctx={ctx:5d}: {us:7.2f} us", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "decode_attn":
+    for B in (1, 16, 32):
+        for ctx in (64, 300, 600, 1500):
+            decode_attn_case(B, ctx)
