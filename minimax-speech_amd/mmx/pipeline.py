@@ -174,7 +174,7 @@ class TtsEngine:
             self._sides = [torch.cuda.Stream(device=self.dev, priority=0) for _ in range(flow_workers)]
             self._flows = [self.flow] + [self.flow.clone_shared() for _ in range(flow_workers - 1)]
             self._hi = torch.cuda.Stream(device=self.dev, priority=-1)
-        qs, err = [queue.Queue() for _ in range(flow_workers)], []     # group k -> worker k % W (deterministic plan reuse)
+        qs, err = [queue.Queue() for _ in range(flow_workers)], []
         caller = torch.cuda.current_stream()
         self._hi.wait_stream(caller)
 
@@ -210,6 +210,8 @@ class TtsEngine:
         seen = set()
         issued = [0]
         arrived, steps_done = {}, [1]
+        free_at = [0.0] * flow_workers
+        STEP_MS, GROUP_MS, FRAME_MS = 1.45, 45.0, 0.037
 
         cur = [self.llm, list(range(B))]                            # active engine, slot -> utterance index
 
@@ -239,13 +241,28 @@ class TtsEngine:
                 waited = steps_done[0] - min(arrived[b] for b in groups[-1])
                 if len(groups[-1]) < want and not (hold_steps > 0 and waited >= hold_steps):
                     groups = groups[:-1]                         # keep a partial group open for later arrivals
+            now = steps_done[0] * STEP_MS
+            assign = None
             if final and hold_steps > 0 and len(groups) == 1 and len(groups[0]) >= 2:
-                g0 = groups[0]                                   # last arrivals: one balanced share per worker
-                groups = [g for g in (g0[w::flow_workers] for w in range(flow_workers)) if g]
+                # last arrivals: longest first, each to the worker predicted to finish it first (the other worker may
+                # still be busy with an earlier group, then splitting only delays the end)
+                fa = [max(free_at[w], now) for w in range(flow_workers)]
+                parts = [[] for _ in range(flow_workers)]
+                for b in sorted(groups[0], key=lambda b: -frames[b]):
+                    w = min(range(flow_workers), key=lambda w: (fa[w] + (0.0 if parts[w] else GROUP_MS) + FRAME_MS * frames[b], w))
+                    fa[w] += (0.0 if parts[w] else GROUP_MS) + FRAME_MS * frames[b]
+                    parts[w].append(b)
+                assign = [w for w in range(flow_workers) if parts[w]]
+                groups = [sorted(parts[w], key=lambda b: (frames[b], b)) for w in assign]
             for grp in groups:
                 ev = torch.cuda.Event()
                 ev.record(main)
-                qs[issued[0] % flow_workers].put((grp, ev))
+                # the worker predicted to be free first.  Prediction, not wall time: decode steps are the clock and a
+                # group costs GROUP_MS + FRAME_MS per frame (fitted to MMX_TIMING=2 traces), so the assignment - and
+                # with it every worker's set of captured plans - repeats from run to run
+                wi = assign.pop(0) if assign else min(range(flow_workers), key=lambda w: (max(free_at[w], now), w))
+                free_at[wi] = max(free_at[wi], now) + GROUP_MS + FRAME_MS * sum(frames[b] for b in grp)
+                qs[wi].put((grp, ev))
                 issued[0] += 1
                 for b in grp:
                     pending.remove(b)
