@@ -101,6 +101,10 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
     float ssq[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) ssq[m] = 0.f;
+    constexpr bool SSQ_MFMA = BF && sizeof(TX) == 2 && EPI != 2;     // EPI 2 (residual projections) never normalises
+    float4_t accd[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) accd[m] = float4_t{0.f, 0.f, 0.f, 0.f};
     // epilogue operands are fetched up front (by the wave that will run the epilogue) so they do not add a
     // dependent memory round trip after the reduction
     float pre_bias = 0.f, pre_res[MT][4];
@@ -162,7 +166,14 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
 #pragma unroll
                         for (int e = 0; e < E; ++e) xv[e] = __uint_as_float((raw[0][e / 2] >> ((e & 1) * 16)) << 16);
                     }
-                    if (rs) {
+                    if constexpr (SSQ_MFMA) {
+                        // sum of squares on the matrix pipe: the fragment times itself is X X^T, whose diagonal is the
+                        // per-row sum of squares (bf16 products are exact in fp32); 16 VALU ops per fragment otherwise
+                        if (rs) {
+                            const short8_t xf = *reinterpret_cast<const short8_t*>(&raw[0]);
+                            accd[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, xf, accd[m], 0, 0, 0);
+                        }
+                    } else if (rs) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) ssq[m] += xv[e] * xv[e];
                     }
@@ -189,6 +200,18 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
                         }
                     }
                 }
+            }
+        }
+    }
+    if constexpr (SSQ_MFMA) {
+        // C layout: lane (g, l16) holds rows 4g..4g+3 of column l16; the diagonal element of row l16 sits on the lane
+        // with g == l16 / 4, register l16 % 4.  The butterfly below then spreads it to the other three k-groups.
+        if (rs) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int r = l16 & 3;
+                const float d = r == 0 ? accd[m][0] : (r == 1 ? accd[m][1] : (r == 2 ? accd[m][2] : accd[m][3]));
+                ssq[m] = (l16 >> 2) == g ? d : 0.f;
             }
         }
     }
@@ -272,6 +295,9 @@ static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, con
     int ksplit = 1;
     while (ksplit < 8 && (nkb + ksplit - 1) / ksplit > KSr) ksplit *= 2;
     int waves = ksplit >= 4 ? ksplit : 4;
+    // batch > 16 and a wide N (gate/up): two tiles per workgroup - the waves of the same k slice then share their
+    // activation fragments through the L1 (tools/skinny_lab.hip: 9.06 -> 8.55 us)
+    if (mt >= 2 && ksplit <= 4 && ntiles >= 256) waves = 8;
     int tpb = waves / ksplit;
     dim3 grid((ntiles + tpb - 1) / tpb), block(waves * 64);
     constexpr int NB = EPI == 1 ? 2 : 1;

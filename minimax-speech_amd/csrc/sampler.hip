@@ -138,21 +138,14 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
             p_lds[tid + i * SAMP_THREADS] = x[i];
         }
 
-    // nucleus candidates = prefix of the stable descending sort (value desc, index asc).
-    // (1) every thread's local maximum; (2) wave 0 finds the top_k-th largest of the 256 maxima (T): at least top_k
-    // elements are >= T, so every global top_k element is >= T; (3) all elements >= T are pushed to a small LDS
-    // list; (4) wave 0 extracts the sorted prefix from that list with wave arg-max rounds, accumulating the fp32
-    // running sum in the reference's order (common.py:124-131).  No workgroup barrier inside the loops.
-    auto wave_argmax = [&](ArgMax v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            ArgMax y;
-            y.v = __shfl_xor(v.v, o, 64);
-            y.i = __shfl_xor(v.i, o, 64);
-            v = better(v, y);
-        }
-        return v;
-    };
+    // nucleus candidates = prefix of the stable descending sort (value desc, index asc), found by RANK COUNTING
+    // rather than by repeated arg-max rounds (50 dependent wave reductions through ds_bpermute cost ~30 us per token):
+    // (1) every thread's local maximum; (2) each thread counts how many of the 256 maxima precede its own in the sort
+    // order - the one with rank top_k-1 is a threshold T with at least top_k elements >= T, so every global top_k
+    // element is >= T; (3) all elements >= T are pushed to a small LDS list; (4) each list entry's rank inside the list
+    // is its position in the sorted prefix; (5) the fp32 running sum walks that prefix in the reference's order
+    // (common.py:124-131).  Ranks are unique because indices are.
+    auto precedes = [](float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); };
     {
         ArgMax a{-2.f, 0x7fffffff};
 #pragma unroll
@@ -162,21 +155,12 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     }
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
-    if (tid < 64) {
-        ArgMax c[SAMP_THREADS / 64];
-#pragma unroll
-        for (int u = 0; u < SAMP_THREADS / 64; ++u) c[u] = ArgMax{lmax_p[tid + u * 64], lmax_i[tid + u * 64]};
-        ArgMax kth{0.f, 0};
-        for (int rnd = 0; rnd < top_k; ++rnd) {
-            ArgMax m = c[0];
-#pragma unroll
-            for (int u = 1; u < SAMP_THREADS / 64; ++u) m = better(m, c[u]);
-            kth = wave_argmax(m);
-#pragma unroll
-            for (int u = 0; u < SAMP_THREADS / 64; ++u)
-                if (c[u].i == kth.i) c[u].v = -2.f;
-        }
-        if (tid == 0) { sh_thr_v = kth.v; sh_thr_i = kth.i; }
+    {
+        const float mv = lmax_p[tid];
+        const int mi = lmax_i[tid];
+        int rk = 0;
+        for (int j = 0; j < SAMP_THREADS; ++j) rk += precedes(lmax_p[j], lmax_i[j], mv, mi) ? 1 : 0;
+        if (rk == min(top_k, SAMP_THREADS) - 1) { sh_thr_v = mv; sh_thr_i = mi; }
     }
     __syncthreads();
     {
@@ -184,8 +168,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
 #pragma unroll
         for (int i = 0; i < SAMP_MAXV; ++i) {
             const ArgMax e{x[i], tid + i * SAMP_THREADS};
-            // e >= thr in the sort order  <=>  !(thr strictly better than e)
-            const bool take = e.i < V && !(thr.v > e.v || (thr.v == e.v && thr.i < e.i));
+            // e >= thr in the sort order  <=>  !(thr strictly precedes e)
+            const bool take = e.i < V && !precedes(thr.v, thr.i, e.v, e.i);
             if (take) {
                 int slot = atomicAdd(&sh_cnt, 1);
                 if (slot < SAMP_LIST) { list_p[slot] = e.v; list_i[slot] = e.i; }
@@ -193,29 +177,24 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
         }
     }
     __syncthreads();
-    if (tid < 64) {
-        const int cnt = min(sh_cnt, SAMP_LIST);
-        ArgMax c[SAMP_LIST / 64];
-#pragma unroll
-        for (int u = 0; u < SAMP_LIST / 64; ++u) {
-            const int id = tid + u * 64;
-            c[u] = id < cnt ? ArgMax{list_p[id], list_i[id]} : ArgMax{-2.f, 0x7fffffff};
-        }
+    const int cnt = min(sh_cnt, SAMP_LIST);
+    for (int id = tid; id < cnt; id += SAMP_THREADS) {
+        const float mv = list_p[id];
+        const int mi = list_i[id];
+        int rk = 0;
+        for (int j = 0; j < cnt; ++j) rk += precedes(list_p[j], list_i[j], mv, mi) ? 1 : 0;
+        if (rk < SAMP_MAXK) { cand_p[rk] = mv; cand_i[rk] = mi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
         float cum = 0.f;
         int nc = 0;
-        while (cum < top_p && nc < top_k) {
-            ArgMax m = c[0];
-#pragma unroll
-            for (int u = 1; u < SAMP_LIST / 64; ++u) m = better(m, c[u]);
-            m = wave_argmax(m);
-            if (tid == 0) { cand_p[nc] = m.v; cand_i[nc] = m.i; }
-#pragma unroll
-            for (int u = 0; u < SAMP_LIST / 64; ++u)
-                if (c[u].i == m.i) c[u].v = -2.f;
-            cum += m.v;                                // fp32 running sum, same order as common.py:127
+        const int lim = min(min(top_k, SAMP_MAXK), cnt);
+        while (cum < top_p && nc < lim) {
+            cum += cand_p[nc];                         // fp32 running sum, same order as common.py:127
             nc++;
         }
-        if (tid == 0) sh_n = nc;
+        sh_n = nc;
     }
     __syncthreads();
     const int nc = sh_n;

@@ -175,3 +175,27 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "decode_attn"
     for B in (1, 16, 32):
         for ctx in (64, 300, 600, 1500):
             decode_attn_case(B, ctx)
+
+
+def sampler_case(B, scale):
+    """mmx_sample_step on random logits (std `scale`: 3 = the peaked synthetic LM, 0.5 = nearly flat)."""
+    V, H = 6564, 896
+    logits = torch.randn(B, V, device="cuda") * scale
+    emb = torch.randn(V, H, device="cuda")
+    x = torch.zeros(B, H, device="cuda")
+    out = torch.zeros(B, 4096, dtype=torch.int32, device="cuda")
+    st0 = torch.zeros(8, B, dtype=torch.int32, device="cuda")
+    st0[4] = 1 << 20                                     # min_len: never stop on eos
+    st0[5] = 1 << 20
+    st = st0.clone()
+
+    def fn():
+        ops.sample_step(logits, st, out, emb, x, V=V, B=B, eos_id=6561, seed=1)
+    us = graph_time(fn, reps=40)
+    print(f"sampler B={B:3d} logit std {scale}: {us:7.2f} us", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sampler":
+    for B in (1, 32):
+        for sc in (3.0, 0.5):
+            sampler_case(B, sc)
