@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="batch", choices=["batch", "single"])
+    ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="2,2,4,8", help="utterances per batched flow ODE solve (ramp: k-th group)")
     ap.add_argument("--pad-ratio", type=float, default=2.0, help="max length ratio inside one flow group")
@@ -145,11 +145,16 @@ def main():
     from mmx.dist import gather_audio, shard_utterances
     dt = 1 if a.dtype == "bf16" else 0
     llm_sd, flow_sd, dac_sd = build_weights(0)
-    PER_GPU = 1 if a.workload == "single" else a.per_gpu
-    eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=dt, device=f"cuda:{local}", max_batch=PER_GPU, max_ctx=640)
+    PER_GPU = 1 if a.workload in ("single", "longform") else a.per_gpu
+    eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=dt, device=f"cuda:{local}", max_batch=PER_GPU,
+                    max_ctx=2048 if a.workload == "longform" else 640)
     del llm_sd, flow_sd, dac_sd
     emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).cuda()
-    if a.workload == "single":
+    if a.workload == "longform":
+        # BASELINE config 5: one 60 s utterance per GPU, streaming (25-token hops, chunk-causal flow over all tokens so
+        # far at every hop, captured decode step); bf16 attention (the fp8 MFMA variant is not built)
+        lens_all = [1500] * world
+    elif a.workload == "single":
         # BASELINE config 3 / SURVEY 8d.3: 48 random text ids, no prompt, exactly 250 decode steps (10 s of audio)
         lens_all = [250] * world
     else:
@@ -159,11 +164,22 @@ def main():
     mine = shard_utterances(lens_all, world)[rank]
     lens = [lens_all[i] for i in mine]
     g = torch.Generator().manual_seed(2)
-    all_text = [torch.randint(0, 151936, (1, 48), generator=g) for _ in range(len(lens_all))]
+    all_text = [torch.randint(0, 151936, (1, 290 if a.workload == "longform" else 48), generator=g) for _ in range(len(lens_all))]
     texts = [all_text[i].cuda() for i in mine]
     max_samples = 2 * max(lens_all) * eng.hop
 
+    first_chunk_ms = []
+
     def step():
+        if a.workload == "longform":
+            t_in = time.perf_counter()
+            n = 0
+            for k, w in enumerate(eng.tts_stream(texts[0], emb, seed=0, exact_steps=lens[0])):
+                if k == 0:
+                    torch.cuda.current_stream().synchronize()
+                    first_chunk_ms.append((time.perf_counter() - t_in) * 1e3)
+                n += w.shape[-1]
+            return n
         wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps)
         if world > 1:
             gather_audio(wavs, mine, len(lens_all), max_samples)      # the path's one exchange step (RCCL all-gather)
@@ -197,7 +213,11 @@ def main():
         samples = float(tot.item())
     audio_s = samples / SAMPLE_RATE
     if rank == 0:
-        if a.workload == "single":
+        if a.workload == "longform":
+            wl = ("BASELINE config 5: one 60 s utterance per GPU per step, streaming synthesis (290 text ids, 1500 AR decode "
+                  "steps on the captured decode graph, 25-token hops: chunk-causal flow over all tokens so far + DAC of the new "
+                  f"frames), bf16 attention; first chunk after {sum(first_chunk_ms[-a.steps:]) / max(1, a.steps):.0f} ms")
+        elif a.workload == "single":
             wl = ("BASELINE config 3: one 10 s utterance per GPU per step (48 text ids, 250 AR decode steps, flow 500 frames "
                   "x 10 Euler steps with CFG, DAC 240000 samples)")
         else:

@@ -80,6 +80,60 @@ class TtsEngine:
         pt = flow_prompt_speech_token if flow_prompt_speech_token is not None else z
         return self.token2wav(toks.reshape(1, -1), pt, pf, flow_embedding)
 
+    @torch.no_grad()
+    def tts_stream(self, text, flow_embedding, seed=0, exact_steps=None, token_hop=25, dac_overlap=8):
+        """Streaming synthesis of one (long) utterance: BASELINE config 5 / cli/model.py:336-369 (`stream=True`).
+        The AR decode runs ahead on its own stream (captured decode step); every `token_hop` tokens (+ the flow's
+        look-ahead) the chunk-causal flow is solved over all tokens so far, as the reference does, and the DAC decoder
+        renders the new frames with `dac_overlap` frames of left context.  Yields waveform chunks [1, n] (device)."""
+        from .llm import ST_FIN, ST_NOUT
+        assert self.llm.B == 1
+        z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
+        zf = torch.zeros(1, 0, 80, device=self.dev)
+        x = self.llm.build_lm_input(text, z, z)
+        n_text = int(text.numel())
+        mn = exact_steps if exact_steps is not None else n_text * 2
+        mx = exact_steps if exact_steps is not None else n_text * 20
+        if not hasattr(self, "_lm_stream"):
+            self._lm_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+        lm, caller = self._lm_stream, torch.cuda.current_stream()
+        lm.wait_stream(caller)
+        L = self.flow.L
+        with torch.cuda.stream(lm):
+            self.llm.start([x], [mn], [mx], seed=seed)
+        done, offset, finished = 1, 0, False
+
+        def render(n_tok, finalize):
+            nonlocal offset
+            ev = torch.cuda.Event()
+            ev.record(lm)
+            caller.wait_event(ev)                          # tokens [0, n_tok) are written
+            tok = self.llm.out_tokens[0:1, :n_tok].to(torch.int64)
+            lat = self.flow.inference_time_major(tok, z, zf, flow_embedding, streaming=True, finalize=finalize)
+            start = offset * 2
+            ctx = min(dac_overlap, start)
+            seg = lat[start - ctx:]
+            T2 = seg.shape[0]
+            zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
+            ops.copy2d(seg, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
+            wav = self.dac.decode_time_major(zt, 1, T2)[:, 0, ctx * self.hop:]
+            return wav
+
+        while not finished:
+            want = offset + token_hop + L                  # tokens needed for the next chunk
+            with torch.cuda.stream(lm):
+                while done < mx and done < want + 8:       # keep the decode a few tokens ahead of the renderer
+                    self.llm.step()
+                    done += 1
+                st = self.llm.state[:, 0].tolist()         # D2H copy on the LM stream: waits for the steps above
+            n_out, finished = st[ST_NOUT], bool(st[ST_FIN]) or done >= mx
+            while n_out - offset >= token_hop + L:
+                yield render(offset + token_hop + L, finalize=False)
+                offset += token_hop
+            if finished:
+                yield render(n_out, finalize=True)
+        caller.wait_stream(lm)
+
     # ------------------------------------------------------------------ batch of independent utterances
     def _groups(self, order, frames, group_size, max_pad_ratio, frame_quantum, first=0):
         """Consecutive runs of `order` (sorted by length) whose lengths are within the padding budget.
