@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--flow-group", default="2,2,4,8", help="utterances per batched flow ODE solve (ramp: k-th group)")
     ap.add_argument("--pad-ratio", type=float, default=2.0, help="max length ratio inside one flow group")
     ap.add_argument("--flow-workers", type=int, default=2, help="host threads / streams solving flow groups concurrently")
+    ap.add_argument("--poll-every", type=int, default=8, help="decode steps between two polls of the finished flags")
     ap.add_argument("--hold-steps", type=int, default=48, help="decode steps a finished utterance waits for a fuller flow group")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
@@ -180,7 +181,7 @@ def main():
                     first_chunk_ms.append((time.perf_counter() - t_in) * 1e3)
                 n += w.shape[-1]
             return n
-        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps)
+        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps, poll_every=a.poll_every)
         if world > 1:
             gather_audio(wavs, mine, len(lens_all), max_samples)      # the path's one exchange step (RCCL all-gather)
         return sum(w.shape[-1] for w in wavs)

@@ -38,7 +38,7 @@ class LlmEngine:
             # (used to continue a partly finished batch at a smaller, cheaper batch size: see compact_from)
             o = share_from
             for k in ("n_layers", "H", "I", "layers", "wdec", "bdec", "embed_tokens", "speech_emb", "llm_emb", "inv_freq",
-                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page"):
+                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page", "pf_layers"):
                 setattr(self, k, getattr(o, k))
             self.B = max_batch
             self.block_table = torch.zeros(self.B, self.max_pages, dtype=torch.int32, device=self.dev)
@@ -49,13 +49,20 @@ class LlmEngine:
         self.n_layers = len({k.split(".")[4] for k in sd if k.startswith(prefix + ".layers.")})
         self.H = sd[prefix + ".norm.weight"].shape[0]
         self.I = sd[prefix + ".layers.0.mlp.gate_proj.weight"].shape[0]
-        self.layers = []
+        self.layers, self.pf_layers = [], []
         for l in range(self.n_layers):
             p = f"{prefix}.layers.{l}"
             a = p + ".self_attn"
             wqkv = torch.cat([f(a + ".q_proj.weight"), f(a + ".k_proj.weight"), f(a + ".v_proj.weight")], 0)
             bqkv = torch.cat([f(a + ".q_proj.bias"), f(a + ".k_proj.bias"), f(a + ".v_proj.bias")], 0).contiguous()
             wgu = torch.cat([f(p + ".mlp.gate_proj.weight"), f(p + ".mlp.up_proj.weight")], 0)
+            if max_batch >= 4:
+                # row-major copies for the batched prompt pass (_prefill_batch): many prompts at once are an ordinary
+                # tall GEMM over weights read once, not max_batch passes of the weight-streaming decode kernels
+                self.pf_layers.append(dict(
+                    wqkv=ops.pack_linear(c(wqkv), dt), wo=ops.pack_linear(c(f(a + ".o_proj.weight")), dt),
+                    wgu=ops.pack_linear(c(wgu), dt), wdown=ops.pack_linear(c(f(p + ".mlp.down_proj.weight")), dt),
+                    g1=f(p + ".input_layernorm.weight"), g2=f(p + ".post_attention_layernorm.weight")))
             self.layers.append(dict(
                 wqkv=ops.pack_skinny(c(wqkv), dtype=dt, kscale=f(p + ".input_layernorm.weight")), bqkv=bqkv,
                 wo=ops.pack_skinny(c(f(a + ".o_proj.weight")), dtype=dt),
@@ -204,15 +211,16 @@ class LlmEngine:
         self.state.copy_(st)
         self.sampled.fill_(-1)
         for b, x in enumerate(lm_inputs):
+            assert x.shape[0] + max_lens[b] <= self.max_pages * self.page, "sequence exceeds the KV cache"
+        if B >= 4 and self.pf_layers:
+            self._prefill_batch(lm_inputs)
+            lm_inputs = []
+        for b, x in enumerate(lm_inputs):
             L = x.shape[0]
-            assert L + max_lens[b] <= self.max_pages * self.page, "sequence exceeds the KV cache"
             x = x.to(self.dev, torch.float32).contiguous()
             for c0 in range(0, L, 64):
                 c1 = min(L, c0 + 64)
-                hc = x[c0:c1].clone()
-                hca = hc.to(self.tdt)
-                pos = torch.tensor([c0], dtype=torch.int32, device=self.dev)
-                self._layers(hc, hca, 1, c1 - c0, pos, self.block_table[b:b + 1])
+                hc, hca = self._prefill_chunk(x[c0:c1], c0, b)
             self.h[b].copy_(hc[-1])
             self.h_act[b].copy_(hca[-1])
             self.state[ST_POS, b] = L - 1                # the sampler's +1 makes it L (= rows in the cache)
@@ -222,6 +230,70 @@ class LlmEngine:
         elif self._graph_key != (self.forced is None, want_logp, self.seed):
             self._decode = Graphed(self._decode_step, self.use_graphs)      # baked arguments changed: re-record
         self._graph_key = (self.forced is None, want_logp, self.seed)
+
+    def _prefill_batch(self, lm_inputs):
+        """All prompts in one pass per layer: rows = B x Lmax (shorter prompts are zero padded; a padded row only adds
+        cache entries past its prompt, which the decode steps overwrite before they are read).  RMSNorm, projections
+        on the windowed GEMM (weights read once for every prompt), RoPE + KV store + causal attention over the paged
+        cache, SwiGLU: 9 launches per layer for the whole batch (32 prompts of 50 rows through the decode kernels cost
+        ~58 ms of GPU time: the 1 GB of weights was streamed once per prompt)."""
+        B, dt, H, I = self.B, self.dtype, self.H, self.I
+        Ls = [int(x.shape[0]) for x in lm_inputs]
+        Lm = max(Ls)
+        R = B * Lm
+        h = torch.zeros(B, Lm, H, device=self.dev)
+        for b, x in enumerate(lm_inputs):
+            h[b, :Ls[b]].copy_(x)
+        h = h.reshape(R, H)
+        a = torch.empty(R, H, dtype=self.tdt, device=self.dev)
+        qkv = torch.empty(R, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
+        q = torch.empty(R, self.Hq * self.D, dtype=self.tdt, device=self.dev)
+        att = torch.empty(R, self.Hq * self.D, dtype=self.tdt, device=self.dev)
+        gu = torch.empty(R, 2 * I, device=self.dev)
+        act = torch.empty(R, I, dtype=self.tdt, device=self.dev)
+        pos = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        for l, (w, ws) in enumerate(zip(self.pf_layers, self.layers)):
+            ops.rownorm(h, w["g1"], None, self.eps, rows=R, C_=H, rms=True, out_act=a, dtype=dt)
+            ops.linear(a, w["wqkv"], H, dtype=dt, bias=ws["bqkv"], out_f32=qkv)
+            ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], self.block_table, B=B, rows=Lm,
+                              Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
+            ops.paged_attn(q, pos, self.kc[l], self.vc[l], self.block_table, att, B=B, rows=Lm, Hq=self.Hq,
+                           Hkv=self.Hkv, page=self.page, dtype=dt)
+            ops.linear(att, w["wo"], self.Hq * self.D, dtype=dt, residual=h, out_f32=h)
+            ops.rownorm(h, w["g2"], None, self.eps, rows=R, C_=H, rms=True, out_act=a, dtype=dt)
+            ops.linear(a, w["wgu"], H, dtype=dt, out_f32=gu)
+            ops.swiglu(gu, act, rows=R, I=I, dtype=dt)
+            ops.linear(act, w["wdown"], I, dtype=dt, residual=h, out_f32=h)
+        last = torch.tensor([b * Lm + Ls[b] - 1 for b in range(B)], dtype=torch.long, device=self.dev)
+        hl = h.index_select(0, last)
+        self.h[:B].copy_(hl)
+        self.h_act[:B].copy_(hl)
+        self.state[ST_POS].copy_(torch.tensor([L - 1 for L in Ls], dtype=torch.int32))
+
+    def _prefill_chunk(self, xc, pos0, b):
+        """<= 64 prompt rows of sequence b through the layers at cache position pos0.  One hipGraph per chunk length over
+        static staging buffers: a 50-row prompt is 144 launches, which the host issues in ~1.5 ms eagerly (32 prompts
+        in front of a batch: ~50 ms with the GPU mostly idle) and the graph replays in ~0.4 ms."""
+        rows = xc.shape[0]
+        if not self.use_graphs:
+            hc = xc.clone()
+            hca = hc.to(self.tdt)
+            pos = torch.tensor([pos0], dtype=torch.int32, device=self.dev)
+            self._layers(hc, hca, 1, rows, pos, self.block_table[b:b + 1])
+            return hc, hca
+        if not hasattr(self, "_pf"):
+            self._pf = dict(h=torch.zeros(64, self.H, device=self.dev), ha=torch.zeros(64, self.H, dtype=self.tdt, device=self.dev),
+                            pos=torch.zeros(1, dtype=torch.int32, device=self.dev),
+                            bt=torch.zeros(1, self.max_pages, dtype=torch.int32, device=self.dev), graphs={})
+        pf = self._pf
+        pf["h"][:rows].copy_(xc)
+        pf["ha"][:rows].copy_(xc)
+        pf["pos"].fill_(pos0)
+        pf["bt"].copy_(self.block_table[b:b + 1])
+        if rows not in pf["graphs"]:
+            pf["graphs"][rows] = Graphed(lambda r=rows: self._layers(pf["h"][:r], pf["ha"][:r], 1, r, pf["pos"], pf["bt"]), True)
+        pf["graphs"][rows]()
+        return pf["h"][:rows], pf["ha"][:rows]
 
     def step(self):
         self._decode()
@@ -313,10 +385,7 @@ class LlmEngine:
             x = x.to(self.dev, torch.float32).contiguous()
             for c0 in range(0, n, 64):
                 c1 = min(n, c0 + 64)
-                hc = x[c0:c1].clone()
-                hca = hc.to(self.tdt)
-                pos = torch.tensor([s["rows"] + c0], dtype=torch.int32, device=self.dev)
-                self._layers(hc, hca, 1, c1 - c0, pos, self.block_table[0:1])
+                hc, hca = self._prefill_chunk(x[c0:c1], s["rows"] + c0, 0)
             self.h[0].copy_(hc[-1])
             self.h_act[0].copy_(hca[-1])
             self._upload_state(s["rows"] + n - 1, ignore_eos)

@@ -244,6 +244,10 @@ class TtsEngine:
                         grp, ev = item
                         side.wait_event(ev)                      # the group's token ids were written on the LM stream
                         t_in = _time.perf_counter()
+                        if _os.environ.get("MMX_SKIP_FLOW"):     # diagnosis: the decode loop alone, same control flow
+                            for b in grp:
+                                wavs[b] = torch.zeros(1, 1, 2 * toks[b].numel() * self.hop, device=self.dev)
+                            continue
                         self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow)
                         if _trace:
                             side.synchronize()

@@ -189,3 +189,30 @@ def test_tts_stream_equals_token_sequence_and_length():
     toks_stream = eng.llm.out_tokens[0, :n_out].tolist()
     toks_off = eng.generate_tokens([text], seed=3, exact_steps=90)[0].tolist()
     assert toks_stream == toks_off
+
+
+@pytest.mark.parametrize("dt,tol", [(0, 2e-3), (1, 0.25)])
+def test_batched_prefill_matches_per_sequence_prefill(dt, tol):
+    """LlmEngine._prefill_batch (all prompts in one tall-GEMM pass, ragged lengths zero padded) against the
+    per-sequence prefill through the decode kernels: same first-step logits, and in the fp32 build the same tokens."""
+    from mmx import shapes, synth
+    from mmx.llm import LlmEngine
+    sd = synth.synth_state_dict(shapes.llm_manifest(layers=2), 0)
+    g = torch.Generator().manual_seed(11)
+    B = 5
+    texts = [torch.randint(0, 151936, (1, n), generator=g).cuda() for n in (7, 30, 12, 70, 3)]
+    z = torch.zeros(1, 0, dtype=torch.long, device="cuda")
+    outs = []
+    for batched in (True, False):
+        eng = LlmEngine(sd, dtype=dt, max_batch=B, max_ctx=256)
+        if not batched:
+            eng.pf_layers = []
+        xs = [eng.build_lm_input(t, z, z) for t in texts]
+        eng.start(xs, [20] * B, [20] * B, seed=5)
+        logits = eng.logits.clone()
+        toks = eng.run(20)
+        outs.append((logits, toks))
+    err = (outs[0][0] - outs[1][0]).abs().max().item()
+    assert err < tol, err
+    if dt == 0:
+        assert outs[0][1] == outs[1][1]
