@@ -34,6 +34,26 @@ import threading
 CAPTURE_LOCK = threading.RLock()     # graph capture is serialised against every other launch of the process
 
 
+_capture_primed = set()
+
+
+def _prime_capture_state(dev):
+    """The first hipGraph capture of a process allocates the CUDA generator's capture-state tensors and every later
+    capture updates them in place.  If that first capture runs under torch.inference_mode() (the drop-in modules keep
+    the reference's @torch.inference_mode() decorators) they are inference tensors, and a later capture outside
+    inference mode fails ("Inplace update to inference tensor outside InferenceMode").  So the very first capture
+    is a trivial one made with inference mode switched off."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key in _capture_primed:
+        return
+    with torch.inference_mode(False):
+        t = torch.zeros(1, device=f"cuda:{key}")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            t.add_(1.0)
+    _capture_primed.add(key)
+
+
 class Graphed:
     """Runs `fn` eagerly once (warm-up), then records it into a hipGraph and replays it.  Capture takes
     CAPTURE_LOCK (callers that launch from another thread take it around their own launches), and uses the
@@ -51,6 +71,7 @@ class Graphed:
                 return self.fn()
             with CAPTURE_LOCK:
                 torch.cuda.synchronize()
+                _prime_capture_state(torch.cuda.current_device())
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.fn()
