@@ -137,11 +137,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # MMX_BENCH_REHEARSE=1: multi-rank rehearsal on a ONE-GPU box - every rank uses cuda:0, collectives run on gloo
+    # over host copies.  Exercises the launch contract, sharding, barriers and the gather; never use it for numbers.
+    rehearse = bool(os.environ.get("MMX_BENCH_REHEARSE")) and world > 1
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    cdev = "cpu" if rehearse else "cuda"
     from mmx.pipeline import TtsEngine, TOKEN_RATE, SAMPLE_RATE
     from mmx.dist import gather_audio, shard_utterances
     dt = 1 if a.dtype == "bf16" else 0
@@ -182,8 +191,8 @@ def main():
                 n += w.shape[-1]
             return n
         wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps, poll_every=a.poll_every)
-        if world > 1:
-            gather_audio(wavs, mine, len(lens_all), max_samples)      # the path's one exchange step (RCCL all-gather)
+        if world > 1:                                              # the path's one exchange step (RCCL all-gather)
+            gather_audio([w.cpu() for w in wavs] if rehearse else wavs, mine, len(lens_all), max_samples)
         return sum(w.shape[-1] for w in wavs)
 
     def fence():
@@ -206,10 +215,10 @@ def main():
     fence()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        t = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-        tot = torch.tensor([samples], device="cuda", dtype=torch.float64)
+        tot = torch.tensor([samples], device=cdev, dtype=torch.float64)
         dist.all_reduce(tot)
         samples = float(tot.item())
     audio_s = samples / SAMPLE_RATE
