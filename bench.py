@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--pad-ratio", type=float, default=2.0, help="max length ratio inside one flow group")
     ap.add_argument("--flow-workers", type=int, default=2, help="host threads / streams solving flow groups concurrently")
     ap.add_argument("--poll-every", type=int, default=8, help="decode steps between two polls of the finished flags")
-    ap.add_argument("--hold-steps", type=int, default=48, help="decode steps a finished utterance waits for a fuller flow group")
+    ap.add_argument("--hold-steps", type=int, default=40, help="decode steps a finished utterance waits for a fuller flow group")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", 0))

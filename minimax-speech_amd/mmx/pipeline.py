@@ -182,7 +182,7 @@ class TtsEngine:
 
     @torch.no_grad()
     def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=(2, 2, 4, 8), max_pad_ratio=2.0,
-                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=48) -> List[torch.Tensor]:
+                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=40) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
         conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
