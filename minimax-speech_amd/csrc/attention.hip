@@ -266,21 +266,24 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         auto softmax_tile = [&](auto mask_c, auto mf_c) {
             constexpr bool MASK = decltype(mask_c)::value;
             constexpr int mf = decltype(mf_c)::value;
+            // the scale (log2 units, > 0) is not applied to the scores: max(s) * sc2 == max(s * sc2), and the exponent
+            // below is one fma, exp2(s * sc2 - m); saves a multiply per score in a VALU-bound loop
             float mx = -INFINITY;
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = s[mf][nf][r] * sc2;
+                    float x = s[mf][nf][r];
                     if constexpr (MASK) {
                         const int j = j0 + nf * 16 + 4 * g + r;
                         x = (j < lim[mf] && kvis[nf][r]) ? x : -INFINITY;
+                        s[mf][nf][r] = x;
                     }
-                    s[mf][nf][r] = x;
                     mx = fmaxf(mx, x);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx *= sc2;
             // lazy rescale (cdna_hip_programming.md T13): keep the old running max while it is at most 2^6 below the
             // new one for EVERY query of the wave; p then reaches at most 64 (fine in bf16 / fp32 sums) and the O
             // accumulators (AGPRs: a rescale costs a read + multiply + write per value) are left alone.
@@ -301,8 +304,10 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
             float rs = 0.f;
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                float p0 = __builtin_amdgcn_exp2f(s[mf][nf][0] - m_use), p1 = __builtin_amdgcn_exp2f(s[mf][nf][1] - m_use);
-                float p2 = __builtin_amdgcn_exp2f(s[mf][nf][2] - m_use), p3 = __builtin_amdgcn_exp2f(s[mf][nf][3] - m_use);
+                float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][0], sc2, -m_use));
+                float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][1], sc2, -m_use));
+                float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][2], sc2, -m_use));
+                float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][3], sc2, -m_use));
                 rs += (p0 + p1) + (p2 + p3);
                 // 4 consecutive keys of query l16 -> one 8-byte write into the row-major [q][key] patch
                 uint2 pk;
