@@ -5,6 +5,8 @@ CosyVoice2Model.tts / token2wav (speech/cosyvoice/cli/model.py:285-386, non-stre
 vocoder call (model.py:316) replaced by DACVAE.decode, as the README pipeline and the flow's training target
 (speech_latent, flow.py:388-389) imply.
 """
+import os
+import time
 from typing import Dict, List, Optional
 
 import torch
@@ -152,33 +154,34 @@ class TtsEngine:
         return out
 
     def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum, flow=None):
+        """Flow + DAC for a group of finished utterances: per-utterance conformer encoder, one batched ODE solve, per-
+        utterance DAC decode.  MMX_TIMING=3 prints the three stage times (with stream syncs between them)."""
         flow = flow or self.flow
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
-        import os
-        import time
-        tr = os.environ.get("MMX_TIMING") == "3"
-        if tr:
-            torch.cuda.current_stream().synchronize()
-            t0 = time.perf_counter()
+        trace = os.environ.get("MMX_TIMING") == "3"
+        marks = []
+
+        def mark():
+            if trace:
+                torch.cuda.current_stream().synchronize()
+                marks.append(time.perf_counter())
+
+        mark()
         conds = [flow.conditions(toks[b].reshape(1, -1), z, zf, embs[b]) for b in grp]
-        if tr:
-            torch.cuda.current_stream().synchronize()
-            t1 = time.perf_counter()
+        mark()
         xs = flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
-        if tr:
-            torch.cuda.current_stream().synchronize()
-            t2 = time.perf_counter()
+        mark()
         for b, lat in zip(grp, xs):
             T2 = lat.shape[0]
             zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
             ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
             wavs[b] = self.dac.decode_time_major(zt, 1, T2)
-        if tr:
-            torch.cuda.current_stream().synchronize()
-            t3 = time.perf_counter()
-            print(f"[flow_dac_group] n={len(grp)} frames={[2 * toks[b].numel() for b in grp]}: encoder {(t1 - t0) * 1e3:.1f} ms, "
-                  f"cfm {(t2 - t1) * 1e3:.1f} ms, dac {(t3 - t2) * 1e3:.1f} ms", flush=True)
+        mark()
+        if trace:
+            e, c, d = ((marks[i + 1] - marks[i]) * 1e3 for i in range(3))
+            print(f"[flow_dac_group] n={len(grp)} frames={[2 * toks[b].numel() for b in grp]}: encoder {e:.1f} ms, "
+                  f"cfm {c:.1f} ms, dac {d:.1f} ms", flush=True)
 
     @torch.no_grad()
     def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=(2, 2, 4, 8), max_pad_ratio=2.0,
@@ -256,9 +259,8 @@ class TtsEngine:
             except BaseException as e:                           # surfaced by the caller
                 err.append(e)
 
-        import os as _os
-        import time as _time
-        _trace = _os.environ.get("MMX_TIMING") == "2"
+        _os, _time = os, time
+        _trace = os.environ.get("MMX_TIMING") == "2"
         self._t0 = _time.perf_counter()
         ths = [threading.Thread(target=worker, args=(wi,), daemon=True) for wi in range(flow_workers)]
         for th in ths:
@@ -340,7 +342,6 @@ class TtsEngine:
                 if len(seen) == B:
                     break
             harvest(True)
-        import os, time
         timing = os.environ.get("MMX_TIMING")
         # The call returns finished audio, so it drains its streams on the host as well: the decode stream here, the
         # flow streams after the workers have issued everything.  Leaving the drain to stream waits (so that the next
