@@ -75,6 +75,12 @@ typedef struct MmxGemmParams {
     int32_t row_stride;                /* 1 for Linear / stride-1 convs; s for a stride-s Conv1d (DAC-VAE encoder) */
 } MmxGemmParams;
 int mmx_gemm_win(const MmxGemmParams* p, int dtype, hipStream_t stream);
+/* The same launch with the block tile forced (0 = the library's heuristic): a tuning entry for tools/microbench.py. */
+#define MMX_TILE_128x128 1
+#define MMX_TILE_128x64 2
+#define MMX_TILE_64x64 3
+#define MMX_TILE_32x64 4
+int mmx_gemm_win_tile(const MmxGemmParams* p, int dtype, int tile, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row-wise normalisation (LayerNorm / RMSNorm) with fused tail:

@@ -22,8 +22,6 @@
 #include "common.h"
 #include "gemm.h"
 #include <utility>
-#include <cstdlib>
-#include <cstring>
 
 template <typename T> struct Frag;
 // LDS row pitch.  A fragment read is ds_read_b128 at (row l16, 16-byte chunk g), served in the lane groups
@@ -354,7 +352,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
 }
 
 template <typename T>
-static int launch_T(const GemmParams& p, hipStream_t s) {
+static int launch_T(const GemmParams& p, hipStream_t s, int force_tile) {
     // shape validation the kernel relies on (16-byte chunk loads)
     constexpr int CH = Frag<T>::CH;
     MMX_CHECK_ARG(p.A && p.W && p.M > 0 && p.N > 0 && p.batch > 0 && p.ntaps >= 1);
@@ -371,12 +369,13 @@ static int launch_T(const GemmParams& p, hipStream_t s) {
     MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use
     // largest tile that still gives every CU a workgroup (256 CUs); short-K GEMMs want many MFMAs per barrier
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch; };
-    static const char* force = getenv("MMX_GEMM_TILE");                // tuning aid (tools/microbench.py)
-    if (force) {
-        if (!strcmp(force, "128x128")) return launch_cfg<T, 128, 128, 2, 2>(p, s);
-        if (!strcmp(force, "128x64")) return launch_cfg<T, 128, 64, 4, 1>(p, s);
-        if (!strcmp(force, "64x64")) return launch_cfg<T, 64, 64, 2, 2>(p, s);
-        if (!strcmp(force, "32x64")) return launch_cfg<T, 32, 64, 1, 4>(p, s);
+    switch (force_tile) {                              // mmx_gemm_win_tile: the tuning entry (tools/microbench.py)
+        case 0: break;
+        case MMX_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2>(p, s);
+        case MMX_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1>(p, s);
+        case MMX_TILE_64x64: return launch_cfg<T, 64, 64, 2, 2>(p, s);
+        case MMX_TILE_32x64: return launch_cfg<T, 32, 64, 1, 4>(p, s);
+        default: return MMX_EARG;
     }
     // measured on MI355X (tools/microbench.py tiles, profiles/r01_gemm_tiles.txt): these GEMMs are short-K and
     // latency bound, so more (smaller) workgroups win until the problem is large: 64x64 beats 128x128 up to
@@ -388,9 +387,12 @@ static int launch_T(const GemmParams& p, hipStream_t s) {
     return launch_cfg<T, 32, 64, 1, 4>(p, s);
 }
 
-extern "C" int mmx_gemm_win(const GemmParams* p, int dtype, hipStream_t stream) {
+extern "C" int mmx_gemm_win_tile(const GemmParams* p, int dtype, int tile, hipStream_t stream) {
     MMX_CHECK_ARG(p != nullptr);
-    if (dtype == MMX_BF16) return launch_T<bf16_t>(*p, stream);
-    if (dtype == MMX_F32) return launch_T<float>(*p, stream);
+    if (dtype == MMX_BF16) return launch_T<bf16_t>(*p, stream, tile);
+    if (dtype == MMX_F32) return launch_T<float>(*p, stream, tile);
     return MMX_EARG;
+}
+extern "C" int mmx_gemm_win(const GemmParams* p, int dtype, hipStream_t stream) {
+    return mmx_gemm_win_tile(p, dtype, 0, stream);
 }

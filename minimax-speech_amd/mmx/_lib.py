@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")
 
 SYMBOLS = [
-    "mmx_abi_version", "mmx_gemm_win", "mmx_rownorm", "mmx_groupnorm", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
+    "mmx_abi_version", "mmx_gemm_win", "mmx_gemm_win_tile", "mmx_rownorm", "mmx_groupnorm", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
     "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_conv_cout1_tanh", "mmx_conv_cin1", "mmx_vae_sample",
     "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_decode_attn", "mmx_swiglu", "mmx_sample_step",
 ]
@@ -99,5 +99,12 @@ def gemm_params(**kw):
     return p
 
 
-def gemm_win(p, dtype):
-    check(load().mmx_gemm_win(C.byref(p), C.c_int(dtype), stream()), "mmx_gemm_win")
+TILES = {"auto": 0, "128x128": 1, "128x64": 2, "64x64": 3, "32x64": 4}
+
+
+def gemm_win(p, dtype, tile=0):
+    """tile != 0 forces the block tile (mmx_gemm_win_tile; tuning tools only)."""
+    if tile:
+        check(load().mmx_gemm_win_tile(C.byref(p), C.c_int(dtype), C.c_int(tile), stream()), "mmx_gemm_win_tile")
+    else:
+        check(load().mmx_gemm_win(C.byref(p), C.c_int(dtype), stream()), "mmx_gemm_win")

@@ -57,6 +57,22 @@ class DacDecoderEngine:
         self.k_final = wf.shape[2]
         self.w_final = wf[0].t().contiguous()                    # [k][C] fp32
         self.b_final = bias(f"{p}.{n + 2}.0")
+        self.ctx_left, self.ctx_right = self.receptive_field(self.rates, self.k_final)
+
+    @staticmethod
+    def receptive_field(rates, k_final=7, k0=7, dils=(1, 3, 9)):
+        """(left, right) latent frames an output sample can depend on beyond its own frame (dac-vae/model.py:326-379):
+        final conv k7, per DecoderBlock three ResidualUnits (k7, dilation 1 / 3 / 9) behind a ConvTranspose1d
+        (kernel 2s, stride s, padding ceil(s/2): output t reads inputs (t + p - 2s + 1)/s .. (t + p)/s), first conv k7.
+        configx2.yml rates (5,4,4,3,2): 16 left, 15 right.  Streaming decodes a window with this much context."""
+        L = R = (k_final - 1) // 2
+        for s in reversed(list(rates)):
+            for d in reversed(dils):
+                L += 3 * d
+                R += 3 * d
+            p = math.ceil(s / 2)
+            L, R = -((-(L + 2 * s - 1 - p)) // s), -((-(R + p)) // s)
+        return L + (k0 - 1) // 2, R + (k0 - 1) // 2
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, skip_pre=False) -> torch.Tensor:

@@ -11,6 +11,7 @@ MFMA flash-attention kernel reads K row-major and V^T row-major without any tran
 A whole 10-step Euler solve (about 5 000 launches) is recorded once per shape into a hipGraph.
 """
 import math
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
@@ -31,7 +32,14 @@ def espnet_rel_pe(T: int, d: int) -> torch.Tensor:
 
 import threading
 
-CAPTURE_LOCK = threading.RLock()     # graph capture is serialised against every other launch of the process
+# Concurrency rule of the engines (one rule, applied everywhere):
+#   * every host thread launches on its OWN non-default stream (torch.cuda.stream(...)); the library itself is
+#     stream-explicit and keeps no global state (include/mmx_hip.h);
+#   * hipGraph capture uses the THREAD-LOCAL capture mode, so launches, graph replays and allocations of other threads
+#     proceed while one thread records (they are not captured and do not invalidate the capture);
+#   * two captures never overlap: CAPTURE_LOCK is taken by Graphed around the capture itself and by nothing else.
+# tests/test_gpu_flow.py::test_capture_while_other_thread_decodes exercises exactly this.
+CAPTURE_LOCK = threading.RLock()
 
 
 _capture_primed = set()
@@ -55,9 +63,9 @@ def _prime_capture_state(dev):
 
 
 class Graphed:
-    """Runs `fn` eagerly once (warm-up), then records it into a hipGraph and replays it.  Capture takes
-    CAPTURE_LOCK (callers that launch from another thread take it around their own launches), and uses the
-    thread-local capture mode so that a concurrent stream of another thread does not invalidate it."""
+    """Runs `fn` eagerly once (warm-up), then records it into a hipGraph and replays it.  The capture takes
+    CAPTURE_LOCK (captures are serialised against each other only) and uses the thread-local capture mode, so other
+    threads keep launching on their own streams meanwhile."""
 
     def __init__(self, fn, enabled=True):
         self.fn, self.enabled, self.graph, self.calls = fn, enabled, None, 0
@@ -70,7 +78,7 @@ class Graphed:
             if self.calls == 1:
                 return self.fn()
             with CAPTURE_LOCK:
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()
                 _prime_capture_state(torch.cuda.current_device())
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -90,7 +98,9 @@ class FlowEngine:
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         lin = lambda k: ops.pack_linear(f(k), dt)
         cv = lambda k: ops.pack_conv1d(f(k), dt)
-        self._pe, self._plans = {}, {}
+        self._pe, self._plans, self._vt = OrderedDict(), OrderedDict(), {}
+        self.plan_budget_bytes = 16 << 30           # recorded Euler solves kept alive (LRU); see _cfm_plan
+        self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
         self.spk_enc = None
@@ -107,21 +117,24 @@ class FlowEngine:
         thread + stream (plans hold the static buffers of a recorded graph, so they cannot be shared)."""
         import copy
         c = copy.copy(self)
-        c._plans, c._pe = {}, {}
+        c._plans, c._pe, c._vt, c.plan_bytes = OrderedDict(), OrderedDict(), {}, 0
         return c
 
     def set_noise(self, noise: torch.Tensor):
         """Replaces rand_noise (the drop-in CausalConditionalCFM owns its own tensor, flow_matching.py:321)."""
         if noise is not self.rand_noise and not torch.equal(noise.cpu(), self.rand_noise):
             self.rand_noise = noise.detach().cpu().float()
-            self._plans = {k: v for k, v in self._plans.items() if k[0] != "cfm"}
+            self._plans.clear()
+            self.plan_bytes = 0
 
     def _init_encoder(self, sd, f, lin, cv):
         dt = self.dtype
-        self.emb_table = f("input_embedding.weight")
-        self.spk_w, self.spk_b = lin("spk_embed_affine_layer.weight"), f("spk_embed_affine_layer.bias")
-        self.spk_dim = sd["spk_embed_affine_layer.weight"].shape[1]
-        self.spk_gamma = torch.full((self.spk_dim,), 1.0 / math.sqrt(self.spk_dim), device=self.dev)
+        flow_level = "input_embedding.weight" in sd          # absent when built for a bare UpsampleConformerEncoder
+        if flow_level:
+            self.emb_table = f("input_embedding.weight")
+            self.spk_w, self.spk_b = lin("spk_embed_affine_layer.weight"), f("spk_embed_affine_layer.bias")
+            self.spk_dim = sd["spk_embed_affine_layer.weight"].shape[1]
+            self.spk_gamma = torch.full((self.spk_dim,), 1.0 / math.sqrt(self.spk_dim), device=self.dev)
         e = "encoder"
         xs = math.sqrt(512.0)
 
@@ -147,8 +160,9 @@ class FlowEngine:
                         layers=[conf_layer(f"{e}.encoders.{i}") for i in range(6)],
                         up_w=cv(e + ".up_layer.conv.weight"), up_b=f(e + ".up_layer.conv.bias"),
                         up_layers=[conf_layer(f"{e}.up_encoders.{i}") for i in range(4)],
-                        ang=f(e + ".after_norm.weight"), anb=f(e + ".after_norm.bias"),
-                        wproj=lin("encoder_proj.weight"), bproj=f("encoder_proj.bias"))
+                        ang=f(e + ".after_norm.weight"), anb=f(e + ".after_norm.bias"))
+        if flow_level:
+            self.enc.update(wproj=lin("encoder_proj.weight"), bproj=f("encoder_proj.bias"))
 
     def _init_estimator(self, sd, f, lin, cv):
         dt = self.dtype
@@ -208,8 +222,13 @@ class FlowEngine:
         return torch.empty(*shape, dtype=torch.float32 if f32 else self.tdt, device=self.dev)
 
     def _pos(self, T):
-        if T not in self._pe:
+        """rel-pos table of length T on the device; a small LRU (a streaming utterance asks for a new T at every hop)."""
+        if T in self._pe:
+            self._pe.move_to_end(T)
+        else:
             self._pe[T] = espnet_rel_pe(T, 512).to(self.dev, self.tdt)
+            while len(self._pe) > 64:
+                self._pe.popitem(last=False)
         return self._pe[T]
 
     # ------------------------------------------------------------------ encoder
@@ -246,10 +265,17 @@ class FlowEngine:
 
     def encode(self, ids: torch.Tensor, finalize: bool, streaming: bool) -> torch.Tensor:
         """ids [L] int64 (prompt + tokens). Returns mu fp32 time-major [2*T, 80], T = L (finalize) or L - 3."""
-        dt, E = self.dtype, self.enc
         Lt = ids.numel()
         a0 = self._new(Lt, 512)
-        ops.gather_rows(ids, self.emb_table, out_act=a0, dtype=dt)
+        ops.gather_rows(ids, self.emb_table, out_act=a0, dtype=self.dtype)
+        return self.encode_embedded(a0, finalize, streaming)
+
+    def encode_embedded(self, a0: torch.Tensor, finalize: bool, streaming: bool, hidden=False) -> torch.Tensor:
+        """UpsampleConformerEncoder.forward (upsample_encoder.py:243-316) on embedded rows a0 [Lt, 512] (compute dtype);
+        with finalize=False the last 3 rows are the look-ahead `context`.  Returns mu = encoder_proj(h) fp32 [2T, 80],
+        or with hidden=True the encoder output h itself (after after_norm) as fp32 [2T, 512]."""
+        dt, E = self.dtype, self.enc
+        Lt = a0.shape[0]
         x_all, xa_all = self._embed(E["embed"], a0, Lt)
         T = Lt if finalize else Lt - self.L
         rows_in = Lt                                    # look-ahead context rows follow the T rows contiguously
@@ -274,7 +300,10 @@ class FlowEngine:
         for lw in E["up_layers"]:
             x = self._conformer(lw, x, T2, pos, 2 * chunk)
         hn = self._new(T2, 512)
-        ops.rownorm(x, E["ang"], E["anb"], 1e-5, rows=T2, C_=512, out_act=hn, dtype=dt)
+        hf = self._new(T2, 512, f32=True) if hidden else None
+        ops.rownorm(x, E["ang"], E["anb"], 1e-5, rows=T2, C_=512, out_f32=hf, out_act=hn, dtype=dt)
+        if hidden:
+            return hf
         mu = self._new(T2, 80, f32=True)
         ops.linear(hn, E["wproj"], 512, dtype=dt, bias=E["bproj"], out_f32=mu)
         return mu
@@ -334,10 +363,10 @@ class FlowEngine:
                  out_act=act_out, ldo_a=act_ld, oa_bstride=T * act_ld)
 
     def _vt_buf(self, B, Tp):
-        key = ("vt", B, Tp)
-        if key not in self._plans:
-            self._plans[key] = torch.zeros(B, 512, Tp, dtype=self.tdt, device=self.dev)   # pad columns stay zero
-        return self._plans[key]
+        key = (B, Tp)                                  # referenced by recorded graphs: never evicted (<= 15 MB each)
+        if key not in self._vt:
+            self._vt[key] = torch.zeros(B, 512, Tp, dtype=self.tdt, device=self.dev)      # pad columns stay zero
+        return self._vt[key]
 
     def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None):
         """All inputs fp32 time-major device tensors: x [x_mod,T,80] (batch b reads x[b % x_mod]), mu/cond [B,T,80],
@@ -431,8 +460,18 @@ class FlowEngine:
         """Plan for n utterances padded to T frames: static buffers + the graph of the whole Euler solve."""
         key = ("cfm", n, T, bool(streaming), bool(masked))
         if key in self._plans:
+            self._plans.move_to_end(key)
             return self._plans[key]
         P = FlowEngine._Plan()
+        # A plan owns its static buffers and (once recorded) a hipGraph of ~5 000 nodes with a private activation pool:
+        # about 2n*T*16 KB of device memory.  Plans are kept in an LRU under `plan_budget_bytes`; an evicted plan's
+        # graph and pool are released, a later call of that shape records it again (one eager pass + one capture).
+        P.nbytes = 2 * n * T * (16 << 10)
+        while self._plans and self.plan_bytes + P.nbytes > self.plan_budget_bytes:
+            _, old = self._plans.popitem(last=False)
+            self.plan_bytes -= old.nbytes
+            del old
+        self.plan_bytes += P.nbytes
         P.x = self._new(n, T, 80, f32=True)             # ODE state, shared by the two halves of the CFG batch
         P.mu = torch.zeros(2 * n, T, 80, device=self.dev)   # rows n.. stay zero: the unconditional branch
         P.spks = torch.zeros(2 * n, 80, device=self.dev)
@@ -479,7 +518,9 @@ class FlowEngine:
 
     def cfm(self, mu, spks, cond, streaming=False) -> torch.Tensor:
         """mu, cond fp32 [T,80] time-major; spks fp32 [80] -> x fp32 [T,80] (owned by the plan: copy if kept)."""
-        return self.cfm_batch([mu], [spks], [cond], streaming)[0]
+        # streaming hops ask for a new length every time: bucket T to two chunks (the row / key masks make the padded
+        # solve equal to the unpadded one), so a 60 s utterance records 30 plans instead of 60
+        return self.cfm_batch([mu], [spks], [cond], streaming, pad_to=(2 * self.est_chunk if streaming else 1))[0]
 
     # ------------------------------------------------------------------ flow.inference
     @torch.no_grad()

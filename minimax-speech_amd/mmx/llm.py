@@ -77,11 +77,13 @@ class LlmEngine:
         # HF Qwen2RotaryEmbedding inv_freq (modeling_qwen2.py: 1 / theta^(arange(0,d,2)/d)), computed like HF in fp32
         self.inv_freq = (1.0 / (rope_theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))).to(self.dev)
         # cos/sin per position exactly as HF computes them (fp32 outer product, then cos/sin): [max_ctx][cos 32 | sin 32]
+        # one capacity for the KV pages, the RoPE table, the token history and every guard: whole pages
+        self.max_pages = (max_ctx + page - 1) // page
+        max_ctx = self.max_pages * page
         ang = torch.arange(max_ctx, dtype=torch.float32)[:, None] * self.inv_freq.cpu()[None, :]
         self.rope_tab = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous().to(self.dev)
         # paged KV cache: [layers][pages][Hkv][page][D]; sequence b owns table row b (static allocation for now)
         self.B = max_batch
-        self.max_pages = (max_ctx + page - 1) // page
         npages = self.B * self.max_pages
         self.trash_page = npages                  # scratch page for unused slots of a compacted batch
         self.kc = torch.zeros(self.n_layers, npages + 1, kv_heads, page, head_dim, dtype=self.tdt, device=self.dev)

@@ -53,7 +53,8 @@ def fold_weight_norm(g, v):
 def gemm(A, W, M, N, *, dtype, lda=None, cin=None, ntaps=1, dil=1, row_off=0, row_lo=0, row_hi=None, batch=1,
          a_bstride=0, w_bstride=0, bias=None, bias_mod=None, bias_per_row=False, act="none", act2="none", slope=0.1,
          residual=None, ldr=0, r_bstride=0, rowmask=None, rm_bstride=0, alpha=None, alpha_mod=None,
-         out_f32=None, ldo_f=0, of_bstride=0, out_act=None, ldo_a=0, oa_bstride=0, out_off=0, out_len=None, row_stride=1):
+         out_f32=None, ldo_f=0, of_bstride=0, out_act=None, ldo_a=0, oa_bstride=0, out_off=0, out_len=None, row_stride=1,
+         tile=0):
     """Launches mmx_gemm_win. A/W/out_* may be tensors or raw device addresses (ints)."""
     ldw = W.shape[-1] if hasattr(W, "shape") else None
     assert ldw is not None
@@ -65,7 +66,7 @@ def gemm(A, W, M, N, *, dtype, lda=None, cin=None, ntaps=1, dil=1, row_off=0, ro
                       out_len=(out_len if out_len is not None else (1 << 62)), M=M, N=N, batch=batch,
                       ntaps=ntaps, cin=cin, dil=dil, bias_mod=(bias_mod or N), alpha_mod=(alpha_mod or N),
                       bias_per_row=int(bias_per_row), act=ACT[act], act2=ACT[act2], slope=slope, row_stride=row_stride)
-    L.gemm_win(p, dtype)
+    L.gemm_win(p, dtype, tile)
 
 
 def linear(x, Wp, K, *, dtype, bias=None, act="none", act2="none", residual=None, rowmask=None, out_f32=None,

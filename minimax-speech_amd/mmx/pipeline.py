@@ -83,11 +83,17 @@ class TtsEngine:
         return self.token2wav(toks.reshape(1, -1), pt, pf, flow_embedding)
 
     @torch.no_grad()
-    def tts_stream(self, text, flow_embedding, seed=0, exact_steps=None, token_hop=25, dac_overlap=8):
+    def tts_stream(self, text, flow_embedding, seed=0, exact_steps=None, token_hop=25, latents_out=None, forced=None):
         """Streaming synthesis of one (long) utterance: BASELINE config 5 / cli/model.py:336-369 (`stream=True`).
         The AR decode runs ahead on its own stream (captured decode step); every `token_hop` tokens (+ the flow's
-        look-ahead) the chunk-causal flow is solved over all tokens so far, as the reference does, and the DAC decoder
-        renders the new frames with `dac_overlap` frames of left context.  Yields waveform chunks [1, n] (device)."""
+        look-ahead) the chunk-causal flow is solved over all tokens so far, as the reference does.  The DAC decoder is
+        NOT causal: a sample depends on `dac.ctx_left` latent frames before and `dac.ctx_right` after its own frame
+        (DacDecoderEngine.receptive_field).  So a hop renders the frames whose right context is already final — it holds
+        the last `ctx_right` frames back for the next hop — from a window with `ctx_left` frames of left context, and
+        the concatenated chunks equal the offline decode of the same latents sample for sample (this replaces the
+        reference's HiFT mel / source cache and its cross-fade, cli/model.py:304-311).  Yields waveform chunks [1, n]
+        (device); `latents_out` (a list) receives the latent frames [n, 80] behind each chunk; `forced` [1, steps]
+        teacher-forces the accepted ids (LlmEngine.start)."""
         from .llm import ST_FIN, ST_NOUT
         assert self.llm.B == 1
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
@@ -101,39 +107,60 @@ class TtsEngine:
         lm, caller = self._lm_stream, torch.cuda.current_stream()
         lm.wait_stream(caller)
         L = self.flow.L
+        CL, CR = self.dac.ctx_left, self.dac.ctx_right
         with torch.cuda.stream(lm):
-            self.llm.start([x], [mn], [mx], seed=seed)
-        done, offset, finished = 1, 0, False
+            self.llm.start([x], [mn], [mx], seed=seed, forced=forced)
+        done, offset, emitted = 1, 0, 0                    # decode steps issued, tokens rendered, latent frames emitted
+        tail = None                                        # the last ctx_left latent frames already emitted
 
         def render(n_tok, finalize):
-            nonlocal offset
+            nonlocal emitted, tail
             ev = torch.cuda.Event()
             ev.record(lm)
             caller.wait_event(ev)                          # tokens [0, n_tok) are written
             tok = self.llm.out_tokens[0:1, :n_tok].to(torch.int64)
-            lat = self.flow.inference_time_major(tok, z, zf, flow_embedding, streaming=True, finalize=finalize)
-            start = offset * 2
-            ctx = min(dac_overlap, start)
-            seg = lat[start - ctx:]
-            T2 = seg.shape[0]
-            zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
-            ops.copy2d(seg, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
-            wav = self.dac.decode_time_major(zt, 1, T2)[:, 0, ctx * self.hop:]
+            # like the reference, the closing pass runs WITHOUT the chunk masks (cli/model.py:371-378 leaves `stream` at
+            # its default False): its frames differ from what a streaming pass would give, so the left context of the
+            # window is the emitted tail kept from the previous pass, not this pass's version of those frames
+            lat = self.flow.inference_time_major(tok, z, zf, flow_embedding, streaming=not finalize, finalize=finalize)
+            T2 = lat.shape[0]
+            hi = T2 if finalize else T2 - CR               # frames whose right context is final
+            if hi <= emitted:
+                return None
+            seg = lat[emitted:] if tail is None else torch.cat([tail, lat[emitted:]], dim=0)
+            nctx = 0 if tail is None else tail.shape[0]
+            n = seg.shape[0]
+            zt = torch.empty(1, n, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
+            ops.copy2d(seg.contiguous(), F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=n, cols=80)
+            wav = self.dac.decode_time_major(zt, 1, n)[:, 0, nctx * self.hop:(nctx + hi - emitted) * self.hop]
+            if latents_out is not None:
+                latents_out.append(lat[emitted:hi].clone())
+            tail = seg[max(0, nctx + hi - emitted - CL):nctx + hi - emitted].clone()
+            emitted = hi
             return wav
 
-        while not finished:
-            want = offset + token_hop + L                  # tokens needed for the next chunk
+        while True:
             with torch.cuda.stream(lm):
-                while done < mx and done < want + 8:       # keep the decode a few tokens ahead of the renderer
-                    self.llm.step()
-                    done += 1
-                st = self.llm.state[:, 0].tolist()         # D2H copy on the LM stream: waits for the steps above
+                st = self.llm.state[:, 0].tolist()         # D2H copy on the LM stream: waits for the steps issued so far
             n_out, finished = st[ST_NOUT], bool(st[ST_FIN]) or done >= mx
             while n_out - offset >= token_hop + L:
-                yield render(offset + token_hop + L, finalize=False)
+                w = render(offset + token_hop + L, finalize=False)
                 offset += token_hop
+                if w is not None:
+                    yield w
             if finished:
-                yield render(n_out, finalize=True)
+                w = render(n_out, finalize=True)
+                if w is not None:
+                    yield w
+                break
+            # keep the decode a few ACCEPTED tokens ahead of the renderer.  The look-ahead is counted in tokens, not in
+            # steps (ids above the EOS id advance the step counter without producing a token, llm.py:755-756), and at
+            # least one step is issued per round, so the loop always makes progress.
+            k = min(mx - done, max(1, offset + token_hop + L + 8 - n_out))
+            with torch.cuda.stream(lm):
+                for _ in range(k):
+                    self.llm.step()
+            done += k
         caller.wait_stream(lm)
 
     # ------------------------------------------------------------------ batch of independent utterances
@@ -198,7 +225,6 @@ class TtsEngine:
         the same from run to run)."""
         import queue
         import threading
-        from .flow import CAPTURE_LOCK
         from .llm import ST_FIN, ST_NOUT
         B = len(texts)
         assert B == self.llm.B
@@ -247,10 +273,6 @@ class TtsEngine:
                         grp, ev = item
                         side.wait_event(ev)                      # the group's token ids were written on the LM stream
                         t_in = _time.perf_counter()
-                        if _os.environ.get("MMX_SKIP_FLOW"):     # diagnosis: the decode loop alone, same control flow
-                            for b in grp:
-                                wavs[b] = torch.zeros(1, 1, 2 * toks[b].numel() * self.hop, device=self.dev)
-                            continue
                         self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow)
                         if _trace:
                             side.synchronize()
@@ -290,8 +312,7 @@ class TtsEngine:
             if (not final and self.llm_small is not None and eng is self.llm and B - len(seen) <= self.llm_small.B
                     and B - len(seen) > 0):
                 act = [s_ for s_ in range(len(slots)) if slots[s_] not in seen]
-                with CAPTURE_LOCK:
-                    self.llm_small.compact_from(self.llm, act)
+                self.llm_small.compact_from(self.llm, act)
                 cur[0], cur[1] = self.llm_small, [slots[s_] for s_ in act]
             frames = {b: 2 * toks[b].numel() for b in pending}
             groups = self._groups(pending, frames, group_size, max_pad_ratio, frame_quantum, first=issued[0])
@@ -328,14 +349,12 @@ class TtsEngine:
                     pending.remove(b)
 
         with torch.cuda.stream(main):
-            with CAPTURE_LOCK:
-                self.llm.start(xs, mins, maxs, seed=seed)
+            self.llm.start(xs, mins, maxs, seed=seed)          # (captures serialise themselves: mmx/flow.py, Graphed)
             done, max_steps = 1, max(maxs)
             while done < max_steps:
                 k = min(poll_every, max_steps - done)
-                with CAPTURE_LOCK:                               # never launch while the other thread records a graph
-                    for _ in range(k):
-                        cur[0].step()
+                for _ in range(k):
+                    cur[0].step()
                 done += k
                 steps_done[0] = done
                 harvest(False)

@@ -3,9 +3,11 @@ streaming hop schedule) and `token2wav`, with the HiFT vocoder call (model.py:31
 composition the README and the flow's training target imply.
 
 Streaming follows the reference's schedule (poll until token_hop_len + pre_lookahead tokens are available, re-run the
-flow over all tokens so far with chunk-causal masks, emit the new part).  The HiFT source/mel caches have no DAC
-equivalent: each hop's waveform is decoded from the newly finalized latents plus `dac_overlap` frames of left
-context whose samples are dropped.
+flow over all tokens so far with chunk-causal masks, emit the new part).  The HiFT source / mel caches and the Hamming
+cross-fade (model.py:258-261,304-311) have no DAC equivalent and are not needed: the DAC decoder's receptive field is
+finite (16 latent frames to the left, 15 to the right for configx2.yml), so each hop decodes a window with that much
+context, emits only the frames whose right context is final and holds the last 15 frames back for the next hop.  The
+concatenated chunks equal the offline decode of the same latents (tests/test_gpu_stream.py).
 """
 import threading
 import time
@@ -15,7 +17,6 @@ from typing import Generator
 import numpy as np
 import torch
 
-from ..utils.common import fade_in_out
 
 
 class CosyVoice2Model:
@@ -25,9 +26,10 @@ class CosyVoice2Model:
         self.llm, self.flow, self.hift = llm, flow, hift
         self.fp16 = fp16                                  # the HIP engines pick bf16 / fp32 themselves
         self.token_hop_len = 25                           # must match the training static_chunk_size
-        self.dac_overlap = 8                              # latent frames of left context per streaming hop
-        self.hop = 480
-        self.speech_window = np.hamming(2 * self.dac_overlap * self.hop)
+        self.hop = int(np.prod(getattr(hift, "decoder_rates", [5, 4, 4, 3, 2])))   # samples per latent frame
+        from mmx.dac import DacDecoderEngine
+        self.dac_ctx_left, self.dac_ctx_right = DacDecoderEngine.receptive_field(getattr(hift, "decoder_rates", [5, 4, 4, 3, 2]))
+        self.llm_stream = None                            # the llm_job thread launches on its own stream (mmx/flow.py rule)
         self.lock = threading.Lock()
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict = {}, {}, {}
 
@@ -45,13 +47,16 @@ class CosyVoice2Model:
         common = dict(prompt_text=prompt_text.to(self.device), prompt_text_len=i32(prompt_text),
                       prompt_speech_token=llm_prompt_speech_token.to(self.device),
                       prompt_speech_token_len=i32(llm_prompt_speech_token), embedding=llm_embedding.to(self.device))
+        if self.llm_stream is None:
+            self.llm_stream = torch.cuda.Stream(device=self.device)
         try:
-            if isinstance(text, Generator):               # streaming input text (cli/model.py:105-112)
-                gen = self.llm.inference_bistream(text=(t.to(self.device) for t in text), **common)
-            else:
-                gen = self.llm.inference(text=text.to(self.device), text_len=i32(text), uuid=uuid_, **common)
-            for tok in gen:
-                self.tts_speech_token_dict[uuid_].append(tok)
+            with torch.cuda.stream(self.llm_stream):
+                if isinstance(text, Generator):           # streaming input text (cli/model.py:105-112)
+                    gen = self.llm.inference_bistream(text=(t.to(self.device) for t in text), **common)
+                else:
+                    gen = self.llm.inference(text=text.to(self.device), text_len=i32(text), uuid=uuid_, **common)
+                for tok in gen:
+                    self.tts_speech_token_dict[uuid_].append(tok)
         except BaseException as e:                        # surface LM errors in tts() instead of spinning forever
             self.llm_error_dict[uuid_] = e
         finally:
@@ -65,18 +70,23 @@ class CosyVoice2Model:
                                      prompt_token=prompt_token.to(self.device), prompt_token_len=i32(prompt_token.shape[1]),
                                      prompt_feat=prompt_feat.to(self.device), prompt_feat_len=i32(prompt_feat.shape[1]),
                                      embedding=embedding.to(self.device), streaming=stream, finalize=finalize)
+        st = self.hift_cache_dict.get(uuid)
         start = token_offset * self.flow.token_mel_ratio
-        # left context for the conv stack: the DAC decoder's receptive field is finite, so decoding the new frames
-        # together with `dac_overlap` already-emitted frames and dropping their samples reproduces the interior of
-        # a full decode up to the receptive-field tail (this replaces the reference's HiFT mel/source cache)
-        ctx = min(self.dac_overlap, start)
-        wav = self.hift.decode(lat[:, :, start - ctx:])[:, 0]                    # [1, samples]
-        wav = wav[:, ctx * self.hop:]
-        prev = self.hift_cache_dict.get(uuid)
-        if prev is not None and prev["speech"].shape[1] == self.speech_window.shape[0] // 2:
-            pass    # (no overlap is re-emitted, so there is nothing to cross-fade; fade_in_out is kept for API parity)
-        if not finalize:
-            self.hift_cache_dict[uuid] = {"speech": wav[:, -self.dac_overlap * self.hop:]}
+        if st is None and finalize:                        # one-shot synthesis: decode everything
+            return self.hift.decode(lat[:, :, start:])[:, 0]
+        # streaming session: `emitted` latent frames are out; this hop renders the frames whose right context is final
+        # from a window whose left context is the emitted tail kept from the previous hop (the closing pass runs without
+        # chunk masks, as in the reference, so its own version of those frames differs)
+        emitted, tail = (start, None) if st is None else (st["emitted"], st["tail"])
+        T2 = lat.shape[2]
+        hi = T2 if finalize else T2 - self.dac_ctx_right
+        if hi <= emitted:
+            return lat.new_zeros(1, 0)
+        seg = lat[:, :, emitted:] if tail is None else torch.cat([tail, lat[:, :, emitted:]], dim=2)
+        nctx = 0 if tail is None else tail.shape[2]
+        wav = self.hift.decode(seg)[:, 0, nctx * self.hop:(nctx + hi - emitted) * self.hop]
+        end = nctx + hi - emitted
+        self.hift_cache_dict[uuid] = {"emitted": hi, "tail": seg[:, :, max(0, end - self.dac_ctx_left):end].clone()}
         return wav
 
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192),
@@ -112,7 +122,8 @@ class CosyVoice2Model:
                     wav = self.token2wav(t, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, token_offset,
                                          this_uuid, stream=True, finalize=False)
                     token_offset += hop
-                    yield {"tts_speech": wav.cpu()}
+                    if wav.shape[1]:
+                        yield {"tts_speech": wav.cpu()}
                 if self.llm_end_dict[this_uuid] and len(toks) - token_offset < hop + L:
                     break
             p.join()

@@ -32,7 +32,25 @@ class UpsampleConformerEncoder(EngineHost):
     def output_size(self) -> int:
         return self._output_size
 
+    def _eng(self):
+        from mmx.flow import FlowEngine
+        dev = self._device()
+        if self._engine is None:
+            sd = {"encoder." + k: v for k, v in self.state_dict().items()}
+            self._engine = FlowEngine(sd, dtype=self.compute_dtype, device=dev, enc_chunk=self.static_chunk_size,
+                                      parts=("encoder",))
+        return self._engine
+
+    @torch.inference_mode()
     def forward(self, xs, xs_lens, context=torch.zeros(0, 0, 0), decoding_chunk_size: int = 0,
                 num_decoding_left_chunks: int = -1, streaming: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
-        raise NotImplementedError("the encoder runs inside CausalMaskedDiffWithXvec.inference (token ids in, mu out); "
-                                  "a standalone embedding-in entry point is not part of the hot path")
+        """upsample_encoder.py:243-316: xs [1, T, 512] embedded tokens (+ `context` [1, 3, 512], the look-ahead rows of
+        a non-final streaming call) -> (h [1, 2T, 512] fp32, masks [1, 1, 2T] bool).  Batch 1, as flow.inference
+        calls it (flow.py:453 asserts it)."""
+        assert xs.shape[0] == 1 and int(xs_lens[0]) == xs.shape[1], "the hot path encodes one unpadded utterance"
+        eng = self._eng()
+        has_ctx = context is not None and context.numel() > 0
+        rows = torch.cat([xs[0], context[0].to(xs.device)], dim=0) if has_ctx else xs[0]
+        a0 = rows.to(eng.dev, eng.tdt).contiguous()
+        h = eng.encode_embedded(a0, finalize=not has_ctx, streaming=streaming, hidden=True)
+        return h.unsqueeze(0), torch.ones(1, 1, h.shape[0], dtype=torch.bool, device=h.device)

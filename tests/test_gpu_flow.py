@@ -40,14 +40,92 @@ def test_estimator_seam(engines, gold, dt):
         assert err < EST_TOL[dt], (name, dt, err)
 
 
+def snr_db(ref, got):
+    return float(10 * torch.log10(ref.pow(2).mean() / (ref - got).pow(2).mean().clamp_min(1e-30)))
+
+
+# encoder output (after after_norm, std ~1): fp32 build abs bound; bf16 build a stated SNR requirement
+ENC_TOL_F32, ENC_MIN_SNR_BF16 = 2e-4, 30.0
+
+
 @pytest.mark.parametrize("dt", [0, 1])
-def test_encoder(engines, gold, dt):
-    """encoder alone is exercised through flow.inference below; here: mu of the no-prompt case is finite and the
-    right shape (the golden holds the full-inference outputs)."""
+def test_encoder_vs_reference_golden(engines, gold, dt):
+    """UpsampleConformerEncoder on the HIP path vs the reference's own outputs (tests/golden/flow.npz: `enc_full` =
+    25 embedded tokens, no context, full attention; `enc_ctx_stream` = the same with 3 look-ahead context rows and
+    chunk-causal masks), upsample_encoder.py:243-316."""
     eng = engines[dt]
-    ids = torch.from_numpy(gold["flow_tok"]).cuda().reshape(-1)
-    mu = eng.encode(ids, True, False)
-    assert mu.shape == (50, 80) and torch.isfinite(mu).all()
+    xs, ctx = torch.from_numpy(gold["enc_xs"]).cuda()[0], torch.from_numpy(gold["enc_ctx"]).cuda()[0]
+    cases = (("enc_full", xs, True, False), ("enc_ctx_stream", torch.cat([xs, ctx], 0), False, True))
+    for name, rows, finalize, streaming in cases:
+        h = eng.encode_embedded(rows.to(eng.tdt).contiguous(), finalize, streaming, hidden=True)
+        ref = torch.from_numpy(gold[name]).cuda()[0]
+        assert h.shape == ref.shape == (50, 512)
+        err, snr = (h - ref).abs().max().item(), snr_db(ref, h)
+        print(f"encoder {name} dtype {dt}: max abs err {err:.3e}, SNR {snr:.1f} dB")
+        if dt == 0:
+            assert err < ENC_TOL_F32, (name, err)
+        else:
+            assert snr > ENC_MIN_SNR_BF16, (name, snr, err)
+
+
+def test_dropin_encoder_forward_vs_reference_golden(gold, golden_dir):
+    """The drop-in UpsampleConformerEncoder.forward(xs, xs_lens, context, streaming) (embedding-in entry point)."""
+    from test_dropin_api import build_flow
+    from oracle import weights as W
+    flow = build_flow()
+    flow.load_state_dict(W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_flow.json")), SEED), strict=True)
+    enc = flow.encoder.to("cuda").float_parity()
+    xs, ctx = torch.from_numpy(gold["enc_xs"]).cuda(), torch.from_numpy(gold["enc_ctx"]).cuda()
+    h, m = enc(xs, torch.tensor([25]).cuda())
+    assert m.shape == (1, 1, 50) and (h.cpu() - torch.from_numpy(gold["enc_full"])).abs().max().item() < ENC_TOL_F32
+    h, _ = enc(xs, torch.tensor([25]).cuda(), context=ctx, streaming=True)
+    assert (h.cpu() - torch.from_numpy(gold["enc_ctx_stream"])).abs().max().item() < ENC_TOL_F32
+
+
+def test_capture_while_other_thread_decodes(engines):
+    """The concurrency rule of mmx/flow.py: a thread records a new Euler-solve graph (thread-local capture) while
+    another thread keeps replaying its own recorded decode graph on its own stream; both results stay correct."""
+    import threading
+    from mmx import shapes, synth
+    from mmx.llm import LlmEngine
+    sd = synth.synth_state_dict(shapes.llm_manifest(layers=2), 0)
+    z = torch.zeros(1, 0, dtype=torch.long, device="cuda")
+    text = torch.randint(0, 151936, (1, 9), generator=torch.Generator().manual_seed(1)).cuda()
+    lm = LlmEngine(sd, dtype=1, max_batch=1, max_ctx=512)
+    x = lm.build_lm_input(text, z, z)
+    lm.start([x], [300], [300], seed=1)
+    ref = lm.run(300)[0]                                   # eager step + capture happen here, single threaded
+    eng = engines[1]
+    g = torch.Generator().manual_seed(23)
+    mus = {T: torch.randn(T, 80, generator=g).cuda() for T in (36, 44, 52, 60)}
+    spk, errs, out = torch.randn(80, generator=g).cuda(), [], {}
+    base = {T: eng.cfm(mus[T], spk, torch.zeros(T, 80).cuda()).clone() for T in mus}     # eager pass of every shape
+    torch.cuda.synchronize()
+    go, stop = threading.Event(), threading.Event()
+
+    def decode_thread():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                lm.start([x], [300], [300], seed=1)
+                go.set()
+                out["toks"] = lm.run(300)[0]               # graph replays while the main thread captures
+        except BaseException as e:
+            errs.append(e)
+        finally:
+            go.set()
+            stop.set()
+
+    th = threading.Thread(target=decode_thread)
+    th.start()
+    go.wait()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for T in mus:                                      # second call of each shape = hipGraph capture
+            y = eng.cfm(mus[T], spk, torch.zeros(T, 80).cuda())
+            torch.cuda.current_stream().synchronize()
+            assert (y - base[T]).abs().max().item() < 1e-5, T
+    th.join()
+    assert not errs, errs
+    assert out["toks"] == ref
 
 
 @pytest.mark.parametrize("dt", [0, 1])

@@ -169,28 +169,6 @@ def test_inference_spk_lm_input_matches_oracle(llm_sd):
     assert x.shape == ref.shape[1:] and (x.cpu() - ref[0]).abs().max().item() < 1e-5
 
 
-def test_tts_stream_equals_token_sequence_and_length():
-    """TtsEngine.tts_stream (BASELINE config 5 at a small size): chunks of 25 tokens (+3 look-ahead), the same tokens as
-    the offline path under the same seed, 960 samples per token in total, first chunk = 25 tokens."""
-    from mmx import shapes, synth
-    from mmx.pipeline import TtsEngine
-    llm_sd = synth.synth_state_dict(shapes.llm_manifest(layers=2), 0)
-    flow_sd = synth.synth_state_dict(shapes.flow_manifest(), 0)
-    dac_sd = synth.synth_state_dict(shapes.dac_decoder_manifest(80), 0)
-    eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=1, max_batch=1, max_ctx=512)
-    text = torch.randint(0, 151936, (1, 20), generator=torch.Generator().manual_seed(4)).cuda()
-    emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(5)).cuda()
-    chunks = list(eng.tts_stream(text, emb, seed=3, exact_steps=90))
-    n_out = int(eng.llm.state[2, 0])                    # 90 sampling steps; ids above the eos id are skipped (llm.py:755)
-    assert 80 <= n_out <= 90
-    assert [c.shape[-1] for c in chunks[:-1]] == [25 * 960] * (len(chunks) - 1) and len(chunks) == 4
-    assert sum(c.shape[-1] for c in chunks) == n_out * 960
-    assert all(torch.isfinite(c).all() for c in chunks)
-    toks_stream = eng.llm.out_tokens[0, :n_out].tolist()
-    toks_off = eng.generate_tokens([text], seed=3, exact_steps=90)[0].tolist()
-    assert toks_stream == toks_off
-
-
 @pytest.mark.parametrize("dt,tol", [(0, 2e-3), (1, 0.25)])
 def test_batched_prefill_matches_per_sequence_prefill(dt, tol):
     """LlmEngine._prefill_batch (all prompts in one tall-GEMM pass, ragged lengths zero padded) against the

@@ -1,0 +1,53 @@
+"""The decode loop of the config-4 rank share ALONE: the same tts_batch control flow (batched prefill, 32-slot decode,
+compaction to the 16-slot engine, harvest / poll schedule, worker threads) with the flow + DAC stage replaced by
+zero waveforms — a measurement tool, not a product switch.
+
+    python tools/decode_alone.py [--dtype bf16|f32] [--per-gpu 32] [--steps 5]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "minimax-speech_amd"))
+from mmx import shapes, synth  # noqa: E402
+from mmx.pipeline import TtsEngine  # noqa: E402
+
+
+class DecodeOnly(TtsEngine):
+    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum, flow=None):
+        for b in grp:
+            wavs[b] = torch.zeros(1, 1, 2 * toks[b].numel() * self.hop, device=self.dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--per-gpu", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=5)
+    a = ap.parse_args()
+    dt = 1 if a.dtype == "bf16" else 0
+    eng = DecodeOnly(synth.synth_state_dict(shapes.llm_manifest(), 0), synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0),
+                     synth.synth_state_dict(shapes.dac_decoder_manifest(80), 0), dtype=dt, max_batch=a.per_gpu, max_ctx=640)
+    lens = torch.randint(50, 501, (a.per_gpu,), generator=torch.Generator().manual_seed(3)).tolist()
+    g = torch.Generator().manual_seed(2)
+    texts = [torch.randint(0, 151936, (1, 48), generator=g).cuda() for _ in lens]
+    emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).cuda()
+    fn = lambda: eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        fn()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    print(f"decode loop alone, {a.per_gpu} utterances (max {max(lens)} steps), {a.dtype}: {ms:.1f} ms per step "
+          f"({ms / max(lens):.3f} ms per decode step)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

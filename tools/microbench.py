@@ -5,7 +5,7 @@ import math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "minimax-speech_amd"))
 import torch
-from mmx import ops
+from mmx import ops, _lib as L
 
 
 def timeit(fn, iters=200, warm=20):
@@ -94,7 +94,7 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "flash":
     flash_case(16, 512, 50)
 
 
-def gemm_graph_case(M, N, K, batch, act="none", out="act"):
+def gemm_graph_case(M, N, K, batch, act="none", out="act", tile="auto"):
     dt = 1
     x = torch.randn(batch, M, K, device="cuda").bfloat16()
     w = ops.pack_linear(torch.randn(N, K, device="cuda") / math.sqrt(K), dt)
@@ -102,15 +102,17 @@ def gemm_graph_case(M, N, K, batch, act="none", out="act"):
     oa = torch.empty(batch, M, N, device="cuda", dtype=torch.bfloat16) if out in ("act", "both") else None
     res = torch.randn(batch, M, N, device="cuda") if out == "f32" else None
     fn = lambda: ops.gemm(x, w, M, N, dtype=dt, lda=K, cin=K, batch=batch, a_bstride=M * K, act=act, residual=res, ldr=N,
-                          r_bstride=M * N, out_f32=of, ldo_f=N, of_bstride=M * N, out_act=oa, ldo_a=N, oa_bstride=M * N)
+                          r_bstride=M * N, out_f32=of, ldo_f=N, of_bstride=M * N, out_act=oa, ldo_a=N, oa_bstride=M * N,
+                          tile=L.TILES[tile])
     us = graph_time(fn)
-    print(f"tile={os.environ.get('MMX_GEMM_TILE','auto'):8s} M={M} N={N:5d} K={K:5d} b={batch:3d} act={act:5s} out={out}: {us:7.2f} us {2.0*M*N*K*batch/us/1e6:7.1f} TF")
+    print(f"tile={tile:8s} M={M} N={N:5d} K={K:5d} b={batch:3d} act={act:5s} out={out}: {us:7.2f} us {2.0*M*N*K*batch/us/1e6:7.1f} TF")
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tiles":
     for (N, K, act, out) in ((1024, 256, "none", "act"), (1024, 256, "gelu", "act"), (256, 1024, "none", "f32"), (256, 512, "none", "f32"), (256, 768, "none", "f32")):
-        gemm_graph_case(512, N, K, 16, act, out)
-        gemm_graph_case(512, N, K, 2, act, out)
+        for tile in ("auto", "128x128", "128x64", "64x64", "32x64"):
+            gemm_graph_case(512, N, K, 16, act, out, tile)
+            gemm_graph_case(512, N, K, 2, act, out, tile)
 
 
 def skinny_case(B, K, N, epi, packed=False):
