@@ -223,6 +223,73 @@ int mmx_sample_step(const float* logits, int64_t ldl, int V, int B, int eos_id, 
                     int32_t* sampled, const int32_t* forced, const float* speech_emb, int E, float* next_x,
                     int64_t ldx, float* logp_out, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Row-tile fused kernels of the CFM estimator (csrc/fused.hip).  One workgroup takes a tile of `bm` frames of one
+ * sequence through every row-local op between two attentions, so a transformer block is 2 launches (this + attention).
+ * Dimensions are those of speech/config.yaml:104-116: C = 256 channels, 8 heads x 64, FF 1024.
+ * Weights are in MFMA fragment order (mmx_pack_skinny of the [N][K] matrix; Conv1d k3: K = tap*Cin + c).
+ *
+ * MmxEstNext (optional, wqkv != NULL): LayerNorm (n1g, n1b) of the result followed by the Q/K/V projection of the NEXT
+ *   transformer block (matcha transformer.py:256-285: norm1 -> attn1.to_q/to_k/to_v, no bias).
+ *   MMX_BF16: q_out = [B][T][ldq >= 1024] (Q | K) and vt_out = V transposed [B][512][ldvt] (frames >= T written as 0);
+ *   MMX_F32 : q_out = [B][T][ldq >= 1536] (Q | K | V), vt_out unused.
+ * mmx_est_tail: x += attn1.to_out(ao) ; x += ff(norm3(x))  (transformer.py:286-313), x fp32 [B][T][256] in place;
+ *   rowmask (optional) multiplies the result; act_out (optional) receives T(x) with row stride act_ld.
+ * mmx_est_resnet: CausalResnetBlock1D (flow/decoder.py:65-85 + matcha decoder.py:56-61):
+ *   h = mish(LN(conv3(a_in) + b1)) * m;  h = (h + tv[b]) * m;  h = mish(LN(conv3(h) + b2)) * m;
+ *   x = h + conv1(a_in) + br.  a_in T [B][T][lda] (cin columns, already masked); tv = mlp(mish(t_emb)) fp32 [B][256].
+ * bm: 16 / 32 / 64 (bf16), 16 / 32 (fp32 tail), 16 (fp32 resnet).
+ */
+typedef struct MmxEstNext {
+    const void* wqkv;
+    const float* n1g;
+    const float* n1b;
+    void* q_out;
+    void* vt_out;
+    int64_t q_bs, vt_bs;
+    int32_t ldq, ldvt;
+} MmxEstNext;
+typedef struct MmxEstTailParams {
+    const void* ao;         /* T [B][T][ldao], 512 columns: attention output */
+    float* x;               /* fp32 [B][T][256] residual stream, in place */
+    const void* wo;         /* packed [256][512] */
+    const void* w1;         /* packed [1024][256] */
+    const void* w2;         /* packed [256][1024] */
+    const float* bo;
+    const float* b1;
+    const float* b2;
+    const float* n3g;
+    const float* n3b;
+    const float* rowmask;   /* fp32 [B][T] or NULL */
+    void* act_out;          /* T or NULL */
+    int64_t ao_bs, x_bs, rm_bs, act_bs;
+    int32_t ldao, act_ld, B, T;
+    float eps;
+    MmxEstNext next;
+} MmxEstTailParams;
+typedef struct MmxEstResnetParams {
+    const void* a_in;
+    float* x;               /* fp32 [B][T][256] out */
+    const void* w1;         /* packed [256][3*cin] */
+    const void* w2;         /* packed [256][768] */
+    const void* wr;         /* packed [256][cin] */
+    const float* b1;
+    const float* g1;
+    const float* be1;
+    const float* b2;
+    const float* g2;
+    const float* be2;
+    const float* br;
+    const float* tv;        /* fp32 [B][...], row stride tv_bs, this block's 256 values */
+    const float* rowmask;
+    int64_t a_bs, x_bs, tv_bs, rm_bs;
+    int32_t lda, cin, B, T;
+    float eps;
+    MmxEstNext next;
+} MmxEstResnetParams;
+int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, hipStream_t stream);
+int mmx_est_resnet(const MmxEstResnetParams* p, int dtype, int bm, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

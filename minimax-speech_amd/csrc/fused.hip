@@ -1,0 +1,624 @@
+// Row-tile fused kernels of the CFM estimator (speech/cosyvoice/flow/decoder.py:405-496 with
+// matcha/models/components/transformer.py:243-316 and decoder.py:56-61 of the reference) for gfx950.
+//
+// The estimator is 14 x (causal ResNet block + 4 transformer blocks) at full time resolution with C = 256 channels:
+// per block a chain of short-K GEMMs (K = 256 .. 1536) over M = B*T rows.  As separate launches every link of the
+// chain is latency bound (5-15 us per launch at M = 1 000 .. 14 000, 8 launches per transformer block, MFMA busy
+// 10 %: profiles/r01_pmc_flow_kernels.txt).  Only attention mixes rows; everything between two attentions is
+// row-local.  So one workgroup takes a tile of BM rows through the whole row-local chain:
+//
+//   est_tail_kernel   : attn-out projection + residual -> LayerNorm -> FF1 + GELU -> FF2 + residual
+//                       -> [LayerNorm of the NEXT block -> its Q/K/V projection]  or  [masked activation copy]
+//   est_resnet_kernel : causal conv k3 -> LayerNorm -> Mish (+ time embedding) -> causal conv k3 -> LayerNorm -> Mish
+//                       -> + 1x1 residual conv -> LayerNorm of the next block -> its Q/K/V projection
+//
+// A transformer block is then 2 launches (this + flash attention) instead of 8, a ResNet block 1 instead of 5, and
+// the fp32 residual stream, the LayerNorm outputs and the 1024-wide FF intermediate never leave the CU.
+//
+// Data flow inside a workgroup (256 threads = 4 waves, one per SIMD):
+//   * the A operand of every GEMM stage is a row tile resident in LDS (full K, row pitch = 32 B mod 256 B so that
+//     the ds_read_b128 fragment reads are bank-conflict free: MI355X_MICROARCH.md, LDS);
+//   * weights are pre-packed in MFMA B-fragment order ([n/16][k/KB][64 lanes][16 B], mmx_pack_skinny) and streamed
+//     from L2 straight into registers, 1 KiB per wave-instruction, through a 2-deep register ring that runs ahead
+//     across stage boundaries (the next stage's first fragments are in flight during the current epilogue);
+//   * every wave owns a 64-column slice of each stage's N; accumulators (MFMA C layout: lane = column) are turned
+//     into the row layout (lane = 16 consecutive columns of one row) through a private LDS patch, so LayerNorm
+//     reductions are in-lane + 2 shuffles + one LDS exchange across the 4 waves, and every global / LDS store is a
+//     16-byte access;
+//   * FF1 -> FF2 is chunked over the intermediate (2 x 512 columns): FF2 accumulates chunk by chunk, the
+//     intermediate lives in the LDS buffer the attention output occupied.
+//
+// bf16 build: v_mfma_f32_16x16x32_bf16; fp32 parity build: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), fp32 tiles.
+#include "common.h"
+#include "../../include/mmx_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+template <typename T> struct FT;
+template <> struct FT<bf16_t> { static constexpr int E = 8, KB = 32; typedef short8_t frag_t; };
+template <> struct FT<float> { static constexpr int E = 4, KB = 16; typedef float4_t frag_t; };
+
+template <typename T>
+__device__ __forceinline__ float4_t mma(typename FT<T>::frag_t a, typename FT<T>::frag_t b, float4_t c) {
+    if constexpr (sizeof(T) == 2) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+        return c;
+    }
+}
+
+// LDS row pitch in bytes of a [rows][K] tile of T: 32 B mod 256 B (conflict-free fragment reads)
+__host__ __device__ constexpr int tile_pitch(int K, int esz) { return ((K * esz + 255) & ~255) + 32; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// One GEMM stage of a wave: acc[MF][NF] += A(LDS row tile) x W(packed fragments, NF n-fragments of 16 columns).
+// The weight ring holds PF k-steps ahead; run() refills it from THIS stage while k-steps remain and from the NEXT
+// stage afterwards, so a stage starts with its first fragments already in registers.
+template <typename T, int NF>
+struct WRing {
+    static constexpr int E = FT<T>::E, PF = 2;
+    u32x4_t w[PF][NF];
+    __device__ __forceinline__ void prime(const T* wb, long ns, int nk) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                w[p][j] = *reinterpret_cast<const u32x4_t*>(wb + j * ns + (long)(p < nk ? p : nk - 1) * 64 * E);
+    }
+};
+
+// a_lane: LDS byte address of this lane's 16-byte chunk of (m-fragment 0, row l16, k-step 0): tile + l16*pitch + g*16.
+// K is walked as `taps` groups of `cin_steps` k-steps; tap t reads the tile `t` rows further down (causal conv k3:
+// taps = 3; Linear: taps = 1).  wb / ns / nk: packed weights of this stage for this wave (lane offset included),
+// elements between n-fragments, k-steps (even).  wbn / nsn: the next stage's (NULL: none).
+template <typename T, int MF, int NF>
+__device__ __forceinline__ void stage_run(WRing<T, NF>& ring, const char* a_lane, int pitch, int cin_steps,
+                                          const T* wb, long ns, int nk, const T* wbn, long nsn, int nkn,
+                                          float4_t (&acc)[MF][NF]) {
+    constexpr int E = FT<T>::E, KB = FT<T>::KB, PF = WRing<T, NF>::PF;
+    typedef typename FT<T>::frag_t frag_t;
+    int tap = 0, c = 0;
+    for (int ks = 0; ks < nk; ks += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const char* ap = a_lane + tap * pitch + c * (KB * (int)sizeof(T));
+            frag_t a[MF], b[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const frag_t*>(ap + i * 16 * pitch);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) b[j] = __builtin_bit_cast(frag_t, ring.w[p][j]);
+            // refill this ring slot: k-step ks+p+PF of this stage, or the head of the next stage (uniform select,
+            // no branch around the loads: the compiler then keeps counted vmcnt waits)
+            const int nx = ks + p + PF;
+            const bool here = nx < nk;
+            const int nxn = wbn ? (nx - nk < nkn ? nx - nk : nkn - 1) : nk - 1;
+            const T* src = here ? wb + (long)nx * 64 * E : (wbn ? wbn + (long)nxn * 64 * E : wb + (long)nxn * 64 * E);
+            const long sst = here ? ns : (wbn ? nsn : ns);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) ring.w[p][j] = *reinterpret_cast<const u32x4_t*>(src + j * sst);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[i][j] = mma<T>(a[i], b[j], acc[i][j]);
+            if (++c == cin_steps) { c = 0; ++tap; }
+        }
+    }
+}
+
+template <int MF, int NF>
+__device__ __forceinline__ void zero_acc(float4_t (&acc)[MF][NF]) {
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+}
+
+// MFMA C layout (lane = column l16 of n-fragment j, rows 4g..4g+3) -> row layout: lane owns row (lane >> 2) of the
+// 16-row fragment and the 16 consecutive columns (lane & 3)*16 .. +15 of the wave's 64-column slice.
+constexpr int LDC = 68;                                // fp32 patch row: 64 + 4 pad (conflict-free ds_write_b32)
+__device__ __forceinline__ void to_rows(const float4_t (&acc)[4], float* patch, int lane, float (&v)[16]) {
+    const int g = lane >> 4, l16 = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(4 * g + r) * LDC + j * 16 + l16] = acc[j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* src = patch + (lane >> 2) * LDC + (lane & 3) * 16;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+        const float4_t t = *reinterpret_cast<const float4_t*>(src + c);
+        v[c] = t[0]; v[c + 1] = t[1]; v[c + 2] = t[2]; v[c + 3] = t[3];
+    }
+    __builtin_amdgcn_wave_barrier();                   // the patch is rewritten by the next fragment
+}
+
+__device__ __forceinline__ void load16(const float* p, float (&v)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+        const float4_t t = *reinterpret_cast<const float4_t*>(p + c);
+        v[c] = t[0]; v[c + 1] = t[1]; v[c + 2] = t[2]; v[c + 3] = t[3];
+    }
+}
+__device__ __forceinline__ void store16(float* p, const float (&v)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) *reinterpret_cast<float4_t*>(p + c) = float4_t{v[c], v[c + 1], v[c + 2], v[c + 3]};
+}
+// 16 consecutive values as T (global or LDS destination, 16-byte aligned)
+template <typename T>
+__device__ __forceinline__ void store16_T(T* p, const float (&v)[16]) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int c = 0; c < 16; c += 8) {
+            uint4 pk;
+            pk.x = pack_bf16x2(v[c], v[c + 1]);
+            pk.y = pack_bf16x2(v[c + 2], v[c + 3]);
+            pk.z = pack_bf16x2(v[c + 4], v[c + 5]);
+            pk.w = pack_bf16x2(v[c + 6], v[c + 7]);
+            *reinterpret_cast<uint4*>(p + c) = pk;
+        }
+    } else {
+        store16(p, v);
+    }
+}
+
+// LayerNorm of the rows of a [BMR x 256] tile held in the row layout (v[i][16] per wave, 4 waves x 64 columns).
+// Two-pass statistics like torch (mean, then the mean of squared deviations), partial sums exchanged through
+// stats[BMR][4].  Contains 3 workgroup barriers; all waves must call it.  Leaves normalised*gamma+beta in v.
+template <int MFR>
+__device__ __forceinline__ void layernorm_rows(float (&v)[MFR][16], float* stats, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps, int wave, int lane, int col0) {
+    const int rl = lane >> 2;
+    float mean[MFR];
+    __syncthreads();                                   // stats free (previous readers done)
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += v[i][c];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if ((lane & 3) == 0) stats[(i * 16 + rl) * 4 + wave] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) {
+        const float4_t t = *reinterpret_cast<const float4_t*>(stats + (i * 16 + rl) * 4);
+        mean[i] = ((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 256.0f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) {
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const float d = v[i][c] - mean[i]; q += d * d; }
+        q += __shfl_xor(q, 1, 64);
+        q += __shfl_xor(q, 2, 64);
+        if ((lane & 3) == 0) stats[(i * 16 + rl) * 4 + wave] = q;
+    }
+    __syncthreads();
+    float g[16], be[16];
+    load16(gamma + col0, g);
+    load16(beta + col0, be);
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) {
+        const float4_t t = *reinterpret_cast<const float4_t*>(stats + (i * 16 + rl) * 4);
+        const float rstd = rsqrtf(((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 256.0f) + eps);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[i][c] = (v[i][c] - mean[i]) * rstd * g[c] + be[c];
+    }
+}
+
+// cooperative copy of `rows` rows x K elements (global row stride ld, first row index r0 of `nrows_valid` valid
+// rows starting at `src`; rows outside [0, nvalid) read zero) into an LDS tile with `pitch` bytes per row
+template <typename T>
+__device__ __forceinline__ void load_tile(const T* __restrict__ src, long ld, int r0, int nvalid, int rows, int K,
+                                          char* tile, int pitch, int tid) {
+    constexpr int E = FT<T>::E;
+    const int cpr = K / E;                             // 16-byte chunks per row
+    const int total = rows * cpr;
+    for (int id = tid; id < total; id += 256) {
+        const int r = id / cpr, ch = id - r * cpr;
+        const int gr = r0 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gr >= 0 && gr < nvalid) v = *reinterpret_cast<const uint4*>(src + (long)gr * ld + ch * E);
+        *reinterpret_cast<uint4*>(tile + r * pitch + ch * 16) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shared tail of both kernels: x (row layout, 64 columns per wave) -> LayerNorm(n1) -> A1 tile -> Q/K/V projection.
+// bf16: Q,K row-major [B][T][1024] and V TRANSPOSED vt[b][512][Tp] (what the flash kernel reads);
+// fp32: q|k|v row-major [B][T][1536] (the dense attention kernel reads strided heads).
+// Q/K/V pass p (0..5) of a wave: kind = p >> 1 (Q, K, V), 64 columns at kind*512 + wave*128 + (p & 1)*64 of the
+// packed [1536][256] projection; returns the wave's (lane-offset) fragment pointer.
+template <typename T>
+__device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lane, int p) {
+    constexpr int E = FT<T>::E, KB = FT<T>::KB;
+    return reinterpret_cast<const T*>(wqkv) + (long)lane * E +
+           (long)(((p >> 1) * 512 + wave * 128 + (p & 1) * 64) / 16) * ((long)(256 / KB) * 64 * E);
+}
+
+// the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
+template <typename T, int MF>
+__device__ __forceinline__ void ln_qkv(float (&xv)[MF][16], const MmxEstNext& nx, float eps, char* a1, char* vp, float* patch,
+                                       float* stats, WRing<T, 4>& ring, int b, int t0, int Tn, int wave, int lane, int tid) {
+    constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256;
+    constexpr int P1 = tile_pitch(C, sizeof(T));
+    constexpr int NK = C / KB;
+    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
+    const long ns = (long)NK * 64 * E;
+    auto pass_w = [&](int p) { return qkv_pass<T>(nx.wqkv, wave, lane, p); };
+    layernorm_rows<MF>(xv, stats, nx.n1g, nx.n1b, eps, wave, lane, wave * 64 + cq);
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+        store16_T<T>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + wave * 64 + cq, xv[i]);
+    __syncthreads();
+    const char* a_lane = a1 + l16 * P1 + g * 16;
+    constexpr bool VT = sizeof(T) == 2;
+    constexpr int PV = MF * 16 * (int)sizeof(T) + 16;  // V^T patch row pitch: [64 columns][BM frames]
+    for (int p = 0; p < 6; ++p) {
+        float4_t acc[MF][4];
+        zero_acc(acc);
+        const T* wn = p < 5 ? pass_w(p + 1) : nullptr;
+        stage_run<T, MF, 4>(ring, a_lane, P1, NK, pass_w(p), ns, NK, wn, ns, NK, acc);
+        const int kind = p >> 1, cw = wave * 128 + (p & 1) * 64;   // column inside the 512-wide Q / K / V
+        if (VT && kind == 2) {
+            // C layout -> [column][frame] patch: a lane holds 4 consecutive frames of one column
+            char* vw = vp + wave * 64 * PV;
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                    pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    *reinterpret_cast<uint2*>(vw + (j * 16 + l16) * PV + (i * 16 + 4 * g) * 2) = pk;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // lane = column; 16-byte chunks of 8 frames; frames >= Tn are written as zeros (the pad stays finite)
+            bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)(cw + lane) * nx.ldvt + t0;
+#pragma unroll
+            for (int c8 = 0; c8 < MF * 2; ++c8) {
+                uint4 v = *reinterpret_cast<const uint4*>(vw + lane * PV + c8 * 16);
+                const int t = t0 + c8 * 8;
+                if (t >= Tn) continue;
+                if (t + 8 > Tn) {
+                    unsigned short* h = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (t + e >= Tn) h[e] = 0;
+                }
+                *reinterpret_cast<uint4*>(dst + c8 * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            T* out = reinterpret_cast<T*>(nx.q_out) + (long)b * nx.q_bs;
+            const int col = kind * 512 + cw + cq;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                float v[16];
+                to_rows(acc[i], patch, lane, v);
+                const int t = t0 + i * 16 + rl;
+                if (t < Tn) store16_T<T>(out + (long)t * nx.ldq + col, v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BM>
+__global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
+    constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
+    constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
+    constexpr bool PRECISE = sizeof(T) == 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* buf0 = smem;                                 // [BM][512] attention output, then the FF intermediate chunk,
+                                                       // then the V^T patches
+    char* a1 = buf0 + BM * P0;                         // [BM][256] LayerNorm output (A operand of FF1 / QKV)
+    float* patch_all = reinterpret_cast<float*>(a1 + BM * P1);
+    float* stats = patch_all + 4 * 16 * LDC;           // [BM][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
+    float* patch = patch_all + wave * 16 * LDC;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM, Tn = p.T;
+    const int col0 = wave * 64 + cq;                   // this lane's 16 columns of a 256-wide row
+
+    const T* wo = reinterpret_cast<const T*>(p.wo) + (long)lane * E;
+    const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
+    const T* w2 = reinterpret_cast<const T*>(p.w2) + (long)lane * E;
+    constexpr int NK0 = CI / KB, NK1 = C / KB, NK2 = CH / KB, NK2T = CF / KB;
+    const long ns0 = (long)NK0 * 64 * E, ns1 = (long)NK1 * 64 * E, ns2 = (long)NK2T * 64 * E;
+    WRing<T, 4> ring;
+    const T* wo_w = wo + (long)(wave * 4) * ns0;       // n-fragments 4*wave .. +3 (64 columns)
+    ring.prime(wo_w, ns0, NK0);
+    load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid);
+    __syncthreads();
+
+    // ---- attention output projection + bias + residual  (transformer.py:290-297: attn1 -> + hidden_states)
+    // FF1 pass q (0..3): chunk q >> 1, 64 columns at chunk*512 + wave*128 + (q & 1)*64
+    auto w1_pass = [&](int q) { return w1 + (long)(((q >> 1) * CH + wave * 128 + (q & 1) * 64) / 16) * ns1; };
+    float x1[MF][16];
+    {
+        float4_t acc[MF][4];
+        zero_acc(acc);
+        stage_run<T, MF, 4>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, acc);
+        float bo[16];
+        load16(p.bo + col0, bo);
+        const float* xr = p.x + (long)b * p.x_bs;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            to_rows(acc[i], patch, lane, x1[i]);
+            const int t = t0 + i * 16 + rl;
+            float r[16];
+            if (t < Tn) load16(xr + (long)t * C + col0, r);
+            else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) r[c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x1[i][c] += bo[c] + r[c];
+        }
+    }
+    // ---- LayerNorm (norm3) -> A1
+    {
+        float hn[MF][16];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) hn[i][c] = x1[i][c];
+        layernorm_rows<MF>(hn, stats, p.n3g, p.n3b, p.eps, wave, lane, col0);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) store16_T<T>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + col0, hn[i]);
+    }
+    __syncthreads();                                   // A1 complete; every wave is done with the attention tile
+    // ---- FF1 + GELU -> LDS chunk -> FF2 accumulate  (transformer.py:306-313, diffusers GELU = Linear + exact gelu)
+    float4_t acc2[MF][4];
+    zero_acc(acc2);
+    const T* w2_w = w2 + (long)(wave * 4) * ns2;       // FF2: 64 output columns per wave, K walked per chunk
+    for (int ch = 0; ch < 2; ++ch) {
+        for (int h = 0; h < 2; ++h) {
+            const int q = ch * 2 + h;
+            float4_t acc[MF][4];
+            zero_acc(acc);
+            const T* wn = h == 0 ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
+            stage_run<T, MF, 4>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, h == 0 ? ns1 : ns2,
+                                h == 0 ? NK1 : NK2, acc);
+            const int hc = wave * 128 + h * 64 + cq;   // column inside the chunk
+            float b1[16];
+            load16(p.b1 + ch * CH + hc, b1);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                float v[16];
+                to_rows(acc[i], patch, lane, v);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v[c] = act_c<ACT_GELU, PRECISE>(v[c] + b1[c], 0.f);
+                store16_T<T>(reinterpret_cast<T*>(buf0 + (i * 16 + rl) * P0) + hc, v);
+            }
+        }
+        __syncthreads();                               // the chunk is complete
+        const T* wn = ch == 0 ? w1_pass(2) : (p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr);
+        stage_run<T, MF, 4>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, acc2);
+        __syncthreads();                               // every wave is done reading the chunk
+    }
+    // ---- + bias + residual -> x (fp32 residual stream, in place)
+    {
+        float b2[16];
+        load16(p.b2 + col0, b2);
+        float* xw = p.x + (long)b * p.x_bs;
+        const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            float v[16];
+            to_rows(acc2[i], patch, lane, v);
+            const int t = t0 + i * 16 + rl;
+            const float rm = (rmk && t < Tn) ? rmk[t] : 1.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x1[i][c] = (x1[i][c] + v[c] + b2[c]) * rm;
+            if (t < Tn) {
+                store16(xw + (long)t * C + col0, x1[i]);
+                if (p.act_out)
+                    store16_T<T>(reinterpret_cast<T*>(p.act_out) + (long)b * p.act_bs + (long)t * p.act_ld + col0, x1[i]);
+            }
+        }
+    }
+    if (p.next.wqkv) ln_qkv<T, MF>(x1, p.next, p.eps, a1, buf0, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BM>
+__global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
+    constexpr int MF = BM / 16, MH = MF + 1, E = FT<T>::E, KB = FT<T>::KB, C = 256;
+    constexpr int P1 = tile_pitch(C, sizeof(T));
+    constexpr bool PRECISE = sizeof(T) == 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cin = p.cin;
+    const int PA = tile_pitch(cin, sizeof(T));
+    char* ain = smem;                                  // [BM + 18][cin]: input rows t0-18 .. t0+BM-1; later V^T patches
+    char* h1 = ain + (BM + 18) * PA;                   // [BM + 16][256]: block1 output rows t0-16 ..; later the A1 tile
+    float* patch_all = reinterpret_cast<float*>(h1 + (BM + 16) * P1);
+    float* stats = patch_all + 4 * 16 * LDC;           // [BM + 16][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
+    float* patch = patch_all + wave * 16 * LDC;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM, Tn = p.T;
+    const int col0 = wave * 64 + cq;
+    const int cs = cin / KB;                           // k-steps per tap
+    const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
+    const T* w2 = reinterpret_cast<const T*>(p.w2) + (long)lane * E;
+    const T* wr = reinterpret_cast<const T*>(p.wr) + (long)lane * E;
+    const int nk1 = 3 * cs, nk2 = 3 * (C / KB), nkr = cs;
+    const long ns1 = (long)nk1 * 64 * E, ns2 = (long)nk2 * 64 * E, nsr = (long)nkr * 64 * E;
+    const T* w1_w = w1 + (long)(wave * 4) * ns1;
+    const T* w2_w = w2 + (long)(wave * 4) * ns2;
+    const T* wr_w = wr + (long)(wave * 4) * nsr;
+    WRing<T, 4> ring;
+    ring.prime(w1_w, ns1, nk1);
+    load_tile<T>(reinterpret_cast<const T*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, tid);
+    __syncthreads();
+    const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
+
+    // ---- block1: causal conv k3 (cin -> 256) + bias -> LayerNorm -> Mish -> * mask, + time embedding, * mask
+    //      (flow/decoder.py:65-85 with matcha decoder.py:56-61) for rows t0-16 .. t0+BM-1 (conv2 needs 2 rows of halo)
+    {
+        float4_t acc[MH][4];
+        zero_acc(acc);
+        stage_run<T, MH, 4>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, acc);
+        float hv[MH][16], bb[16], tv[16];
+        load16(p.b1 + col0, bb);
+        load16(p.tv + (long)b * p.tv_bs + col0, tv);
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+            to_rows(acc[i], patch, lane, hv[i]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) hv[i][c] += bb[c];
+        }
+        layernorm_rows<MH>(hv, stats, p.g1, p.be1, p.eps, wave, lane, col0);
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+            const int t = t0 - 16 + i * 16 + rl;
+            const float rm = (t >= 0 && t < Tn) ? (rmk ? rmk[t] : 1.f) : 0.f;
+            float o[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float y = act_c<ACT_MISH, PRECISE>(hv[i][c], 0.f) * rm;
+                o[c] = t >= 0 ? (y + tv[c]) * rm : 0.f;               // rows before the sequence start are conv padding
+            }
+            store16_T<T>(reinterpret_cast<T*>(h1 + (i * 16 + rl) * P1) + col0, o);
+        }
+    }
+    __syncthreads();
+    // ---- block2: causal conv k3 (256 -> 256) -> LayerNorm -> Mish -> * mask
+    float h2[MF][16];
+    {
+        float4_t acc[MF][4];
+        zero_acc(acc);
+        stage_run<T, MF, 4>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, acc);
+        float bb[16];
+        load16(p.b2 + col0, bb);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            to_rows(acc[i], patch, lane, h2[i]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) h2[i][c] += bb[c];
+        }
+        layernorm_rows<MF>(h2, stats, p.g2, p.be2, p.eps, wave, lane, col0);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int t = t0 + i * 16 + rl;
+            const float rm = t < Tn ? (rmk ? rmk[t] : 1.f) : 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) h2[i][c] = act_c<ACT_MISH, PRECISE>(h2[i][c], 0.f) * rm;
+        }
+    }
+    // ---- + res_conv(x) (1x1) -> x (fp32 residual stream)
+    {
+        float4_t acc[MF][4];
+        zero_acc(acc);
+        const T* wq0 = p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr;
+        stage_run<T, MF, 4>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, acc);
+        float bb[16];
+        load16(p.br + col0, bb);
+        float* xw = p.x + (long)b * p.x_bs;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            float v[16];
+            to_rows(acc[i], patch, lane, v);
+            const int t = t0 + i * 16 + rl;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) h2[i][c] += v[c] + bb[c];
+            if (t < Tn) store16(xw + (long)t * C + col0, h2[i]);
+        }
+    }
+    __syncthreads();                                   // every wave is done with ain / h1 (reused by ln_qkv)
+    if (p.next.wqkv) ln_qkv<T, MF>(h2, p.next, p.eps, h1, ain, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+}
+
+template <typename T, int BM>
+size_t tail_lds() {
+    return (size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T)) + 4 * 16 * LDC * 4 + (size_t)BM * 16;
+}
+template <typename T, int BM>
+size_t resnet_lds(int cin) {
+    return (size_t)(BM + 18) * tile_pitch(cin, sizeof(T)) + (size_t)(BM + 16) * tile_pitch(256, sizeof(T)) + 4 * 16 * LDC * 4 +
+           (size_t)(BM + 16) * 16;
+}
+
+int check_next(const MmxEstNext& nx, int dtype, int T_) {
+    if (!nx.wqkv) return MMX_OK;
+    MMX_CHECK_ARG(nx.n1g && nx.n1b && nx.q_out);
+    MMX_CHECK_ARG(((uintptr_t)nx.q_out % 16) == 0 && nx.q_bs % 8 == 0);
+    if (dtype == MMX_BF16) {
+        MMX_CHECK_ARG(nx.vt_out && nx.ldq % 8 == 0 && nx.ldq >= 1024 && nx.ldvt % 8 == 0 && nx.ldvt >= ((T_ + 7) / 8) * 8);
+        MMX_CHECK_ARG(((uintptr_t)nx.vt_out % 16) == 0 && nx.vt_bs % 8 == 0);
+    } else {
+        MMX_CHECK_ARG(nx.ldq % 4 == 0 && nx.ldq >= 1536);
+    }
+    return MMX_OK;
+}
+
+}  // namespace
+
+extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, hipStream_t stream) {
+    MMX_CHECK_ARG(pp != nullptr);
+    const MmxEstTailParams& p = *pp;
+    MMX_CHECK_ARG(p.ao && p.x && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.n3g && p.n3b && p.B > 0 && p.T > 0);
+    MMX_CHECK_ARG(p.ldao >= 512 && p.ldao % 8 == 0 && p.ao_bs % 8 == 0 && p.x_bs % 4 == 0);
+    MMX_CHECK_ARG(((uintptr_t)p.ao % 16) == 0 && ((uintptr_t)p.x % 16) == 0);
+    MMX_CHECK_ARG(!p.act_out || (p.act_ld % 8 == 0 && p.act_bs % 8 == 0 && ((uintptr_t)p.act_out % 16) == 0));
+    if (int rc = check_next(p.next, dtype, p.T)) return rc;
+#define TAIL(TT, BM)                                                                                       \
+    do {                                                                                                   \
+        const size_t lds = tail_lds<TT, BM>();                                                              \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_tail_kernel<TT, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+    } while (0)
+    if (dtype == MMX_BF16) {
+        if (bm == 64) TAIL(bf16_t, 64);
+        else if (bm == 32) TAIL(bf16_t, 32);
+        else if (bm == 16) TAIL(bf16_t, 16);
+        else return MMX_EARG;
+    } else if (dtype == MMX_F32) {
+        if (bm == 32) TAIL(float, 32);
+        else if (bm == 16) TAIL(float, 16);
+        else return MMX_EARG;
+    } else return MMX_EARG;
+#undef TAIL
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, hipStream_t stream) {
+    MMX_CHECK_ARG(pp != nullptr);
+    const MmxEstResnetParams& p = *pp;
+    MMX_CHECK_ARG(p.a_in && p.x && p.w1 && p.w2 && p.wr && p.b1 && p.b2 && p.br && p.g1 && p.be1 && p.g2 && p.be2 && p.tv);
+    MMX_CHECK_ARG(p.B > 0 && p.T > 0 && p.cin >= 64 && p.cin % 32 == 0 && p.cin <= 512 && p.lda >= p.cin && p.lda % 8 == 0 && p.a_bs % 8 == 0);
+    MMX_CHECK_ARG(((uintptr_t)p.a_in % 16) == 0 && ((uintptr_t)p.x % 16) == 0 && p.x_bs % 4 == 0 && p.tv_bs % 4 == 0 && ((uintptr_t)p.tv % 16) == 0);
+    if (int rc = check_next(p.next, dtype, p.T)) return rc;
+#define RESN(TT, BM)                                                                                       \
+    do {                                                                                                   \
+        const size_t lds = resnet_lds<TT, BM>(p.cin);                                                       \
+        MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_resnet_kernel<TT, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
+        hipLaunchKernelGGL((est_resnet_kernel<TT, BM>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+    } while (0)
+    if (dtype == MMX_BF16) {
+        if (bm == 64) RESN(bf16_t, 64);
+        else if (bm == 32) RESN(bf16_t, 32);
+        else if (bm == 16) RESN(bf16_t, 16);
+        else return MMX_EARG;
+    } else if (dtype == MMX_F32) {
+        if (bm == 16) RESN(float, 16);
+        else return MMX_EARG;
+    } else return MMX_EARG;
+#undef RESN
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")
 SYMBOLS = [
     "mmx_abi_version", "mmx_gemm_win", "mmx_gemm_win_tile", "mmx_rownorm", "mmx_groupnorm", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
     "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_conv_cout1_tanh", "mmx_conv_cin1", "mmx_vae_sample",
-    "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_decode_attn", "mmx_swiglu", "mmx_sample_step",
+    "mmx_est_tail", "mmx_est_resnet", "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_decode_attn", "mmx_swiglu", "mmx_sample_step",
 ]
 
 
@@ -33,6 +33,33 @@ class GemmParams(C.Structure):
         ("bias_mod", C.c_int32), ("alpha_mod", C.c_int32), ("bias_per_row", C.c_int32),
         ("act", C.c_int32), ("act2", C.c_int32), ("slope", C.c_float), ("row_stride", C.c_int32),
     ]
+
+
+class EstNext(C.Structure):
+    _fields_ = [("wqkv", C.c_void_p), ("n1g", C.c_void_p), ("n1b", C.c_void_p), ("q_out", C.c_void_p), ("vt_out", C.c_void_p),
+                ("q_bs", C.c_int64), ("vt_bs", C.c_int64), ("ldq", C.c_int32), ("ldvt", C.c_int32)]
+
+
+class EstTailParams(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("ao", "x", "wo", "w1", "w2", "bo", "b1", "b2", "n3g", "n3b", "rowmask", "act_out")] + \
+               [(k, C.c_int64) for k in ("ao_bs", "x_bs", "rm_bs", "act_bs")] + \
+               [(k, C.c_int32) for k in ("ldao", "act_ld", "B", "T")] + [("eps", C.c_float), ("next", EstNext)]
+
+
+class EstResnetParams(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("a_in", "x", "w1", "w2", "wr", "b1", "g1", "be1", "b2", "g2", "be2", "br", "tv", "rowmask")] + \
+               [(k, C.c_int64) for k in ("a_bs", "x_bs", "tv_bs", "rm_bs")] + \
+               [(k, C.c_int32) for k in ("lda", "cin", "B", "T")] + [("eps", C.c_float), ("next", EstNext)]
+
+
+def fill_struct(st, **kw):
+    """Sets fields of a ctypes structure; tensors become device addresses."""
+    for k, v in kw.items():
+        if v is not None and hasattr(v, "data_ptr"):
+            assert v.is_cuda
+            v = v.data_ptr()
+        setattr(st, k, v)
+    return st
 
 
 _lib = None

@@ -89,11 +89,16 @@ class Graphed:
 
 class FlowEngine:
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", n_timesteps=10, cfg_rate=0.7,
-                 enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True, parts=("encoder", "estimator")):
+                 enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True, parts=("encoder", "estimator"),
+                 fused=True):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
         self.enc_chunk, self.est_chunk = enc_chunk, est_chunk
         self.use_graphs = use_graphs
+        # fused=True: the estimator runs on the row-tile kernels of csrc/fused.hip (2 launches per transformer block,
+        # 1 per ResNet block); fused=False keeps one launch per Linear / Conv1d / LayerNorm (the composition the fused
+        # kernels are tested against, tests/test_gpu_kernels.py)
+        self.fused = fused
         dt = dtype
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         lin = lambda k: ops.pack_linear(f(k), dt)
@@ -179,6 +184,10 @@ class FlowEngine:
                      w1=lin(p + ".ff.net.0.proj.weight"), b1=f(p + ".ff.net.0.proj.bias"),
                      w2=lin(p + ".ff.net.2.weight"), b2=f(p + ".ff.net.2.bias"))
             wq, wk, wv = f(a + ".to_q.weight"), f(a + ".to_k.weight"), f(a + ".to_v.weight")
+            if self.fused:
+                pk = lambda w: ops.pack_skinny(w.to(self.tdt).contiguous(), dtype=dt)
+                d.update(wo_p=pk(f(a + ".to_out.0.weight")), w1_p=pk(f(p + ".ff.net.0.proj.weight")),
+                         w2_p=pk(f(p + ".ff.net.2.weight")), wqkv_p=pk(torch.cat([wq, wk, wv], 0)))
             if dt == BF16:
                 d["wqk"] = ops.pack_linear(torch.cat([wq, wk], 0), dt)       # [1024, 256]
                 d["wv"] = ops.pack_linear(wv, dt)                            # A operand of the V^T GEMM
@@ -196,6 +205,9 @@ class FlowEngine:
                      w2=cv(p + ".block2.block.0.weight"), b2=f(p + ".block2.block.0.bias"),
                      g2=f(p + ".block2.block.2.weight"), be2=f(p + ".block2.block.2.bias"),
                      wr=cv(p + ".res_conv.weight"), br=f(p + ".res_conv.bias"))
+            if self.fused:
+                pc = lambda k: ops.pack_skinny(ops.pack_conv1d(f(k), dt), dtype=dt)
+                r.update(w1_p=pc(p + ".block1.block.0.weight"), w2_p=pc(p + ".block2.block.0.weight"), wr_p=pc(p + ".res_conv.weight"))
             mlp_w.append(f(p + ".mlp.1.weight"))
             mlp_b.append(f(p + ".mlp.1.bias"))
             self.resnets.append(r)
@@ -371,6 +383,8 @@ class FlowEngine:
     def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None):
         """All inputs fp32 time-major device tensors: x [x_mod,T,80] (batch b reads x[b % x_mod]), mu/cond [B,T,80],
         spks [B,80], t [B]; mask fp32 [B,T] or None.  Returns fp32 [B,T,80]."""
+        if self.fused:
+            return self._estimator_fused(x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod)
         dt, C = self.dtype, self.C
         chunk = self.est_chunk if streaming else 0
         te = self._new(B, self.tdim)
@@ -409,6 +423,84 @@ class FlowEngine:
         self._resnet(self.up["res"], cat, 2 * C, B, T, tv, mask, xs)
         for j, w in enumerate(self.up["blocks"]):
             self._tblock(w, xs, B, T, mask, chunk, act_out=(a if j == 3 else None), act_ld=C)
+        a2 = self._new(B, T, C)
+        ops.conv1d(a, self.up_w, T=T, Cin=C, k=3, pad_left=2, dtype=dt, batch=B, bias=self.up_b, rowmask=mask, out_act=a2)
+        c1 = self._new(B, T, C, f32=True)
+        ops.conv1d(a2, self.fin_w, T=T, Cin=C, k=3, pad_left=2, dtype=dt, batch=B, bias=self.fin_b, out_f32=c1)
+        ops.rownorm(c1, self.fin_g, self.fin_be, 1e-5, rows=T, C_=C, batch=B, act="mish", rowmask=mask, out_act=a, dtype=dt)
+        if out is None:
+            out = self._new(B, T, 80, f32=True)
+        ops.conv1d(a, self.proj_w, T=T, Cin=C, k=1, dtype=dt, batch=B, bias=self.proj_b, rowmask=mask, out_f32=out)
+        return out
+
+    # ------------------------------------------------------------------ estimator on the row-tile fused kernels
+    def _tile_rows(self, B, T):
+        """Rows per workgroup of the fused kernels: the largest tile that still gives most of the 256 CUs a workgroup."""
+        tiles = lambda bm: B * ((T + bm - 1) // bm)
+        if self.dtype == BF16:
+            bm = 64 if tiles(64) >= 160 else (32 if tiles(32) >= 128 else 16)
+            return bm, bm
+        return (32 if tiles(32) >= 128 else 16), 16            # fp32: tail, resnet (LDS: fp32 tiles are twice as large)
+
+    def _estimator_fused(self, x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod):
+        dt, C = self.dtype, self.C
+        chunk = self.est_chunk if streaming else 0
+        bm_t, bm_r = self._tile_rows(B, T)
+        te = self._new(B, self.tdim)
+        ops.sinusoidal_emb(t, te, dim=self.tdim, dtype=dt)
+        t1 = self._new(B, 1024)
+        ops.linear(te, self.t_w1, self.tdim, dtype=dt, bias=self.t_b1, act="silu", out_act=t1)
+        t2 = self._new(B, 1024)
+        ops.linear(t1, self.t_w2, 1024, dtype=dt, bias=self.t_b2, act2="mish", out_act=t2)
+        ntv = self.mlp_w.shape[0]
+        tv = self._new(B, ntv, f32=True)
+        ops.linear(t2, self.mlp_w, 1024, dtype=dt, bias=self.mlp_b, out_f32=tv)
+        h0 = self._new(B, T, 320)
+        ops.est_pack(x, mu, spks, cond, h0, B=B, T=T, dtype=dt, x_bstride=x_bstride, x_mod=(x_mod or B))
+        xs = self._new(B, T, C, f32=True)
+        cat = self._new(B, T, 2 * C)
+        a = self._new(B, T, C)
+        ao = self._new(B, T, 512)
+        bf = dt == BF16
+        if bf:
+            Tp = ops.round_up(T, 8)
+            qk, vt = self._new(B, T, 1024), self._vt_buf(B, Tp)
+        else:
+            qk, vt, Tp = self._new(B, T, 1536), None, 0
+        ldq = qk.shape[-1]
+
+        def nxt(w):
+            return ops.est_next(wqkv=w["wqkv_p"], n1g=w["n1g"], n1b=w["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
+                                vt_bs=512 * Tp)
+
+        def attention():
+            if bf:
+                ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
+                                    k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, keymask=mask, chunk=chunk)
+            else:
+                ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                               q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, keymask=mask,
+                               chunk=chunk)
+
+        def stage(st, a_in, lda, cin, act_out, act_ld):
+            r, blocks = st["res"], st["blocks"]
+            ops.est_resnet(a_in, lda, cin, xs, r, tv[:, r["idx"] * C:], ntv, B=B, T=T, dtype=dt, bm=bm_r, rowmask=mask,
+                           nxt=nxt(blocks[0]))
+            for j, w in enumerate(blocks):
+                attention()
+                last = j == len(blocks) - 1
+                ops.est_tail(ao, xs, w, B=B, T=T, dtype=dt, bm=bm_t, rowmask=(mask if last else None),
+                             act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])))
+
+        # down block: its last transformer block drops the masked activation copy into cat[:, :, C:] (the skip)
+        stage(self.down, h0, 320, 320, cat[:, :, C:], 2 * C)
+        ops.gemm(cat[:, :, C:], self.down_w, T, C, dtype=dt, lda=2 * C, cin=C, ntaps=3, row_off=-2, row_lo=0, row_hi=T,
+                 batch=B, a_bstride=T * 2 * C, bias=self.down_b, rowmask=mask, rm_bstride=T, out_act=a, ldo_a=C,
+                 oa_bstride=T * C)
+        for i, st in enumerate(self.mid):
+            lastst = i == len(self.mid) - 1
+            stage(st, a, C, C, cat if lastst else a, 2 * C if lastst else C)
+        stage(self.up, cat, 2 * C, 2 * C, a, C)
         a2 = self._new(B, T, C)
         ops.conv1d(a, self.up_w, T=T, Cin=C, k=3, pad_left=2, dtype=dt, batch=B, bias=self.up_b, rowmask=mask, out_act=a2)
         c1 = self._new(B, T, C, f32=True)

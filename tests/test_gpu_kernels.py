@@ -362,3 +362,133 @@ def test_sampler_matches_oracle(env):
             assert torch.equal(nx[0], emb[want])
             assert st[0] == 41 and st[1] == step + 1
     assert mism == 0, f"{mism} sampled ids differ from the oracle"
+
+
+# ----------------------------------------------------------------------------- fused estimator row-tile kernels (csrc/fused.hip)
+FUSED_BM = {0: [16, 32], 1: [16, 32, 64]}
+FUSED_TOL = {0: 5e-5, 1: 3e-2}
+
+
+def _pk(ops, w, dt):
+    return ops.pack_skinny(cast(w, dt).contiguous(), dtype=dt)
+
+
+def _ln(x, g, b):
+    return F.layer_norm(x, x.shape[-1:], g, b, 1e-5)
+
+
+def _check_qkv(ops, dt, hn, wqkv, qk, vt, B, T, tol, tag):
+    ref = hn @ wqkv.t()
+    if dt == 1:
+        assert rel_err(qk[:, :T], ref[..., :1024]) < tol, (tag, "qk", rel_err(qk[:, :T], ref[..., :1024]))
+        assert rel_err(vt[:, :, :T].transpose(1, 2), ref[..., 1024:]) < tol, (tag, "vt")
+        assert float(vt[:, :, T:].abs().max()) == 0.0 if vt.shape[2] > T else True
+    else:
+        assert rel_err(qk[:, :T], ref) < tol, (tag, "qkv", rel_err(qk[:, :T], ref))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,T,masked,with_next", [(2, 50, False, True), (3, 37, True, False), (1, 130, True, True), (2, 64, False, True)])
+def test_est_tail_fused(env, dt, B, T, masked, with_next):
+    """attn-out projection + residual -> LayerNorm -> FF1 + GELU -> FF2 + residual (-> LayerNorm -> Q/K/V of the next
+    block) in one launch vs plain torch fp32 (matcha transformer.py:286-313, 256-285)."""
+    L, ops = env
+    g = torch.Generator().manual_seed(100 * B + T)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+    ao, x = rn(B, T, 512), rn(B, T, 256)
+    wo, w1, w2, wqkv = rn(256, 512, sc=512 ** -0.5), rn(1024, 256, sc=1 / 16), rn(256, 1024, sc=1 / 32), rn(1536, 256, sc=1 / 16)
+    bo, b1, b2 = rn(256, sc=0.1), rn(1024, sc=0.1), rn(256, sc=0.1)
+    n3g, n3b, n1g, n1b = 1 + rn(256, sc=0.1), rn(256, sc=0.1), 1 + rn(256, sc=0.1), rn(256, sc=0.1)
+    mask = (torch.rand(B, T, generator=g) > 0.3).float().cuda() if masked else None
+    aoq, wq = cast(ao, dt), lambda w: cast(w, dt).float()
+    x1 = x + aoq.float() @ wq(wo).t() + bo
+    h = cast(_ln(x1, n3g, n3b), dt).float()
+    ff = cast(F.gelu(h @ wq(w1).t() + b1), dt).float() @ wq(w2).t() + b2
+    x2 = x1 + ff
+    if mask is not None:
+        x2 = x2 * mask[..., None]
+    hn = cast(_ln(x2, n1g, n1b), dt).float()
+    w = dict(wo_p=_pk(ops, wo, dt), w1_p=_pk(ops, w1, dt), w2_p=_pk(ops, w2, dt), bo=bo, b1=b1, b2=b2, n3g=n3g, n3b=n3b)
+    wqkv_p = _pk(ops, wqkv, dt)
+    tol = FUSED_TOL[dt]
+    for bm in FUSED_BM[dt]:
+        xio = x.clone()
+        Tp = ops.round_up(T, 8)
+        ldq = 1024 if dt == 1 else 1536
+        qk = torch.zeros(B, T, ldq, device="cuda", dtype=L.TORCH_DT[dt])
+        vt = torch.full((B, 512, Tp), 7.0, device="cuda", dtype=L.TORCH_DT[dt]) if dt == 1 else None
+        act = torch.zeros(B, T, 512, device="cuda", dtype=L.TORCH_DT[dt])
+        nxt = ops.est_next(wqkv=wqkv_p, n1g=n1g, n1b=n1b, q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp, vt_bs=512 * Tp) if with_next else None
+        ops.est_tail(aoq.contiguous(), xio, w, B=B, T=T, dtype=dt, bm=bm, rowmask=mask, act_out=act[:, :, 256:], act_ld=512, nxt=nxt)
+        torch.cuda.synchronize()
+        assert rel_err(xio, x2) < tol, (bm, "x", rel_err(xio, x2))
+        assert rel_err(act[:, :, 256:], x2) < max(tol, 1e-2 if dt == 1 else 0) and float(act[:, :, :256].abs().max()) == 0.0
+        if with_next:
+            _check_qkv(ops, dt, hn, wq(wqkv), qk, vt, B, T, tol, bm)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,T,cin,lda,masked", [(2, 50, 320, 320, False), (2, 45, 256, 512, True), (1, 100, 512, 512, True), (3, 16, 256, 256, False)])
+def test_est_resnet_fused(env, dt, B, T, cin, lda, masked):
+    """CausalResnetBlock1D (+ LayerNorm + Q/K/V of the following block) in one launch vs plain torch fp32
+    (flow/decoder.py:65-85, matcha decoder.py:56-61)."""
+    L, ops = env
+    g = torch.Generator().manual_seed(7 * B + T + cin)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+    mask = (torch.rand(B, T, generator=g) > 0.25).float().cuda() if masked else None
+    m3 = mask[..., None] if masked else 1.0
+    a_full = rn(B, T, lda) * m3
+    a_in = cast(a_full, dt)
+    wc1, wc2, wcr = rn(256, cin, 3, sc=(3 * cin) ** -0.5), rn(256, 256, 3, sc=768 ** -0.5), rn(256, cin, 1, sc=cin ** -0.5)
+    b1, b2, br = rn(256, sc=0.1), rn(256, sc=0.1), rn(256, sc=0.1)
+    g1, be1, g2, be2 = 1 + rn(256, sc=0.1), rn(256, sc=0.1), 1 + rn(256, sc=0.1), rn(256, sc=0.1)
+    tv_all = rn(B, 3 * 256)
+    tv = tv_all[:, 256:512]
+    n1g, n1b, wqkv = 1 + rn(256, sc=0.1), rn(256, sc=0.1), rn(1536, 256, sc=1 / 16)
+    wq = lambda w: cast(w, dt).float()
+    xin = a_in.float()[..., :cin].transpose(1, 2)                       # [B, cin, T]
+    conv = lambda z, w, b: F.conv1d(F.pad(z, (w.shape[2] - 1, 0)), wq(w), b).transpose(1, 2)
+    h = F.mish(_ln(conv(xin, wc1, b1), g1, be1)) * m3
+    h = cast((h + tv[:, None, :]) * m3, dt).float()
+    h = F.mish(_ln(conv(h.transpose(1, 2), wc2, b2), g2, be2)) * m3
+    xo = h + conv(xin, wcr, br)
+    hn = cast(_ln(xo, n1g, n1b), dt).float()
+    pc = lambda w: ops.pack_skinny(ops.pack_conv1d(w, dt), dtype=dt)
+    r = dict(w1_p=pc(wc1), w2_p=pc(wc2), wr_p=pc(wcr), b1=b1, g1=g1, be1=be1, b2=b2, g2=g2, be2=be2, br=br)
+    wqkv_p = _pk(ops, wqkv, dt)
+    tol = FUSED_TOL[dt]
+    for bm in ([16] if dt == 0 else [16, 32, 64]):
+        x = torch.zeros(B, T, 256, device="cuda")
+        Tp = ops.round_up(T, 8)
+        ldq = 1024 if dt == 1 else 1536
+        qk = torch.zeros(B, T, ldq, device="cuda", dtype=L.TORCH_DT[dt])
+        vt = torch.full((B, 512, Tp), 7.0, device="cuda", dtype=L.TORCH_DT[dt]) if dt == 1 else None
+        nxt = ops.est_next(wqkv=wqkv_p, n1g=n1g, n1b=n1b, q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp, vt_bs=512 * Tp)
+        ops.est_resnet(a_in.contiguous(), lda, cin, x, r, tv, tv_all.shape[1], B=B, T=T, dtype=dt, bm=bm, rowmask=mask, nxt=nxt)
+        torch.cuda.synchronize()
+        assert rel_err(x, xo) < tol, (bm, "x", rel_err(x, xo))
+        _check_qkv(ops, dt, hn, wq(wqkv), qk, vt, B, T, tol, bm)
+
+
+@pytest.mark.parametrize("dt,tol", [(0, 2e-4), (1, 8e-2)])
+@pytest.mark.parametrize("B,T,masked,streaming", [(2, 64, False, False), (2, 500, False, False), (4, 130, True, True), (16, 320, True, False)])
+def test_estimator_fused_equals_unfused(dt, tol, B, T, masked, streaming):
+    """The whole estimator on the row-tile kernels (every tile size the host picks: 16 / 32 / 64 rows) vs the
+    one-launch-per-op composition, same weights."""
+    from mmx import shapes, synth
+    from mmx.flow import FlowEngine
+    sd = synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=2), 3)
+    ef, eu = (FlowEngine(sd, dtype=dt, parts=("estimator",), fused=f) for f in (True, False))
+    g = torch.Generator().manual_seed(B + T)
+    x, mu = torch.randn(B, 80, T, generator=g).cuda(), torch.randn(B, 80, T, generator=g).cuda()
+    cond, spks = torch.randn(B, 80, T, generator=g).cuda() * 0.5, torch.randn(B, 80, generator=g).cuda()
+    t = torch.rand(B, generator=g).cuda()
+    mask = torch.ones(B, 1, T).cuda()
+    if masked:
+        for b in range(B):
+            mask[b, :, T - 7 * b:] = 0
+    a = ef.estimator_channels_first(x, mask, mu, t, spks, cond, streaming)
+    b_ = eu.estimator_channels_first(x, mask, mu, t, spks, cond, streaming)
+    err = (a - b_).abs().max().item()
+    print(f"fused vs unfused estimator dtype {dt} B={B} T={T}: max abs diff {err:.3e} (std {b_.std().item():.3f})")
+    assert torch.isfinite(a).all() and err < tol, err

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 N_TEXT, N_STEPS, SEED = 48, 250, 0
 WAV_TOL_F32 = 1e-3                 # north star (abs, waveform in [-1, 1])
-BF16_MIN_SNR_DB = 15.0             # bf16 build, same token ids: waveform SNR vs the oracle (requirement, not a measurement)
-BF16_MIN_ID_PREFIX = 8             # bf16 build, free running: ids agree with the oracle at least this far
+BF16_MIN_SNR_DB = 25.0             # bf16 build, same token ids: waveform SNR vs the oracle (requirement, not a measurement)
+BF16_MIN_TF_AGREEMENT = 0.6        # bf16 build, teacher forced with the oracle's ids: share of steps that draw the same id
 
 
 @pytest.fixture(scope="module")
@@ -62,22 +62,32 @@ def test_composed_pipeline_fp32_ids_identical_waveform_1e3(case):
 
 
 def test_composed_pipeline_bf16_bound(case):
-    """bf16 build: (a) free-running ids vs the oracle — mismatch count and first divergence are reported, a common
-    prefix is required; (b) flow + DAC on the ORACLE's ids: waveform SNR / max abs error vs the oracle's waveform."""
+    """bf16 build: (a) ids vs the oracle.  Free running, one flipped near-tie changes the whole continuation (random-init
+    logits are flat), so the free-running mismatch count and first divergence are reported, and the requirement is put
+    on the TEACHER-FORCED run (the oracle's ids are fed back, every step still draws its own id from the same Philox
+    noise): the share of steps whose draw equals the oracle's.  (b) flow + DAC on the ORACLE's ids: waveform SNR / max
+    abs error vs the oracle's waveform."""
     eng = _engine(case, 1)
     eng.tts(case["text"].cuda(), case["emb"].cuda(), seed=SEED, exact_steps=N_STEPS)
     got, want = eng.llm.tokens()[0], case["toks"]
     n = min(len(got), len(want))
     first = next((i for i in range(n) if got[i] != want[i]), n)
     mism = sum(1 for i in range(n) if got[i] != want[i]) + abs(len(got) - len(want))
+    z0 = torch.zeros(1, 0, dtype=torch.long, device="cuda")
+    x = eng.llm.build_lm_input(case["text"].cuda(), z0, z0)
+    eng.llm.start([x], [N_STEPS], [N_STEPS], seed=SEED, forced=torch.tensor(want).reshape(1, -1))
+    eng.llm.run(N_STEPS)
+    drawn = eng.llm.sampled[0, :len(want)].tolist()
+    agree = sum(1 for a, b in zip(drawn, want) if a == b) / len(want)
     tok = torch.tensor(want, device="cuda").reshape(1, -1)
     z = torch.zeros(1, 0, dtype=torch.long, device="cuda")
     wav = eng.token2wav(tok, z, torch.zeros(1, 0, 80, device="cuda"), case["emb"].cuda()).cpu()
     err = (wav - case["wav"]).abs().max().item()
     snr = _snr_db(case["wav"], wav)
-    print(f"bf16 composed: ids {mism}/{n} differ (first divergence at step {first}); same-ids waveform max abs err "
-          f"{err:.3e}, SNR {snr:.1f} dB (std {case['wav'].std().item():.3f})")
-    assert first >= BF16_MIN_ID_PREFIX, (first, got[:12], want[:12])
+    print(f"bf16 composed: free running {mism}/{n} ids differ (first divergence at step {first}); teacher forced "
+          f"{agree * 100:.1f} % of the draws equal the oracle's; same-ids waveform max abs err {err:.3e}, SNR {snr:.1f} dB "
+          f"(std {case['wav'].std().item():.3f})")
+    assert agree >= BF16_MIN_TF_AGREEMENT, agree
     assert wav.shape == case["wav"].shape and snr >= BF16_MIN_SNR_DB, (snr, err)
 
 

@@ -24,7 +24,13 @@ def timeit(fn, n=10):
 
 
 def main():
-    eng = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=1)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--unfused", action="store_true", help="one launch per Linear / Conv1d / LayerNorm (the round-1 path)")
+    a = ap.parse_args()
+    eng = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=(1 if a.dtype == "bf16" else 0), fused=not a.unfused)
+    print(f"dtype {a.dtype}, {'unfused' if a.unfused else 'fused row-tile'} estimator", flush=True)
     g = torch.Generator().manual_seed(0)
     for n_tok in (250, 500):
         tok = torch.randint(0, 6561, (1, n_tok), generator=g).cuda()
