@@ -139,6 +139,7 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
 // v_mfma_f32_16x16x32_bf16; online softmax in registers (exp2 with log2e folded into the scale), row reductions
 // over the 16 lanes that share a query row via 4 xor-shuffles; P goes through a per-wave LDS patch (wave-local
 // ordering only) to turn the C-layout tile into the A-operand layout.
+template <int MF>
 __global__ __launch_bounds__(256) void attn_flash_kernel(
     const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
     const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     // adjacent chunks per group: a 144 B pitch puts 7 of the 16 lanes on busy banks (8 LDS cycles instead of 4; PMC:
     // 39 % of this kernel's LDS cycles were bank conflicts), 160 B is conflict free.  The P patch keeps 144 B: its
     // 8-byte stores (16 contiguous lanes, 32 banks) would be 4-way conflicted at 160 B.
-    constexpr int D = 64, KT = 64, LDK = 80, LD = 72, QW = 32, MF = 2;
+    // MF query fragments of 16 per wave: 2 for long / batched problems (every K / V^T fragment read feeds two MFMAs),
+    // 1 when the grid would otherwise leave most CUs idle (one 10 s utterance: 16 (batch, head) pairs x 4 tiles of 128)
+    constexpr int D = 64, KT = 64, LDK = 80, LD = 72, QW = 16 * MF;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KT * LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[2][D * LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Ps[4][QW * LD];
@@ -321,10 +324,10 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         };
         if (need_mask) {
             softmax_tile(std::true_type{}, std::integral_constant<int, 0>{});
-            softmax_tile(std::true_type{}, std::integral_constant<int, 1>{});
+            if constexpr (MF > 1) softmax_tile(std::true_type{}, std::integral_constant<int, MF - 1>{});
         } else {
             softmax_tile(std::false_type{}, std::integral_constant<int, 0>{});
-            softmax_tile(std::false_type{}, std::integral_constant<int, 1>{});
+            if constexpr (MF > 1) softmax_tile(std::false_type{}, std::integral_constant<int, MF - 1>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -368,10 +371,16 @@ extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, con
     MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
     MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8);
     MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0);
-    const int nq = (T_ + 127) / 128, npairs = H * B;
+    const int npairs = H * B;
+    const bool small = (long)npairs * ((T_ + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
+    const int qtile = small ? 64 : 128, nq = (T_ + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
-    hipLaunchKernelGGL(attn_flash_kernel, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
-                       (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs);
+    if (small)
+        hipLaunchKernelGGL(attn_flash_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs);
+    else
+        hipLaunchKernelGGL(attn_flash_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

@@ -58,9 +58,12 @@ __host__ __device__ constexpr int tile_pitch(int K, int esz) { return ((K * esz 
 // One GEMM stage of a wave: acc[MF][NF] += A(LDS row tile) x W(packed fragments, NF n-fragments of 16 columns).
 // The weight ring holds PF k-steps ahead; run() refills it from THIS stage while k-steps remain and from the NEXT
 // stage afterwards, so a stage starts with its first fragments already in registers.
-template <typename T, int NF>
+// PF: k-steps the ring runs ahead.  One k-step of a wave is MF*NF MFMAs (16 cycles each), an L2 hit takes ~500-800
+// cycles: a 16-row tile (MF = 1) needs ~8 k-steps in flight, a 64-row tile 2.  Every stage's k-step count must be a
+// multiple of PF (checked on the host).
+template <typename T, int NF, int PF_>
 struct WRing {
-    static constexpr int E = FT<T>::E, PF = 2;
+    static constexpr int E = FT<T>::E, PF = PF_;
     u32x4_t w[PF][NF];
     __device__ __forceinline__ void prime(const T* wb, long ns, int nk) {
 #pragma unroll
@@ -75,11 +78,11 @@ struct WRing {
 // K is walked as `taps` groups of `cin_steps` k-steps; tap t reads the tile `t` rows further down (causal conv k3:
 // taps = 3; Linear: taps = 1).  wb / ns / nk: packed weights of this stage for this wave (lane offset included),
 // elements between n-fragments, k-steps (even).  wbn / nsn: the next stage's (NULL: none).
-template <typename T, int MF, int NF>
-__device__ __forceinline__ void stage_run(WRing<T, NF>& ring, const char* a_lane, int pitch, int cin_steps,
+template <typename T, int MF, int NF, int PF>
+__device__ __forceinline__ void stage_run(WRing<T, NF, PF>& ring, const char* a_lane, int pitch, int cin_steps,
                                           const T* wb, long ns, int nk, const T* wbn, long nsn, int nkn,
                                           float4_t (&acc)[MF][NF]) {
-    constexpr int E = FT<T>::E, KB = FT<T>::KB, PF = WRing<T, NF>::PF;
+    constexpr int E = FT<T>::E, KB = FT<T>::KB;
     typedef typename FT<T>::frag_t frag_t;
     int tap = 0, c = 0;
     for (int ks = 0; ks < nk; ks += PF) {
@@ -244,9 +247,9 @@ __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lan
 }
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
-template <typename T, int MF>
+template <typename T, int MF, int PF>
 __device__ __forceinline__ void ln_qkv(float (&xv)[MF][16], const MmxEstNext& nx, float eps, char* a1, char* vp, float* patch,
-                                       float* stats, WRing<T, 4>& ring, int b, int t0, int Tn, int wave, int lane, int tid) {
+                                       float* stats, WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane, int tid) {
     constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256;
     constexpr int P1 = tile_pitch(C, sizeof(T));
     constexpr int NK = C / KB;
@@ -265,7 +268,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][16], const MmxEstNext& nx
         float4_t acc[MF][4];
         zero_acc(acc);
         const T* wn = p < 5 ? pass_w(p + 1) : nullptr;
-        stage_run<T, MF, 4>(ring, a_lane, P1, NK, pass_w(p), ns, NK, wn, ns, NK, acc);
+        stage_run<T, MF, 4, PF>(ring, a_lane, P1, NK, pass_w(p), ns, NK, wn, ns, NK, acc);
         const int kind = p >> 1, cw = wave * 128 + (p & 1) * 64;   // column inside the 512-wide Q / K / V
         if (VT && kind == 2) {
             // C layout -> [column][frame] patch: a lane holds 4 consecutive frames of one column
@@ -312,7 +315,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][16], const MmxEstNext& nx
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM>
+template <typename T, int BM, int PF>
 __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
     constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
     const T* w2 = reinterpret_cast<const T*>(p.w2) + (long)lane * E;
     constexpr int NK0 = CI / KB, NK1 = C / KB, NK2 = CH / KB, NK2T = CF / KB;
     const long ns0 = (long)NK0 * 64 * E, ns1 = (long)NK1 * 64 * E, ns2 = (long)NK2T * 64 * E;
-    WRing<T, 4> ring;
+    WRing<T, 4, PF> ring;
     const T* wo_w = wo + (long)(wave * 4) * ns0;       // n-fragments 4*wave .. +3 (64 columns)
     ring.prime(wo_w, ns0, NK0);
     load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid);
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
     {
         float4_t acc[MF][4];
         zero_acc(acc);
-        stage_run<T, MF, 4>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, acc);
+        stage_run<T, MF, 4, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, acc);
         float bo[16];
         load16(p.bo + col0, bo);
         const float* xr = p.x + (long)b * p.x_bs;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
             float4_t acc[MF][4];
             zero_acc(acc);
             const T* wn = h == 0 ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
-            stage_run<T, MF, 4>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, h == 0 ? ns1 : ns2,
+            stage_run<T, MF, 4, PF>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, h == 0 ? ns1 : ns2,
                                 h == 0 ? NK1 : NK2, acc);
             const int hc = wave * 128 + h * 64 + cq;   // column inside the chunk
             float b1[16];
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
         }
         __syncthreads();                               // the chunk is complete
         const T* wn = ch == 0 ? w1_pass(2) : (p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr);
-        stage_run<T, MF, 4>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, acc2);
+        stage_run<T, MF, 4, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, acc2);
         __syncthreads();                               // every wave is done reading the chunk
     }
     // ---- + bias + residual -> x (fp32 residual stream, in place)
@@ -427,11 +430,11 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
             }
         }
     }
-    if (p.next.wqkv) ln_qkv<T, MF>(x1, p.next, p.eps, a1, buf0, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+    if (p.next.wqkv) ln_qkv<T, MF, PF>(x1, p.next, p.eps, a1, buf0, patch, stats, ring, b, t0, Tn, wave, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM>
+template <typename T, int BM, int PF>
 __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
     constexpr int MF = BM / 16, MH = MF + 1, E = FT<T>::E, KB = FT<T>::KB, C = 256;
     constexpr int P1 = tile_pitch(C, sizeof(T));
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
     const T* w1_w = w1 + (long)(wave * 4) * ns1;
     const T* w2_w = w2 + (long)(wave * 4) * ns2;
     const T* wr_w = wr + (long)(wave * 4) * nsr;
-    WRing<T, 4> ring;
+    WRing<T, 4, PF> ring;
     ring.prime(w1_w, ns1, nk1);
     load_tile<T>(reinterpret_cast<const T*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, tid);
     __syncthreads();
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
     {
         float4_t acc[MH][4];
         zero_acc(acc);
-        stage_run<T, MH, 4>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, acc);
+        stage_run<T, MH, 4, PF>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, acc);
         float hv[MH][16], bb[16], tv[16];
         load16(p.b1 + col0, bb);
         load16(p.tv + (long)b * p.tv_bs + col0, tv);
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
     {
         float4_t acc[MF][4];
         zero_acc(acc);
-        stage_run<T, MF, 4>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, acc);
+        stage_run<T, MF, 4, PF>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, acc);
         float bb[16];
         load16(p.b2 + col0, bb);
 #pragma unroll
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
         float4_t acc[MF][4];
         zero_acc(acc);
         const T* wq0 = p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr;
-        stage_run<T, MF, 4>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, acc);
+        stage_run<T, MF, 4, PF>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, acc);
         float bb[16];
         load16(p.br + col0, bb);
         float* xw = p.x + (long)b * p.x_bs;
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
         }
     }
     __syncthreads();                                   // every wave is done with ain / h1 (reused by ln_qkv)
-    if (p.next.wqkv) ln_qkv<T, MF>(h2, p.next, p.eps, h1, ain, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+    if (p.next.wqkv) ln_qkv<T, MF, PF>(h2, p.next, p.eps, h1, ain, patch, stats, ring, b, t0, Tn, wave, lane, tid);
 }
 
 template <typename T, int BM>
@@ -572,21 +575,22 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, hipSt
     MMX_CHECK_ARG(((uintptr_t)p.ao % 16) == 0 && ((uintptr_t)p.x % 16) == 0);
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % 8 == 0 && p.act_bs % 8 == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
-#define TAIL(TT, BM)                                                                                       \
+#define TAIL(TT, BM, PF)                                                                                  \
     do {                                                                                                   \
-        const size_t lds = tail_lds<TT, BM>();                                                              \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_tail_kernel<TT, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        const size_t lds = tail_lds<TT, BM>();                                                             \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_tail_kernel<TT, BM, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
     } while (0)
+    // ring depth by tile height (see WRing); the stage k-step counts here are 8 / 16 (bf16) and 16 / 32 (fp32)
     if (dtype == MMX_BF16) {
-        if (bm == 64) TAIL(bf16_t, 64);
-        else if (bm == 32) TAIL(bf16_t, 32);
-        else if (bm == 16) TAIL(bf16_t, 16);
+        if (bm == 64) TAIL(bf16_t, 64, 2);
+        else if (bm == 32) TAIL(bf16_t, 32, 4);
+        else if (bm == 16) TAIL(bf16_t, 16, 8);
         else return MMX_EARG;
     } else if (dtype == MMX_F32) {
-        if (bm == 32) TAIL(float, 32);
-        else if (bm == 16) TAIL(float, 16);
+        if (bm == 32) TAIL(float, 32, 4);
+        else if (bm == 16) TAIL(float, 16, 8);
         else return MMX_EARG;
     } else return MMX_EARG;
 #undef TAIL
@@ -601,21 +605,28 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, h
     MMX_CHECK_ARG(p.B > 0 && p.T > 0 && p.cin >= 64 && p.cin % 32 == 0 && p.cin <= 512 && p.lda >= p.cin && p.lda % 8 == 0 && p.a_bs % 8 == 0);
     MMX_CHECK_ARG(((uintptr_t)p.a_in % 16) == 0 && ((uintptr_t)p.x % 16) == 0 && p.x_bs % 4 == 0 && p.tv_bs % 4 == 0 && ((uintptr_t)p.tv % 16) == 0);
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
-#define RESN(TT, BM)                                                                                       \
+#define RESN(TT, BM, PF)                                                                                  \
     do {                                                                                                   \
-        const size_t lds = resnet_lds<TT, BM>(p.cin);                                                       \
+        const size_t lds = resnet_lds<TT, BM>(p.cin);                                                      \
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_resnet_kernel<TT, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_resnet_kernel<TT, BM, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
-        hipLaunchKernelGGL((est_resnet_kernel<TT, BM>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
     } while (0)
+    // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count
+    // (conv k3 over cin, conv k3 over 256, 1x1 over cin, Q/K/V over 256); cin = 320 allows 2 (bf16) / 4 (fp32) only
+    const int kb = dtype == MMX_BF16 ? 32 : 16;
+    const int want = bm == 16 ? 8 : (bm == 32 ? 4 : 2);
+    int pf = want;
+    while (pf > 2 && ((3 * p.cin / kb) % pf || (p.cin / kb) % pf || (256 / kb) % pf)) pf /= 2;
+    MMX_CHECK_ARG((p.cin / kb) % 2 == 0);
     if (dtype == MMX_BF16) {
-        if (bm == 64) RESN(bf16_t, 64);
-        else if (bm == 32) RESN(bf16_t, 32);
-        else if (bm == 16) RESN(bf16_t, 16);
+        if (bm == 64) RESN(bf16_t, 64, 2);
+        else if (bm == 32) { if (pf == 4) RESN(bf16_t, 32, 4); else RESN(bf16_t, 32, 2); }
+        else if (bm == 16) { if (pf == 8) RESN(bf16_t, 16, 8); else if (pf == 4) RESN(bf16_t, 16, 4); else RESN(bf16_t, 16, 2); }
         else return MMX_EARG;
     } else if (dtype == MMX_F32) {
-        if (bm == 16) RESN(float, 16);
+        if (bm == 16) { if (pf == 8) RESN(float, 16, 8); else if (pf == 4) RESN(float, 16, 4); else RESN(float, 16, 2); }
         else return MMX_EARG;
     } else return MMX_EARG;
 #undef RESN

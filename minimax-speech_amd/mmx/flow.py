@@ -90,14 +90,17 @@ class Graphed:
 class FlowEngine:
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", n_timesteps=10, cfg_rate=0.7,
                  enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True, parts=("encoder", "estimator"),
-                 fused=True):
+                 fused=None):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
         self.enc_chunk, self.est_chunk = enc_chunk, est_chunk
         self.use_graphs = use_graphs
         # fused=True: the estimator runs on the row-tile kernels of csrc/fused.hip (2 launches per transformer block,
-        # 1 per ResNet block); fused=False keeps one launch per Linear / Conv1d / LayerNorm (the composition the fused
-        # kernels are tested against, tests/test_gpu_kernels.py)
+        # 1 per ResNet block); fused=False: one launch per Linear / Conv1d / LayerNorm (the composition the fused kernels
+        # are tested against, tests/test_gpu_kernels.py).  None (default): fused, except for the fp32 build on small
+        # problems — exact-fp32 MFMA runs at 1/16 of the bf16 rate, so there the GEMMs are MFMA bound and a row tile per
+        # workgroup (64 workgroups for one 10 s utterance) leaves 3/4 of the matrix cores idle, while the per-op launches
+        # split N over all CUs (measured, one 10 s utterance, fp32: 175 ms fused, 104 ms per-op)
         self.fused = fused
         dt = dtype
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
@@ -184,7 +187,7 @@ class FlowEngine:
                      w1=lin(p + ".ff.net.0.proj.weight"), b1=f(p + ".ff.net.0.proj.bias"),
                      w2=lin(p + ".ff.net.2.weight"), b2=f(p + ".ff.net.2.bias"))
             wq, wk, wv = f(a + ".to_q.weight"), f(a + ".to_k.weight"), f(a + ".to_v.weight")
-            if self.fused:
+            if self.fused is not False:
                 pk = lambda w: ops.pack_skinny(w.to(self.tdt).contiguous(), dtype=dt)
                 d.update(wo_p=pk(f(a + ".to_out.0.weight")), w1_p=pk(f(p + ".ff.net.0.proj.weight")),
                          w2_p=pk(f(p + ".ff.net.2.weight")), wqkv_p=pk(torch.cat([wq, wk, wv], 0)))
@@ -205,7 +208,7 @@ class FlowEngine:
                      w2=cv(p + ".block2.block.0.weight"), b2=f(p + ".block2.block.0.bias"),
                      g2=f(p + ".block2.block.2.weight"), be2=f(p + ".block2.block.2.bias"),
                      wr=cv(p + ".res_conv.weight"), br=f(p + ".res_conv.bias"))
-            if self.fused:
+            if self.fused is not False:
                 pc = lambda k: ops.pack_skinny(ops.pack_conv1d(f(k), dt), dtype=dt)
                 r.update(w1_p=pc(p + ".block1.block.0.weight"), w2_p=pc(p + ".block2.block.0.weight"), wr_p=pc(p + ".res_conv.weight"))
             mlp_w.append(f(p + ".mlp.1.weight"))
@@ -383,7 +386,7 @@ class FlowEngine:
     def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None):
         """All inputs fp32 time-major device tensors: x [x_mod,T,80] (batch b reads x[b % x_mod]), mu/cond [B,T,80],
         spks [B,80], t [B]; mask fp32 [B,T] or None.  Returns fp32 [B,T,80]."""
-        if self.fused:
+        if self.fused or (self.fused is None and (self.dtype == BF16 or B * ((T + 15) // 16) >= 256)):
             return self._estimator_fused(x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod)
         dt, C = self.dtype, self.C
         chunk = self.est_chunk if streaming else 0

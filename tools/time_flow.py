@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--unfused", action="store_true", help="one launch per Linear / Conv1d / LayerNorm (the round-1 path)")
     a = ap.parse_args()
-    eng = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=(1 if a.dtype == "bf16" else 0), fused=not a.unfused)
+    eng = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=(1 if a.dtype == "bf16" else 0), fused=(False if a.unfused else None))
     print(f"dtype {a.dtype}, {'unfused' if a.unfused else 'fused row-tile'} estimator", flush=True)
     g = torch.Generator().manual_seed(0)
     for n_tok in (250, 500):
