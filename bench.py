@@ -97,11 +97,13 @@ def _event_time_graph(fn, iters):
 
 
 def measure_flow_kernel(eng, n=8, T=896):
-    """Roofline of the kernel that dominates GPU time of the step (rocprofv3 kernel stats under profiles/): the MFMA
-    GEMM behind the estimator's transformer blocks, on the five GEMM shapes of one block at a typical flow-group shape
-    (n utterances x T frames, CFG pair -> M = 2nT rows): QK projection, V^T projection, attention output projection,
-    FF1 (+GELU), FF2 (+residual).  `achieved` = algorithmic FLOPs of those launches / their duration measured live with
-    HIP events (graph of launches rotating over the mid blocks' weights), against the dense bf16 MFMA peak."""
+    """Roofline of the kernel that dominates GPU time of the step (rocprofv3 kernel stats under profiles/): the
+    row-tile fused kernel of the estimator's transformer blocks (est_tail_kernel: attention-output projection +
+    residual -> LayerNorm -> FF1 + GELU -> FF2 + residual -> LayerNorm -> Q/K/V projection of the next block), at a
+    typical flow-group shape (n utterances x T frames, CFG pair -> M = 2nT rows).  Algorithmic FLOPs per launch =
+    2 * M * (512*256 + 256*1024 + 1024*256 + 256*1536) (SURVEY.md §8d: the linear part of a transformer block);
+    duration measured live with HIP events over a hipGraph of launches rotating over the mid blocks' weights (56
+    different 2 MB weight sets, as in the pipeline), on the launch stream; against the dense bf16 MFMA peak."""
     from mmx import ops
     fl = eng.flow
     dt = fl.dtype
@@ -110,31 +112,27 @@ def measure_flow_kernel(eng, n=8, T=896):
     M = B * T
     blocks = [w for st in fl.mid for w in st["blocks"]]
     Tp = ops.round_up(T, 8)
-    hn = torch.randn(B, T, C, device=fl.dev).to(fl.tdt)
     ao = torch.randn(B, T, 512, device=fl.dev).to(fl.tdt)
     x = torch.randn(B, T, C, device=fl.dev)
     qk, vt = fl._new(B, T, 1024), torch.zeros(B, 512, Tp, dtype=fl.tdt, device=fl.dev)
-    ff = fl._new(B, T, 1024)
+    bm, _ = fl._tile_rows(B, T)
 
     def one(i=0):
-        w = blocks[i % len(blocks)]
-        ops.gemm(hn, w["wqk"], T, 1024, dtype=dt, lda=C, cin=C, batch=B, a_bstride=T * C, out_act=qk, ldo_a=1024, oa_bstride=T * 1024)
-        ops.gemm(w["wv"], hn, 512, T, dtype=dt, lda=w["wv"].shape[1], cin=C, batch=B, a_bstride=0, w_bstride=T * C, out_act=vt,
-                 ldo_a=Tp, oa_bstride=512 * Tp)
-        ops.gemm(ao, w["wo"], T, C, dtype=dt, lda=512, cin=512, batch=B, a_bstride=T * 512, bias=w["bo"], residual=x, ldr=C,
-                 r_bstride=T * C, out_f32=x, ldo_f=C, of_bstride=T * C)
-        ops.gemm(hn, w["w1"], T, 1024, dtype=dt, lda=C, cin=C, batch=B, a_bstride=T * C, bias=w["b1"], act="gelu", out_act=ff,
-                 ldo_a=1024, oa_bstride=T * 1024)
-        ops.gemm(ff, w["w2"], T, C, dtype=dt, lda=1024, cin=1024, batch=B, a_bstride=T * 1024, bias=w["b2"], residual=x, ldr=C,
-                 r_bstride=T * C, out_f32=x, ldo_f=C, of_bstride=T * C)
+        w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=1024, q_bs=T * 1024, vt_out=vt,
+                           ldvt=Tp, vt_bs=512 * Tp)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt)
 
-    nl = 5
-    us_block = _event_time_graph(one, 2 * len(blocks))
-    flops = 2.0 * M * (C * 1024 + C * 512 + 512 * C + C * 1024 + 1024 * C)
-    tfs = flops / (us_block * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": f"gemm_win_kernel<bf16> (the {nl} GEMM launches of one estimator transformer block, M={M} rows, C={C})",
+    us = _event_time_graph(one, 2 * len(blocks))
+    flops = 2.0 * M * (512 * C + C * 1024 + 1024 * C + C * 1536)
+    tfs = flops / (us * 1e-6) / 1e12
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "r02_pmc_flow.json")
+    if os.path.exists(pj):
+        traffic = json.load(open(pj)).get(f"est_tail_bm{bm}_hbm_bytes_per_launch")
+    return {"bound": "mfma", "kernel": f"est_tail_kernel<bf16, {bm}> (fused transformer-block tail, M={M} rows = {n} utterances x {T} frames x CFG pair)",
             "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
-            "traffic": None, "flops_per_launch": flops / nl, "us_per_launch": round(us_block / nl, 3)}
+            "traffic": traffic, "flops_per_launch": flops, "us_per_launch": round(us, 3)}
 
 
 def cpu_baseline():

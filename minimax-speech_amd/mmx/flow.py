@@ -42,15 +42,17 @@ import threading
 CAPTURE_LOCK = threading.RLock()
 
 
-_capture_primed = set()
+_capture_primed = {}
 
 
 def _prime_capture_state(dev):
-    """The first hipGraph capture of a process allocates the CUDA generator's capture-state tensors and every later
-    capture updates them in place.  If that first capture runs under torch.inference_mode() (the drop-in modules keep
-    the reference's @torch.inference_mode() decorators) they are inference tensors, and a later capture outside
-    inference mode fails ("Inplace update to inference tensor outside InferenceMode").  So the very first capture
-    is a trivial one made with inference mode switched off."""
+    """torch keeps the CUDA generator's capture-state tensors (seed / offset) alive only while at least one CUDAGraph is
+    registered with the generator, allocates them at the first registration and updates them IN PLACE at every capture.
+    If that allocation happens under torch.inference_mode() (the drop-in modules keep the reference's
+    @torch.inference_mode() decorators) they are inference tensors, and a later capture outside inference mode fails
+    ("Inplace update to inference tensor outside InferenceMode").  So the first capture of a process is a trivial one
+    made with inference mode switched off, and its graph is kept alive for the life of the process: the state tensors
+    are then never re-allocated, whatever engines come and go."""
     key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     if key in _capture_primed:
         return
@@ -59,7 +61,7 @@ def _prime_capture_state(dev):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             t.add_(1.0)
-    _capture_primed.add(key)
+    _capture_primed[key] = (g, t)
 
 
 class Graphed:
