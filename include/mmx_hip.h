@@ -287,8 +287,9 @@ typedef struct MmxEstResnetParams {
     float eps;
     MmxEstNext next;
 } MmxEstResnetParams;
-int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, hipStream_t stream);
-int mmx_est_resnet(const MmxEstResnetParams* p, int dtype, int bm, hipStream_t stream);
+/* pf: k-steps of weight fragments a wave keeps in flight (2 / 4 / 8; 0 = the library's default for that tile). */
+int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, int pf, hipStream_t stream);
+int mmx_est_resnet(const MmxEstResnetParams* p, int dtype, int bm, int pf, hipStream_t stream);
 
 #ifdef __cplusplus
 }

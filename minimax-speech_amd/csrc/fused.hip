@@ -84,14 +84,28 @@ __device__ __forceinline__ void stage_run(WRing<T, NF, PF>& ring, const char* a_
                                           float4_t (&acc)[MF][NF]) {
     constexpr int E = FT<T>::E, KB = FT<T>::KB;
     typedef typename FT<T>::frag_t frag_t;
-    int tap = 0, c = 0;
+    // A fragments come from LDS AD - 1 k-steps ahead of their use (one wave per SIMD: nothing else hides the ~130
+    // cycle LDS latency; a k-step is MF*NF MFMAs = 64 cycles at MF = 1, 256 at MF = 4)
+    constexpr int AD = (MF == 1 && PF >= 4) ? 4 : 2;
+    static_assert(PF % AD == 0, "ring depths");
+    frag_t a[AD][MF];
+    int rt = 0, rc = 0, rs = 0;                        // tap / k-step inside the tap / k-step of the next A read
+    auto read_a = [&](frag_t (&dst)[MF]) {
+        const char* ap = a_lane + rt * pitch + rc * (KB * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < MF; ++i) dst[i] = *reinterpret_cast<const frag_t*>(ap + i * 16 * pitch);
+        if (rs + 1 < nk) {                             // past the end: re-read the last k-step (never used)
+            ++rs;
+            if (++rc == cin_steps) { rc = 0; ++rt; }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < AD - 1; ++s) read_a(a[s]);
     for (int ks = 0; ks < nk; ks += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const char* ap = a_lane + tap * pitch + c * (KB * (int)sizeof(T));
-            frag_t a[MF], b[NF];
-#pragma unroll
-            for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const frag_t*>(ap + i * 16 * pitch);
+            read_a(a[(p + AD - 1) % AD]);
+            frag_t b[NF];
 #pragma unroll
             for (int j = 0; j < NF; ++j) b[j] = __builtin_bit_cast(frag_t, ring.w[p][j]);
             // refill this ring slot: k-step ks+p+PF of this stage, or the head of the next stage (uniform select,
@@ -103,11 +117,15 @@ __device__ __forceinline__ void stage_run(WRing<T, NF, PF>& ring, const char* a_
             const long sst = here ? ns : (wbn ? nsn : ns);
 #pragma unroll
             for (int j = 0; j < NF; ++j) ring.w[p][j] = *reinterpret_cast<const u32x4_t*>(src + j * sst);
+            // keep the refill (and the A read-ahead) HERE: left alone, the scheduler sinks these loads down to their
+            // first use PF k-steps later (register pressure), which turns the ring into load-then-wait every k-step
+            // (measured: the same kernel time at ring depth 2, 4 and 8)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mma<T>(a[i], b[j], acc[i][j]);
-            if (++c == cin_steps) { c = 0; ++tap; }
+                for (int j = 0; j < NF; ++j) acc[i][j] = mma<T>(a[p % AD][i], b[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -172,9 +190,10 @@ __device__ __forceinline__ void store16_T(T* p, const float (&v)[16]) {
 // LayerNorm of the rows of a [BMR x 256] tile held in the row layout (v[i][16] per wave, 4 waves x 64 columns).
 // Two-pass statistics like torch (mean, then the mean of squared deviations), partial sums exchanged through
 // stats[BMR][4].  Contains 3 workgroup barriers; all waves must call it.  Leaves normalised*gamma+beta in v.
+// gamma / beta: this lane's 16 columns, loaded by the caller BEFORE the preceding MFMA stage (see "epilogue operands").
 template <int MFR>
-__device__ __forceinline__ void layernorm_rows(float (&v)[MFR][16], float* stats, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float eps, int wave, int lane, int col0) {
+__device__ __forceinline__ void layernorm_rows(float (&v)[MFR][16], float* stats, const float (&g)[16], const float (&be)[16],
+                                               float eps, int wave, int lane) {
     const int rl = lane >> 2;
     float mean[MFR];
     __syncthreads();                                   // stats free (previous readers done)
@@ -204,9 +223,6 @@ __device__ __forceinline__ void layernorm_rows(float (&v)[MFR][16], float* stats
         if ((lane & 3) == 0) stats[(i * 16 + rl) * 4 + wave] = q;
     }
     __syncthreads();
-    float g[16], be[16];
-    load16(gamma + col0, g);
-    load16(beta + col0, be);
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
         const float4_t t = *reinterpret_cast<const float4_t*>(stats + (i * 16 + rl) * 4);
@@ -248,15 +264,16 @@ __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lan
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
 template <typename T, int MF, int PF>
-__device__ __forceinline__ void ln_qkv(float (&xv)[MF][16], const MmxEstNext& nx, float eps, char* a1, char* vp, float* patch,
-                                       float* stats, WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane, int tid) {
+__device__ __forceinline__ void ln_qkv(float (&xv)[MF][16], const float (&n1g)[16], const float (&n1b)[16], const MmxEstNext& nx,
+                                       float eps, char* a1, char* vp, float* patch, float* stats, WRing<T, 4, PF>& ring, int b,
+                                       int t0, int Tn, int wave, int lane, int tid) {
     constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256;
     constexpr int P1 = tile_pitch(C, sizeof(T));
     constexpr int NK = C / KB;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
     const long ns = (long)NK * 64 * E;
     auto pass_w = [&](int p) { return qkv_pass<T>(nx.wqkv, wave, lane, p); };
-    layernorm_rows<MF>(xv, stats, nx.n1g, nx.n1b, eps, wave, lane, wave * 64 + cq);
+    layernorm_rows<MF>(xv, stats, n1g, n1b, eps, wave, lane);
 #pragma unroll
     for (int i = 0; i < MF; ++i)
         store16_T<T>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + wave * 64 + cq, xv[i]);
@@ -340,32 +357,40 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
     WRing<T, 4, PF> ring;
     const T* wo_w = wo + (long)(wave * 4) * ns0;       // n-fragments 4*wave .. +3 (64 columns)
     ring.prime(wo_w, ns0, NK0);
-    load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid);
-    __syncthreads();
 
+    // Epilogue operands (residual rows, biases, LayerNorm weights, row mask) are loaded BEFORE the MFMA stage whose
+    // epilogue uses them.  A wave waits for a load with s_waitcnt vmcnt(N), which counts in issue order: a load issued
+    // in the epilogue would wait for itself AND drain the weight ring that is running ahead for the next stage
+    // (measured: ~25 exposed L2 / HBM round trips per workgroup, half of the kernel's time).
     // ---- attention output projection + bias + residual  (transformer.py:290-297: attn1 -> + hidden_states)
     // FF1 pass q (0..3): chunk q >> 1, 64 columns at chunk*512 + wave*128 + (q & 1)*64
     auto w1_pass = [&](int q) { return w1 + (long)(((q >> 1) * CH + wave * 128 + (q & 1) * 64) / 16) * ns1; };
-    float x1[MF][16];
+    float x1[MF][16], bo[16], n3g[16], n3b[16];
     {
-        float4_t acc[MF][4];
-        zero_acc(acc);
-        stage_run<T, MF, 4, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, acc);
-        float bo[16];
-        load16(p.bo + col0, bo);
         const float* xr = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            to_rows(acc[i], patch, lane, x1[i]);
             const int t = t0 + i * 16 + rl;
-            float r[16];
-            if (t < Tn) load16(xr + (long)t * C + col0, r);
+            if (t < Tn) load16(xr + (long)t * C + col0, x1[i]);
             else {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) r[c] = 0.f;
+                for (int c = 0; c < 16; ++c) x1[i][c] = 0.f;
             }
+        }
+        load16(p.bo + col0, bo);
+        load16(p.n3g + col0, n3g);
+        load16(p.n3b + col0, n3b);
+        load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid);
+        __syncthreads();
+        float4_t acc[MF][4];
+        zero_acc(acc);
+        stage_run<T, MF, 4, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, acc);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x1[i][c] += bo[c] + r[c];
+        for (int i = 0; i < MF; ++i) {
+            float v[16];
+            to_rows(acc[i], patch, lane, v);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x1[i][c] += v[c] + bo[c];
         }
     }
     // ---- LayerNorm (norm3) -> A1
@@ -375,7 +400,7 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
         for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int c = 0; c < 16; ++c) hn[i][c] = x1[i][c];
-        layernorm_rows<MF>(hn, stats, p.n3g, p.n3b, p.eps, wave, lane, col0);
+        layernorm_rows<MF>(hn, stats, n3g, n3b, p.eps, wave, lane);
 #pragma unroll
         for (int i = 0; i < MF; ++i) store16_T<T>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + col0, hn[i]);
     }
@@ -384,17 +409,18 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
     float4_t acc2[MF][4];
     zero_acc(acc2);
     const T* w2_w = w2 + (long)(wave * 4) * ns2;       // FF2: 64 output columns per wave, K walked per chunk
+    float b2[16], n1g[16], n1b[16], rm[MF];
     for (int ch = 0; ch < 2; ++ch) {
         for (int h = 0; h < 2; ++h) {
             const int q = ch * 2 + h;
+            const int hc = wave * 128 + h * 64 + cq;   // column inside the chunk
+            float b1[16];
+            load16(p.b1 + ch * CH + hc, b1);
             float4_t acc[MF][4];
             zero_acc(acc);
             const T* wn = h == 0 ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
             stage_run<T, MF, 4, PF>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, h == 0 ? ns1 : ns2,
-                                h == 0 ? NK1 : NK2, acc);
-            const int hc = wave * 128 + h * 64 + cq;   // column inside the chunk
-            float b1[16];
-            load16(p.b1 + ch * CH + hc, b1);
+                                    h == 0 ? NK1 : NK2, acc);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[16];
@@ -405,24 +431,30 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
             }
         }
         __syncthreads();                               // the chunk is complete
+        if (ch == 1) {                                 // operands of the closing epilogue and of the next LayerNorm
+            load16(p.b2 + col0, b2);
+            if (p.next.wqkv) { load16(p.next.n1g + col0, n1g); load16(p.next.n1b + col0, n1b); }
+            const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int t = t0 + i * 16 + rl;
+                rm[i] = (rmk && t < Tn) ? rmk[t] : 1.f;
+            }
+        }
         const T* wn = ch == 0 ? w1_pass(2) : (p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr);
         stage_run<T, MF, 4, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, acc2);
         __syncthreads();                               // every wave is done reading the chunk
     }
     // ---- + bias + residual -> x (fp32 residual stream, in place)
     {
-        float b2[16];
-        load16(p.b2 + col0, b2);
         float* xw = p.x + (long)b * p.x_bs;
-        const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[16];
             to_rows(acc2[i], patch, lane, v);
             const int t = t0 + i * 16 + rl;
-            const float rm = (rmk && t < Tn) ? rmk[t] : 1.f;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x1[i][c] = (x1[i][c] + v[c] + b2[c]) * rm;
+            for (int c = 0; c < 16; ++c) x1[i][c] = (x1[i][c] + v[c] + b2[c]) * rm[i];
             if (t < Tn) {
                 store16(xw + (long)t * C + col0, x1[i]);
                 if (p.act_out)
@@ -430,7 +462,7 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
             }
         }
     }
-    if (p.next.wqkv) ln_qkv<T, MF, PF>(x1, p.next, p.eps, a1, buf0, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+    if (p.next.wqkv) ln_qkv<T, MF, PF>(x1, n1g, n1b, p.next, p.eps, a1, buf0, patch, stats, ring, b, t0, Tn, wave, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -462,9 +494,20 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
     const T* wr_w = wr + (long)(wave * 4) * nsr;
     WRing<T, 4, PF> ring;
     ring.prime(w1_w, ns1, nk1);
+    const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
+    // epilogue operands first (see est_tail_kernel): block1's bias, LayerNorm weights, time embedding, row mask
+    float bb[16], tv[16], gg[16], be[16], rm1[MH];
+    load16(p.b1 + col0, bb);
+    load16(p.tv + (long)b * p.tv_bs + col0, tv);
+    load16(p.g1 + col0, gg);
+    load16(p.be1 + col0, be);
+#pragma unroll
+    for (int i = 0; i < MH; ++i) {
+        const int t = t0 - 16 + i * 16 + rl;
+        rm1[i] = (t >= 0 && t < Tn) ? (rmk ? rmk[t] : 1.f) : 0.f;
+    }
     load_tile<T>(reinterpret_cast<const T*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, tid);
     __syncthreads();
-    const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
 
     // ---- block1: causal conv k3 (cin -> 256) + bias -> LayerNorm -> Mish -> * mask, + time embedding, * mask
     //      (flow/decoder.py:65-85 with matcha decoder.py:56-61) for rows t0-16 .. t0+BM-1 (conv2 needs 2 rows of halo)
@@ -472,29 +515,32 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
         float4_t acc[MH][4];
         zero_acc(acc);
         stage_run<T, MH, 4, PF>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, acc);
-        float hv[MH][16], bb[16], tv[16];
-        load16(p.b1 + col0, bb);
-        load16(p.tv + (long)b * p.tv_bs + col0, tv);
+        float hv[MH][16];
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
             to_rows(acc[i], patch, lane, hv[i]);
 #pragma unroll
             for (int c = 0; c < 16; ++c) hv[i][c] += bb[c];
         }
-        layernorm_rows<MH>(hv, stats, p.g1, p.be1, p.eps, wave, lane, col0);
+        layernorm_rows<MH>(hv, stats, gg, be, p.eps, wave, lane);
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
             const int t = t0 - 16 + i * 16 + rl;
-            const float rm = (t >= 0 && t < Tn) ? (rmk ? rmk[t] : 1.f) : 0.f;
             float o[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const float y = act_c<ACT_MISH, PRECISE>(hv[i][c], 0.f) * rm;
-                o[c] = t >= 0 ? (y + tv[c]) * rm : 0.f;               // rows before the sequence start are conv padding
+                const float y = act_c<ACT_MISH, PRECISE>(hv[i][c], 0.f) * rm1[i];
+                o[c] = t >= 0 ? (y + tv[c]) * rm1[i] : 0.f;           // rows before the sequence start are conv padding
             }
             store16_T<T>(reinterpret_cast<T*>(h1 + (i * 16 + rl) * P1) + col0, o);
         }
     }
+    // operands of block2's epilogue and of the residual conv's
+    float br[16];
+    load16(p.b2 + col0, bb);
+    load16(p.g2 + col0, gg);
+    load16(p.be2 + col0, be);
+    load16(p.br + col0, br);
     __syncthreads();
     // ---- block2: causal conv k3 (256 -> 256) -> LayerNorm -> Mish -> * mask
     float h2[MF][16];
@@ -502,31 +548,25 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
         float4_t acc[MF][4];
         zero_acc(acc);
         stage_run<T, MF, 4, PF>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, acc);
-        float bb[16];
-        load16(p.b2 + col0, bb);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             to_rows(acc[i], patch, lane, h2[i]);
 #pragma unroll
             for (int c = 0; c < 16; ++c) h2[i][c] += bb[c];
         }
-        layernorm_rows<MF>(h2, stats, p.g2, p.be2, p.eps, wave, lane, col0);
+        layernorm_rows<MF>(h2, stats, gg, be, p.eps, wave, lane);
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int t = t0 + i * 16 + rl;
-            const float rm = t < Tn ? (rmk ? rmk[t] : 1.f) : 0.f;
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) h2[i][c] = act_c<ACT_MISH, PRECISE>(h2[i][c], 0.f) * rm;
-        }
+            for (int c = 0; c < 16; ++c) h2[i][c] = act_c<ACT_MISH, PRECISE>(h2[i][c], 0.f) * rm1[i + 1];
     }
     // ---- + res_conv(x) (1x1) -> x (fp32 residual stream)
     {
+        if (p.next.wqkv) { load16(p.next.n1g + col0, gg); load16(p.next.n1b + col0, be); }
         float4_t acc[MF][4];
         zero_acc(acc);
         const T* wq0 = p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr;
         stage_run<T, MF, 4, PF>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, acc);
-        float bb[16];
-        load16(p.br + col0, bb);
         float* xw = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -534,12 +574,12 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
             to_rows(acc[i], patch, lane, v);
             const int t = t0 + i * 16 + rl;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) h2[i][c] += v[c] + bb[c];
+            for (int c = 0; c < 16; ++c) h2[i][c] += v[c] + br[c];
             if (t < Tn) store16(xw + (long)t * C + col0, h2[i]);
         }
     }
     __syncthreads();                                   // every wave is done with ain / h1 (reused by ln_qkv)
-    if (p.next.wqkv) ln_qkv<T, MF, PF>(h2, p.next, p.eps, h1, ain, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+    if (p.next.wqkv) ln_qkv<T, MF, PF>(h2, gg, be, p.next, p.eps, h1, ain, patch, stats, ring, b, t0, Tn, wave, lane, tid);
 }
 
 template <typename T, int BM>
@@ -567,7 +607,7 @@ int check_next(const MmxEstNext& nx, int dtype, int T_) {
 
 }  // namespace
 
-extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, hipStream_t stream) {
+extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int pf, hipStream_t stream) {
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstTailParams& p = *pp;
     MMX_CHECK_ARG(p.ao && p.x && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.n3g && p.n3b && p.B > 0 && p.T > 0);
@@ -583,14 +623,15 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, hipSt
         hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
     } while (0)
     // ring depth by tile height (see WRing); the stage k-step counts here are 8 / 16 (bf16) and 16 / 32 (fp32)
+    // pf = 0: the default depth
     if (dtype == MMX_BF16) {
-        if (bm == 64) TAIL(bf16_t, 64, 2);
-        else if (bm == 32) TAIL(bf16_t, 32, 4);
-        else if (bm == 16) TAIL(bf16_t, 16, 8);
+        if (bm == 64) { if (pf == 4) TAIL(bf16_t, 64, 4); else if (pf == 0 || pf == 2) TAIL(bf16_t, 64, 2); else return MMX_EARG; }
+        else if (bm == 32) { if (pf == 2) TAIL(bf16_t, 32, 2); else if (pf == 0 || pf == 4) TAIL(bf16_t, 32, 4); else return MMX_EARG; }
+        else if (bm == 16 && (pf == 0 || pf == 8)) TAIL(bf16_t, 16, 8);
         else return MMX_EARG;
     } else if (dtype == MMX_F32) {
-        if (bm == 32) TAIL(float, 32, 4);
-        else if (bm == 16) TAIL(float, 16, 8);
+        if (bm == 32 && (pf == 0 || pf == 4)) TAIL(float, 32, 4);
+        else if (bm == 16 && (pf == 0 || pf == 8)) TAIL(float, 16, 8);
         else return MMX_EARG;
     } else return MMX_EARG;
 #undef TAIL
@@ -598,7 +639,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, hipSt
     return MMX_OK;
 }
 
-extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, hipStream_t stream) {
+extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, int pf_req, hipStream_t stream) {
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstResnetParams& p = *pp;
     MMX_CHECK_ARG(p.a_in && p.x && p.w1 && p.w2 && p.wr && p.b1 && p.b2 && p.br && p.g1 && p.be1 && p.g2 && p.be2 && p.tv);
@@ -616,13 +657,14 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, h
     // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count
     // (conv k3 over cin, conv k3 over 256, 1x1 over cin, Q/K/V over 256); cin = 320 allows 2 (bf16) / 4 (fp32) only
     const int kb = dtype == MMX_BF16 ? 32 : 16;
-    const int want = bm == 16 ? 8 : (bm == 32 ? 4 : 2);
+    const int want = pf_req > 0 ? pf_req : (bm == 16 ? 8 : 4);
+    MMX_CHECK_ARG(want == 2 || want == 4 || want == 8);
     int pf = want;
     while (pf > 2 && ((3 * p.cin / kb) % pf || (p.cin / kb) % pf || (256 / kb) % pf)) pf /= 2;
     MMX_CHECK_ARG((p.cin / kb) % 2 == 0);
     if (dtype == MMX_BF16) {
-        if (bm == 64) RESN(bf16_t, 64, 2);
-        else if (bm == 32) { if (pf == 4) RESN(bf16_t, 32, 4); else RESN(bf16_t, 32, 2); }
+        if (bm == 64) { if (pf >= 4) RESN(bf16_t, 64, 4); else RESN(bf16_t, 64, 2); }
+        else if (bm == 32) { if (pf >= 4) RESN(bf16_t, 32, 4); else RESN(bf16_t, 32, 2); }
         else if (bm == 16) { if (pf == 8) RESN(bf16_t, 16, 8); else if (pf == 4) RESN(bf16_t, 16, 4); else RESN(bf16_t, 16, 2); }
         else return MMX_EARG;
     } else if (dtype == MMX_F32) {
