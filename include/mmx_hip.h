@@ -96,9 +96,15 @@ int mmx_rownorm(const float* x, int64_t ldx, int64_t x_bstride, int rows, int C,
                 void* out_act, int64_t ldo_a, int64_t oa_bstride, int dtype, hipStream_t stream);
 
 /* GroupNorm over a time-major fp32 tensor [B][T][C] (statistics per (batch, group) over C/groups channels x T),
- * output in T.  Replaces arch_util.py:21-38 GroupNorm32 inside LearnableSpeakerEncoder (llm.py:34-96). */
+ * then act (MMX_ACT_NONE / MMX_ACT_MISH) and * rowmask[b][t] (optional), output in T.  Replaces arch_util.py:21-38
+ * GroupNorm32 inside LearnableSpeakerEncoder (llm.py:34-96) and GroupNorm + Mish of matcha Block1D (decoder.py:32-43). */
 int mmx_groupnorm(const float* x, int B, int T, int C, int groups, const float* gamma, const float* beta, float eps,
-                  void* out, int dtype, hipStream_t stream);
+                  int act, const float* rowmask, void* out, int dtype, hipStream_t stream);
+
+/* out = act(x) * rowmask[row] on a fp32 [rows][C] tensor (fp32 and / or T output): the stand-alone Mish / SiLU / mask
+ * multiplications of the matcha block classes (decoder.py:41-43,49,59; transformer.py) when they are called one by one. */
+int mmx_act_rows(const float* x, int64_t rows, int C, int act, const float* rowmask, float* out_f32, void* out_act, int dtype,
+                 hipStream_t stream);
 
 /* out[i][:] = table[ids[i]][:] * scale * (rowmask ? rowmask[i] : 1)   (ids < 0 are clamped to 0,
  * flow.py:477).  Replaces nn.Embedding lookups (flow.py:477, llm.py:694-700). */

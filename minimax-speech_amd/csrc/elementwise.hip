@@ -349,7 +349,8 @@ extern "C" int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* 
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x, int Tn, int C, int cpg,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, T* __restrict__ out) {
+                                                        float eps, int act, const float* __restrict__ rowmask,
+                                                        T* __restrict__ out) {
     __shared__ float sh[8];
     const int g = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (long)b * Tn * C + g * cpg;
@@ -374,18 +375,46 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < n; i += 256) {
         const int c = i % cpg;
         const long o = (long)(i / cpg) * C + c;
-        ob[o] = Cvt<T>::from_f((xb[o] - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c]);
+        float y = (xb[o] - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c];
+        if (act == ACT_MISH) y = act_c<ACT_MISH, sizeof(T) == 4>(y, 0.f);
+        if (rowmask) y *= rowmask[(long)b * Tn + i / cpg];
+        ob[o] = Cvt<T>::from_f(y);
     }
 }
 extern "C" int mmx_groupnorm(const float* x, int B, int T_, int C, int groups, const float* gamma, const float* beta,
-                             float eps, void* out, int dtype, hipStream_t stream) {
+                             float eps, int act, const float* rowmask, void* out, int dtype, hipStream_t stream) {
     MMX_CHECK_ARG(x && gamma && beta && out && B > 0 && T_ > 0 && C > 0 && groups > 0 && C % groups == 0);
+    MMX_CHECK_ARG(act == ACT_NONE || act == ACT_MISH);
     dim3 grid(groups, B);
-    if (dtype == MMX_BF16) hipLaunchKernelGGL(groupnorm_kernel<bf16_t>, grid, dim3(256), 0, stream, x, T_, C, C / groups, gamma, beta, eps, (bf16_t*)out);
-    else if (dtype == MMX_F32) hipLaunchKernelGGL(groupnorm_kernel<float>, grid, dim3(256), 0, stream, x, T_, C, C / groups, gamma, beta, eps, (float*)out);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(groupnorm_kernel<bf16_t>, grid, dim3(256), 0, stream, x, T_, C, C / groups, gamma, beta, eps, act, rowmask, (bf16_t*)out);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(groupnorm_kernel<float>, grid, dim3(256), 0, stream, x, T_, C, C / groups, gamma, beta, eps, act, rowmask, (float*)out);
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
 
-extern "C" int mmx_abi_version(void) { return 1; }
+// ---------------------------------------------------------------------------- elementwise activation * row mask
+template <typename T>
+__global__ void act_rows_kernel(const float* __restrict__ x, long n, int C, int act, const float* __restrict__ rowmask,
+                                float* __restrict__ outf, T* __restrict__ outa) {
+    constexpr bool PRECISE = sizeof(T) == 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = act_apply<PRECISE>(x[i], act, 0.1f);
+        if (rowmask) v *= rowmask[i / C];
+        if (outf) outf[i] = v;
+        if (outa) outa[i] = Cvt<T>::from_f(v);
+    }
+}
+extern "C" int mmx_act_rows(const float* x, int64_t rows, int C, int act, const float* rowmask, float* out_f32, void* out_act,
+                            int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(x && rows > 0 && C > 0 && (out_f32 || out_act) && act >= ACT_NONE && act <= ACT_TANH);
+    const long n = rows * C;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(act_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, x, n, C, act, rowmask, out_f32, (bf16_t*)out_act);
+    else if (dtype == MMX_F32) hipLaunchKernelGGL(act_rows_kernel<float>, dim3(grid), dim3(256), 0, stream, x, n, C, act, rowmask, out_f32, (float*)out_act);
+    else return MMX_EARG;
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+extern "C" int mmx_abi_version(void) { return 2; }

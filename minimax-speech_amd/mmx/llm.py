@@ -38,7 +38,7 @@ class LlmEngine:
             # (used to continue a partly finished batch at a smaller, cheaper batch size: see compact_from)
             o = share_from
             for k in ("n_layers", "H", "I", "layers", "wdec", "bdec", "embed_tokens", "speech_emb", "llm_emb", "inv_freq",
-                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page", "pf_layers"):
+                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page", "pf_layers", "norm_w"):
                 setattr(self, k, getattr(o, k))
             self.B = max_batch
             self.block_table = torch.zeros(self.B, self.max_pages, dtype=torch.int32, device=self.dev)
@@ -69,11 +69,15 @@ class LlmEngine:
                 wgu=ops.pack_skinny(c(wgu), dtype=dt, kscale=f(p + ".post_attention_layernorm.weight"), interleave_half=self.I),
                 wdown=ops.pack_skinny(c(f(p + ".mlp.down_proj.weight")), dtype=dt)))
             del wqkv, wgu
-        self.wdec = ops.pack_skinny(c(f("llm_decoder.weight")), dtype=dt, kscale=f(prefix + ".norm.weight"))
-        self.bdec = f("llm_decoder.bias")
+        self.norm_w = f(prefix + ".norm.weight")
         self.embed_tokens = f(prefix + ".embed_tokens.weight")
-        self.speech_emb = f("speech_embedding.weight")
-        self.llm_emb = f("llm_embedding.weight")
+        if "llm_decoder.weight" in sd:
+            self.wdec = ops.pack_skinny(c(f("llm_decoder.weight")), dtype=dt, kscale=self.norm_w)
+            self.bdec = f("llm_decoder.bias")
+            self.speech_emb = f("speech_embedding.weight")
+            self.llm_emb = f("llm_embedding.weight")
+        else:                                              # backbone only (Qwen2Encoder.forward_one_step)
+            self.wdec = self.bdec = self.speech_emb = self.llm_emb = None
         # HF Qwen2RotaryEmbedding inv_freq (modeling_qwen2.py: 1 / theta^(arange(0,d,2)/d)), computed like HF in fp32
         self.inv_freq = (1.0 / (rope_theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))).to(self.dev)
         # cos/sin per position exactly as HF computes them (fp32 outer product, then cos/sin): [max_ctx][cos 32 | sin 32]
@@ -299,6 +303,22 @@ class LlmEngine:
 
     def step(self):
         self._decode()
+
+    @torch.no_grad()
+    def forward_rows(self, x: torch.Tensor, pos0: int) -> torch.Tensor:
+        """Qwen2Encoder.forward_one_step (llm.py:359-371): appends the rows x [n, H] to sequence 0's KV cache at position
+        pos0 (full causal attention over the cache) and returns hidden_states[-1] = the final RMSNorm of
+        the backbone, fp32 [n, H]."""
+        n = x.shape[0]
+        if pos0 + n > self.max_pages * self.page:
+            raise RuntimeError("sequence exceeds the KV cache")
+        x = x.to(self.dev, torch.float32).contiguous()
+        out = torch.empty(n, self.H, device=self.dev)
+        for c0 in range(0, n, 64):
+            c1 = min(n, c0 + 64)
+            hc, _ = self._prefill_chunk(x[c0:c1], pos0 + c0, 0)
+            ops.rownorm(hc, self.norm_w, None, self.eps, rows=c1 - c0, C_=self.H, rms=True, out_f32=out[c0:c1], dtype=F32)
+        return out
 
     def compact_from(self, big: "LlmEngine", idx: List[int]):
         """Continue the still-active sequences `idx` of `big` in this (smaller-batch) engine: loop state, token

@@ -111,9 +111,14 @@ def rownorm(x, gamma, beta, eps, *, rows, C_, batch=1, x_bstride=None, rms=False
                              dtype, stream()), "mmx_rownorm")
 
 
-def groupnorm(x, gamma, beta, out, *, B, T, C_, groups, dtype, eps=1e-5):
-    check(load().mmx_groupnorm(_p(x), B, T, C_, groups, _p(gamma), _p(beta), C.c_float(eps), _p(out), dtype, stream()),
-          "mmx_groupnorm")
+def groupnorm(x, gamma, beta, out, *, B, T, C_, groups, dtype, eps=1e-5, act="none", rowmask=None):
+    check(load().mmx_groupnorm(_p(x), B, T, C_, groups, _p(gamma), _p(beta), C.c_float(eps), ACT[act], _p(rowmask), _p(out),
+                               dtype, stream()), "mmx_groupnorm")
+
+
+def act_rows(x, *, rows, C_, act="none", rowmask=None, out_f32=None, out_act=None, dtype=F32):
+    check(load().mmx_act_rows(_p(x), i64(rows), C_, ACT[act], _p(rowmask), _p(out_f32), _p(out_act), dtype, stream()),
+          "mmx_act_rows")
 
 
 def gather_rows(ids, table, *, scale=1.0, rowmask=None, out_f32=None, out_act=None, dtype=F32):

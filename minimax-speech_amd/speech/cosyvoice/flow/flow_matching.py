@@ -18,6 +18,37 @@ class ConditionalCFM(EngineHost):
         assert self.t_scheduler == "cosine", "config.yaml:96: cosine schedule"
         self.estimator = estimator
 
+    def forward_estimator(self, x, mask, mu, t, spks, cond, streaming=False):
+        """flow_matching.py:128-131 (the nn.Module branch; the TensorRT branch has no counterpart here)."""
+        return self.estimator(x, mask, mu, t, spks, cond, streaming=streaming)
+
+    @torch.inference_mode()
+    def solve_euler(self, x, t_span, mu, mask, spks, cond, streaming=False):
+        """flow_matching.py:74-126: fixed-step Euler over t_span with classifier-free guidance — per step the CFG pair
+        [cond; uncond] goes through forward_estimator, then x += dt * ((1 + cfg) * d_cond - cfg * d_uncond) (one kernel).
+        x, mu, cond [1, 80, T]; mask [1, 1, T]; spks [1, 80].  `forward` uses the recorded whole-solve graph instead."""
+        from mmx import ops
+        dev = x.device
+        T = x.size(2)
+        x = x.to(torch.float32).contiguous().clone()
+        t, dt = t_span[0:1].to(dev, torch.float32), (t_span[1] - t_span[0]).to(dev, torch.float32)
+        x_in, mask_in = torch.zeros(2, 80, T, device=dev), torch.zeros(2, 1, T, device=dev)
+        mu_in, t_in = torch.zeros(2, 80, T, device=dev), torch.zeros(2, device=dev)
+        spks_in, cond_in = torch.zeros(2, 80, device=dev), torch.zeros(2, 80, T, device=dev)
+        for step in range(1, len(t_span)):
+            x_in[:] = x
+            mask_in[:] = mask
+            mu_in[0] = mu
+            t_in[:] = t
+            spks_in[0] = spks
+            cond_in[0] = cond
+            d = self.forward_estimator(x_in, mask_in, mu_in, t_in, spks_in, cond_in, streaming).contiguous()
+            ops.cfg_euler(x, d[0], d[1], self.inference_cfg_rate, float(dt), 80 * T)
+            t = t + dt
+            if step < len(t_span) - 1:
+                dt = (t_span[step + 1].to(dev) - t).reshape(())
+        return x.float()
+
 
 class CausalConditionalCFM(ConditionalCFM):
     def __init__(self, in_channels, cfm_params, n_spks=1, spk_emb_dim=64, estimator: torch.nn.Module = None):

@@ -71,6 +71,51 @@ class Qwen2Encoder(nn.Module):
         register(self, man, prefix="llm.")                     # -> self.model.model.{embed_tokens,layers,norm}
         et = self.model.model.embed_tokens
         et.forward = lambda ids: torch.nn.functional.embedding(ids, et.weight)   # callers use it as a module (llm.py:694)
+        self.compute_dtype, self.max_ctx, self._engine = 1, 2048, None
+
+    class _Cache:
+        """Stands for HF's past_key_values: the KV rows live in the engine's paged cache, this records how many."""
+
+        def __init__(self, rows):
+            self.rows = rows
+
+        def get_seq_length(self):
+            return self.rows
+
+    def _eng(self):
+        from mmx.llm import LlmEngine
+        p = next(self.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("Qwen2Encoder: the MI355X hot path has no CPU fallback; move the module to a ROCm device")
+        if self._engine is None:
+            c = self.cfg
+            sd = {"llm." + k: v for k, v in self.state_dict().items()}
+            self._engine = LlmEngine(sd, dtype=self.compute_dtype, device=p.device, max_batch=1, max_ctx=self.max_ctx,
+                                     heads=c["num_attention_heads"], kv_heads=c["num_key_value_heads"],
+                                     head_dim=c["hidden_size"] // c["num_attention_heads"], rope_theta=c["rope_theta"],
+                                     eps=c["rms_norm_eps"])
+        return self._engine
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    @torch.inference_mode()
+    def forward_one_step(self, xs, masks, cache=None):
+        """llm.py:359-371: xs [1, q, H] appended after `cache` -> (hidden_states[-1] [1, q, H], new cache).  `masks` is the
+        reference's lower-triangular [1, q, q]; attention is full causal over the cache (the pinned-stack semantics,
+        SURVEY.md §7 "version-drift trap"), which for a lower-triangular mask is the same thing."""
+        assert xs.shape[0] == 1, "the AR loop decodes one sequence (llm.py:745-760)"
+        rows = 0 if cache is None else cache.rows
+        h = self._eng().forward_rows(xs[0], rows)
+        return h.unsqueeze(0), Qwen2Encoder._Cache(rows + xs.shape[1])
+
+    @torch.inference_mode()
+    def forward(self, xs: torch.Tensor, xs_lens: torch.Tensor):
+        """llm.py:349-357 (teacher-forced pass of one unpadded sequence): -> (hidden [1, T, H], masks [1, 1, T])."""
+        assert xs.shape[0] == 1 and int(xs_lens[0]) == xs.shape[1]
+        h = self._eng().forward_rows(xs[0], 0)
+        return h.unsqueeze(0), torch.ones(1, 1, xs.shape[1], dtype=torch.bool, device=h.device)
 
 
 class Qwen2LM(EngineHost):
@@ -159,6 +204,12 @@ class Qwen2LM(EngineHost):
         text_len += prompt_text_len                      # the reference mutates text_len in place (llm.py:693)
         x = eng.build_lm_input(text, prompt_text, prompt_speech_token)
         yield from self._decode_loop(eng, x, int(tl * min_token_text_ratio), int(tl * max_token_text_ratio))
+
+    @torch.inference_mode()
+    def inference_wrapper(self, lm_input, sampling, min_len, max_len, uuid):
+        """llm.py:713-760, non-vLLM branch: the AR loop over a prepared lm_input [1, L, H] — batched prompt pass, captured
+        decode step, log-softmax + RAS + stop / skip rules on the device (mmx/llm.py, csrc/sampler.hip)."""
+        yield from self._decode_loop(self.engine(1), lm_input[0], int(min_len), int(max_len))
 
     def _is_device_sampler(self):
         from cosyvoice.utils.common import ras_sampling

@@ -204,6 +204,61 @@ def gen_flow():
     np.savez_compressed(os.path.join(GOLD, "flow.npz"), **out)
 
 
+def gen_blocks():
+    """(ii, continued) every sub-block of the estimator on its own (SURVEY.md §8c "each sub-block"), run with the
+    reference's classes: TimestepEmbedding, CausalBlock1D, CausalResnetBlock1D, FeedForward, BasicTransformerBlock (with a
+    pad mask and with a chunk mask as additive bias), the Qwen2 backbone's forward_one_step on a 2-layer model, plus the
+    non-causal matcha Block1D / ResnetBlock1D (GroupNorm) with small seeded weights that travel inside the fixture."""
+    flow = build_flow()
+    sd = flow.state_dict()
+    flow.load_state_dict(W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED), strict=True)
+    est = flow.decoder.estimator
+    from cosyvoice.utils.mask import add_optional_chunk_mask
+    from cosyvoice.utils.common import mask_to_bias
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    B, T = 2, 40
+    with torch.no_grad():
+        t = torch.tensor([0.25, 0.7])
+        temb_in = est.time_embeddings(t)
+        temb = est.time_mlp(temb_in)
+        out.update(temb_in=np_(temb_in), temb=np_(temb))
+        x = torch.randn(B, 256, T, generator=g)
+        mask = torch.ones(B, 1, T)
+        mask[1, :, 31:] = 0
+        fb = est.final_block
+        out.update(cb_x=np_(x), cb_mask=np_(mask), cb_out=np_(fb(x, mask)))
+        rb = est.mid_blocks[0][0]
+        out["rb_out"] = np_(rb(x, mask, temb))
+        rb0 = est.down_blocks[0][0]
+        x320 = torch.randn(B, 320, T, generator=g)
+        out.update(rb0_x=np_(x320), rb0_out=np_(rb0(x320, mask, temb)))
+        tb = est.mid_blocks[0][1][0]
+        hs = torch.randn(B, T, 256, generator=g)
+        out["tb_hs"] = np_(hs)
+        for name, chunk in (("pad", 0), ("chunk", 16)):
+            am = add_optional_chunk_mask(hs, mask.bool(), False, False, 0, chunk, -1).repeat(1, T, 1) if chunk == 0 else \
+                add_optional_chunk_mask(hs, mask.bool(), False, False, 0, chunk, -1)
+            bias = mask_to_bias(am == 1, hs.dtype)
+            out[f"tb_bias_{name}"] = np_(bias)
+            out[f"tb_out_{name}"] = np_(tb(hidden_states=hs, attention_mask=bias, timestep=None))
+        out["ff_out"] = np_(tb.ff(hs))
+        # non-causal matcha blocks (GroupNorm), small seeded weights
+        from matcha.models.components.decoder import Block1D, ResnetBlock1D
+        torch.manual_seed(5)
+        mb, mr = Block1D(64, 96, groups=8).eval(), ResnetBlock1D(64, 96, 128, groups=8).eval()
+        xs = torch.randn(B, 64, T, generator=g)
+        te = torch.randn(B, 128, generator=g)
+        out.update(m_x=np_(xs), m_te=np_(te), mb_out=np_(mb(xs, mask)), mr_out=np_(mr(xs, mask, te)))
+        for k, v in mb.state_dict().items():
+            out["mb." + k] = np_(v)
+        for k, v in mr.state_dict().items():
+            out["mr." + k] = np_(v)
+    for k in ("temb", "cb_out", "rb_out", "rb0_out", "tb_out_pad", "tb_out_chunk", "ff_out", "mb_out", "mr_out"):
+        print(k, out[k].shape, f"std {out[k].std():.3f}")
+    np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **out)
+
+
 def gen_llm():
     R.import_cosyvoice()
     from functools import partial
@@ -366,8 +421,8 @@ def gen_sampler():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["dac", "dacenc", "flow", "llm", "bistream", "sampler", "spk"]
+    which = sys.argv[1:] or ["dac", "dacenc", "flow", "blocks", "llm", "bistream", "sampler", "spk"]
     for w in which:
         t0 = time.time()
-        {"dac": gen_dac, "dacenc": gen_dac_enc, "flow": gen_flow, "llm": gen_llm, "bistream": gen_bistream, "sampler": gen_sampler, "spk": gen_spk}[w]()
+        {"dac": gen_dac, "dacenc": gen_dac_enc, "flow": gen_flow, "blocks": gen_blocks, "llm": gen_llm, "bistream": gen_bistream, "sampler": gen_sampler, "spk": gen_spk}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f}s")
