@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import dac as ODAC
 from oracle import flow as OFLOW
@@ -206,3 +207,24 @@ def test_llm_bistream_matches_reference(golden_dir, case):
     assert lp.shape[0] == g[f"{case}_logp_head"].shape[0]
     assert (lp[:, :128] - torch.from_numpy(g[f"{case}_logp_head"])).abs().max() < 2e-4
     assert (lp.max(dim=1).values - torch.from_numpy(g[f"{case}_logp_max"])).abs().max() < 2e-4
+
+
+def test_flow_sub_blocks_match_reference(golden_dir, flow_sd):
+    """Every estimator sub-block of the oracle vs the reference's own modules (tests/golden/blocks.npz): time MLP, causal
+    block, causal ResNet block (256- and 320-channel input), transformer block under a pad mask and under a chunk mask."""
+    g = _load(golden_dir, "blocks.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    e = "decoder.estimator"
+    temb = OFLOW.sinusoidal_pos_emb(torch.tensor([0.25, 0.7]), 320)
+    assert (temb - t("temb_in")).abs().max() < 1e-5
+    te = F.linear(F.silu(F.linear(temb, flow_sd[e + ".time_mlp.linear_1.weight"], flow_sd[e + ".time_mlp.linear_1.bias"])),
+                  flow_sd[e + ".time_mlp.linear_2.weight"], flow_sd[e + ".time_mlp.linear_2.bias"])
+    assert (te - t("temb")).abs().max() < 2e-5
+    x, m = t("cb_x").transpose(1, 2), t("cb_mask").transpose(1, 2)
+    assert (OFLOW.causal_block(flow_sd, e + ".final_block", x, m).transpose(1, 2) - t("cb_out")).abs().max() < 2e-5
+    assert (OFLOW.causal_resnet(flow_sd, e + ".mid_blocks.0.0", x, m, t("temb")).transpose(1, 2) - t("rb_out")).abs().max() < 2e-5
+    y = OFLOW.causal_resnet(flow_sd, e + ".down_blocks.0.0", t("rb0_x").transpose(1, 2), m, t("temb")).transpose(1, 2)
+    assert (y - t("rb0_out")).abs().max() < 2e-5
+    for name in ("pad", "chunk"):
+        y = OFLOW.basic_transformer_block(flow_sd, e + ".mid_blocks.0.1.0", t("tb_hs"), t(f"tb_bias_{name}"))
+        assert (y - t(f"tb_out_{name}")).abs().max() < 2e-5, name
