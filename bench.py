@@ -204,6 +204,13 @@ def _time_steps(fn, build, warmup, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def make_engine(dt, device, max_batch, max_ctx):
+    """The engine under test (full-size synthetic weights).  A function of its own so that the 2-rank CPU rehearsal of
+    this script's launch / shard / barrier / gather contract can substitute a stub (tests/test_cpu_host.py)."""
+    from mmx.pipeline import TtsEngine
+    return TtsEngine(*build_weights(0), dtype=dt, device=device, max_batch=max_batch, max_ctx=max_ctx)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,9 +235,12 @@ def main():
     # MMX_BENCH_REHEARSE=1: multi-rank rehearsal on a ONE-GPU box - every rank uses cuda:0, collectives run on gloo
     # over host copies.  Exercises the launch contract, sharding, barriers and the gather; never use it for numbers.
     rehearse = bool(os.environ.get("MMX_BENCH_REHEARSE")) and world > 1
+    have_gpu = torch.cuda.is_available()
     if rehearse:
         local = 0
-    torch.cuda.set_device(local)
+    if have_gpu:
+        torch.cuda.set_device(local)
+    dev = f"cuda:{local}" if have_gpu else "cpu"         # "cpu" only in the rehearsal test (tests/test_cpu_host.py stubs the engine)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -239,15 +249,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     cdev = "cpu" if rehearse else "cuda"
-    from mmx.pipeline import TtsEngine, TOKEN_RATE, SAMPLE_RATE
+    from mmx.pipeline import TOKEN_RATE, SAMPLE_RATE
     from mmx.dist import gather_audio, shard_utterances
     dt = 1 if a.dtype == "bf16" else 0
-    llm_sd, flow_sd, dac_sd = build_weights(0)
     PER_GPU = 1 if a.workload in ("single", "longform") else a.per_gpu
-    eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=dt, device=f"cuda:{local}", max_batch=PER_GPU,
-                    max_ctx=2048 if a.workload == "longform" else 640)
-    del llm_sd, flow_sd, dac_sd
-    emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).cuda()
+    eng = make_engine(dt, dev, PER_GPU, 2048 if a.workload == "longform" else 640)
+    emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).to(dev)
     if a.workload == "longform":
         # BASELINE config 5: one 60 s utterance per GPU, streaming (25-token hops, chunk-causal flow over all tokens so
         # far at every hop, captured decode step); bf16 attention (the fp8 MFMA variant is not built)
@@ -263,7 +270,7 @@ def main():
     lens = [lens_all[i] for i in mine]
     g = torch.Generator().manual_seed(2)
     all_text = [torch.randint(0, 151936, (1, 290 if a.workload == "longform" else 48), generator=g) for _ in range(len(lens_all))]
-    texts = [all_text[i].cuda() for i in mine]
+    texts = [all_text[i].to(dev) for i in mine]
     max_samples = 2 * max(lens_all) * eng.hop
 
     first_chunk_ms = []
@@ -274,7 +281,8 @@ def main():
             n = 0
             for k, w in enumerate(eng.tts_stream(texts[0], emb, seed=0, exact_steps=lens[0])):
                 if k == 0:
-                    torch.cuda.current_stream().synchronize()
+                    if have_gpu:
+                        torch.cuda.current_stream().synchronize()
                     first_chunk_ms.append((time.perf_counter() - t_in) * 1e3)
                 n += w.shape[-1]
             return n
@@ -284,10 +292,12 @@ def main():
         return sum(w.shape[-1] for w in wavs)
 
     def fence():
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if have_gpu:
+                torch.cuda.synchronize()
 
     # engine build, part of setup like weight packing: the first pass over a new shape runs eagerly and the second
     # records its hipGraphs (decode step per batch size, one Euler solve per flow group shape); W warm-up steps follow
@@ -336,6 +346,7 @@ def main():
                 # extra keys, measured after the timed region: (1) BASELINE config 3 (one 10 s utterance) for the
                 # per-utterance RTF target (>= 10x real time); (2) the same config-4 share on the fp32 build, the build
                 # that meets the north-star parity (ids identical, waveform <= 1e-3: tests/test_gpu_pipeline.py)
+                from mmx.pipeline import TtsEngine
                 del eng
                 torch.cuda.empty_cache()
                 w3 = build_weights(0)

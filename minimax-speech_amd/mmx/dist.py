@@ -19,31 +19,32 @@ def shard_utterances(lengths: Sequence[int], world: int) -> List[List[int]]:
 
 
 def gather_audio(wavs: List[torch.Tensor], owned: List[int], n_total: int, max_samples: int,
-                 group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All ranks end up with every utterance: returns (audio [n_total, max_samples] fp32 zero padded,
-    lengths [n_total] int64).  Two collectives: sample counts, then the padded buffer (fixed shapes, so the
-    call can be overlapped/captured; payload <= 61 MB per rank for 32 x 20 s)."""
+                 group=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """All ranks end up with every utterance.  Returns (buf, lengths, row_of): utterance i (global index) is
+    buf[row_of[i], :lengths[i]]; buf is THE receive buffer of the all-gather, [world * per_rank, max_samples] fp32 zero
+    padded, in rank-major slot order — no second copy in global order is made (61 MB per rank at 32 x 20 s).
+    Two collectives: (index, sample count) pairs, then the padded audio (fixed shapes, so the call can be overlapped /
+    captured)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = wavs[0].device if wavs else torch.device("cpu")
     per = (n_total + world - 1) // world
-    buf = torch.zeros(per, max_samples, dtype=torch.float32, device=dev)
-    meta = torch.full((per, 2), -1, dtype=torch.int64, device=dev)      # (global index, n samples)
+    assert len(wavs) <= per
+    all_buf = torch.zeros(world * per, max_samples, dtype=torch.float32, device=dev)
+    all_meta = torch.full((world * per, 2), -1, dtype=torch.int64, device=dev)      # (global index, n samples)
+    buf, meta = all_buf[rank * per:(rank + 1) * per], all_meta[rank * per:(rank + 1) * per]   # this rank's slots, in place
     for slot, (w, gi) in enumerate(zip(wavs, owned)):
         n = w.numel()
         buf[slot, :n] = w.reshape(-1)
         meta[slot, 0], meta[slot, 1] = gi, n
-    if world == 1:
-        all_buf, all_meta = buf, meta
-    else:
-        all_buf = torch.empty(world * per, max_samples, dtype=torch.float32, device=dev)
-        all_meta = torch.empty(world * per, 2, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(all_meta, meta, group=group)
-        dist.all_gather_into_tensor(all_buf, buf, group=group)
-    audio = torch.zeros(n_total, max_samples, dtype=torch.float32, device=dev)
+    if world > 1:
+        dist.all_gather_into_tensor(all_meta, meta.clone(), group=group)
+        dist.all_gather_into_tensor(all_buf, buf, group=group)      # in-place form: the input is this rank's slice of the output
     lens = torch.zeros(n_total, dtype=torch.int64, device=dev)
-    m = all_meta.reshape(-1, 2)
-    valid = m[:, 0] >= 0
-    audio[m[valid, 0]] = all_buf.reshape(-1, max_samples)[valid]
-    lens[m[valid, 0]] = m[valid, 1]
-    return audio, lens
+    row_of = torch.full((n_total,), -1, dtype=torch.int64, device=dev)
+    valid = all_meta[:, 0] >= 0
+    rows = torch.nonzero(valid).reshape(-1)
+    row_of[all_meta[rows, 0]] = rows
+    lens[all_meta[rows, 0]] = all_meta[rows, 1]
+    return all_buf, lens, row_of

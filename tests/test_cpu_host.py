@@ -123,10 +123,11 @@ lens = [300, 120, 480, 50, 77]
 sh = shard_utterances(lens, 2)
 mine = sh[rank]
 wavs = [torch.full((lens[i] * 3,), float(i + 1)) for i in mine]
-audio, n = gather_audio(wavs, mine, len(lens), 480 * 3)
+buf, n, row_of = gather_audio(wavs, mine, len(lens), 480 * 3)
 for i, L in enumerate(lens):
     assert int(n[i]) == L * 3, (i, n)
-    assert torch.all(audio[i, :L * 3] == i + 1) and torch.all(audio[i, L * 3:] == 0)
+    a = buf[int(row_of[i])]
+    assert torch.all(a[:L * 3] == i + 1) and torch.all(a[L * 3:] == 0)
 dist.destroy_process_group()
 print("ok", rank)
 """
@@ -141,3 +142,45 @@ def test_two_rank_audio_all_gather_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+_BENCH_WORKER = r"""
+import json, os, sys, torch
+root = sys.argv[1]
+sys.path.insert(0, root)
+os.environ.update(RANK=sys.argv[3], LOCAL_RANK=sys.argv[3], WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2],
+                  MMX_BENCH_REHEARSE="1")
+import bench
+
+
+class StubEngine:
+    # stands for TtsEngine in the CPU rehearsal: zero waveforms of the right lengths (2 frames per token, 480 samples per frame)
+    hop = 480
+
+    def tts_batch(self, texts, embs, seed=0, exact_steps=None, **kw):
+        return [torch.zeros(1, 1, 2 * n * self.hop) for n in exact_steps]
+
+
+bench.make_engine = lambda dt, device, max_batch, max_ctx: StubEngine()
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu", "4", "--no-cpu-baseline", "--no-extras"]
+bench.main()
+"""
+
+
+def test_bench_two_rank_rehearsal_gloo(tmp_path):
+    """bench.py's multi-rank contract on 2 gloo ranks (CPU tensors, stub engine): env-driven rendezvous, length-balanced
+    sharding, barrier-bracketed timed region, max-over-ranks time, all-gather of the audio, ONE JSON line from rank 0
+    whose value is the whole-job aggregate."""
+    script = tmp_path / "b.py"
+    script.write_text(_BENCH_WORKER)
+    port = 31500 + os.getpid() % 2000
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
+    lines = [l for l in outs[0][0].decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].decode().splitlines() if l.startswith("{")]
+    j = json.loads(lines[0])
+    lens = torch.randint(50, 501, (8,), generator=torch.Generator().manual_seed(3)).tolist()
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert abs(j["config"]["audio_s_per_step"] - sum(lens) / 25.0) < 0.01          # both ranks' utterances are counted
