@@ -143,6 +143,8 @@ int mmx_cfg_euler(float* x, const float* d_cond, const float* d_uncond, float cf
  *   arch_util.py:58-77 QKVAttentionLegacy, whose q*s . k*s with s = D^-1/4 equals scale = D^-1/2).
  *   Replaces diffusers Attention (SDPA) of transformer.py:196-204 with the additive bias of
  *   decoder.py:441-445 / common.py:160-168, and RelPositionMultiHeadedAttention.
+ * q_begin (multiple of 16; 0 = all): only queries q_begin .. T-1 are computed (keys still 0 .. T-1) — the streaming hop with
+ *   cached K / V.
  * mmx_attn_flash_bf16: the MFMA flash-attention kernel for the same contract without rel-pos, bf16,
  *   D = 64, V given TRANSPOSED as vt[b][h*D + d][t] (ldvt elements per row, zero padded).
  */
@@ -150,10 +152,10 @@ int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int6
                    const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
                    int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs, int chunk,
                    const void* pos, int64_t ldp, const float* pos_u, const float* pos_v,
-                   int head_stride, int dtype, hipStream_t stream);
+                   int head_stride, int q_begin, int dtype, hipStream_t stream);
 int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
-                        int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk,
+                        int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk, int q_begin,
                         hipStream_t stream);
 
 /* DAC-VAE encoder head: Conv1d(1 -> C, k) + LeakyReLU (dac-vae/model.py:208 with :509-514) on a mono waveform
@@ -245,6 +247,9 @@ int mmx_sample_step(const float* logits, int64_t ldl, int V, int B, int eos_id, 
  *   h = mish(LN(conv3(a_in) + b1)) * m;  h = (h + tv[b]) * m;  h = mish(LN(conv3(h) + b2)) * m;
  *   x = h + conv1(a_in) + br.  a_in T [B][T][lda] (cin columns, already masked); tv = mlp(mish(t_emb)) fp32 [B][256].
  * bm: 16 / 32 / 64 (bf16), 16 / 32 (fp32 tail), 16 (fp32 resnet).
+ * t_begin > 0 (streaming with cached state, config 5): only frames t_begin .. T-1 are computed; every buffer is indexed by
+ * absolute frame with the batch strides given, so the rows of earlier hops (the conv halo, the K / V rows) are found
+ * where those hops left them.
  */
 typedef struct MmxEstNext {
     const void* wqkv;
@@ -270,6 +275,7 @@ typedef struct MmxEstTailParams {
     void* act_out;          /* T or NULL */
     int64_t ao_bs, x_bs, rm_bs, act_bs;
     int32_t ldao, act_ld, B, T;
+    int32_t t_begin;        /* first frame to process (multiple of 16; 0 = all): frames before it are only read */
     float eps;
     MmxEstNext next;
 } MmxEstTailParams;
@@ -290,6 +296,7 @@ typedef struct MmxEstResnetParams {
     const float* rowmask;
     int64_t a_bs, x_bs, tv_bs, rm_bs;
     int32_t lda, cin, B, T;
+    int32_t t_begin;        /* as in MmxEstTailParams; the causal halo rows t_begin-18 .. are read from a_in */
     float eps;
     MmxEstNext next;
 } MmxEstResnetParams;

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
     const T* __restrict__ q, long ldq, long q_bs, const T* __restrict__ k, long ldk, long k_bs,
     const T* __restrict__ v, long ldv, long v_bs, T* __restrict__ out, long ldo, long o_bs,
     int H, int Tq, int Tk, float scale, const float* __restrict__ keymask, long km_bs, int chunk,
-    const T* __restrict__ pos, long ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v, int hs) {
+    const T* __restrict__ pos, long ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v, int hs,
+    int q_begin) {
     constexpr int D = 64, QT = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qu = reinterpret_cast<float*>(smem);        // [QT][D]  q (+u)
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
     float* inv_l = qv + QT * D;                        // [QT]
     float* S = inv_l + QT;                             // [QT][Tk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QT;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = q_begin + blockIdx.x * QT;
     q += (long)b * q_bs + h * hs;                     // hs: column stride between heads of q/k/v (D, or 3D for the
     k += (long)b * k_bs + h * hs;                     // head-interleaved qkv of arch_util.QKVAttentionLegacy)
     v += (long)b * v_bs + h * hs;
@@ -111,21 +112,22 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
                               const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
                               int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs,
                               int chunk, const void* pos, int64_t ldp, const float* pos_u, const float* pos_v,
-                              int head_stride, int dtype, hipStream_t stream) {
+                              int head_stride, int q_begin, int dtype, hipStream_t stream) {
     MMX_CHECK_ARG(q && k && v && out && B > 0 && H > 0 && D == 64 && Tq > 0 && Tk > 0 && chunk >= 0);
+    MMX_CHECK_ARG(q_begin >= 0 && q_begin < Tq && q_begin % 8 == 0);
     const int hs = head_stride > 0 ? head_stride : D;
     MMX_CHECK_ARG(!pos || (pos_u && pos_v && Tq == Tk));
     size_t lds = (size_t)(2 * 8 * 64 + 8 + 8 * (size_t)Tk) * 4;
     MMX_CHECK_ARG(lds <= 160 * 1024);
-    dim3 grid((Tq + 7) / 8, H, B);
+    dim3 grid((Tq - q_begin + 7) / 8, H, B);
     if (dtype == MMX_BF16)
         hipLaunchKernelGGL(attn_dense_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
                            (const bf16_t*)v, ldv, v_bs, (bf16_t*)out, ldo, o_bs, H, Tq, Tk, scale, keymask, km_bs, chunk,
-                           (const bf16_t*)pos, ldp, pos_u, pos_v, hs);
+                           (const bf16_t*)pos, ldp, pos_u, pos_v, hs, q_begin);
     else if (dtype == MMX_F32)
         hipLaunchKernelGGL(attn_dense_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, ldq, q_bs, (const float*)k, ldk, k_bs,
                            (const float*)v, ldv, v_bs, (float*)out, ldo, o_bs, H, Tq, Tk, scale, keymask, km_bs, chunk,
-                           (const float*)pos, ldp, pos_u, pos_v, hs);
+                           (const float*)pos, ldp, pos_u, pos_v, hs, q_begin);
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;
@@ -143,7 +145,8 @@ template <int MF>
 __global__ __launch_bounds__(256) void attn_flash_kernel(
     const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
     const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
-    int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs) {
+    int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
+    int q_begin) {
     // LDS row pitches.  A fragment read is ds_read_b128 at (row l16, 16-byte chunk g); the hardware serves it in the lane
     // groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS), i.e. 16 different rows with two
     // adjacent chunks per group: a 144 B pitch puts 7 of the 16 lanes on busy banks (8 LDS cycles instead of 4; PMC:
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     if (pair >= npairs) return;                        // uniform: the grid is padded to a multiple of 8 pairs
     const int qt = slot % nq;
     const int b = pair / nheads, h = pair % nheads;
-    const int qb = qt * (4 * QW) + wave * QW;          // this wave's first query
+    const int qb = q_begin + qt * (4 * QW) + wave * QW;   // this wave's first query
     q += (long)b * q_bs + h * D;
     k += (long)b * k_bs + h * D;
     vt += (long)b * vt_bs + (long)h * D * ldvt;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     // keys beyond the last query's chunk are invisible to the whole block
     int kend = Tn;
     if (chunk > 0) {
-        int qlast = qt * (4 * QW) + 4 * QW - 1;
+        int qlast = q_begin + qt * (4 * QW) + 4 * QW - 1;
         if (qlast > Tn - 1) qlast = Tn - 1;
         int e = (qlast / chunk + 1) * chunk;
         if (e < kend) kend = e;
@@ -366,21 +369,23 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
 extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                                    const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                                    int B, int H, int T_, float scale, const float* keymask, int64_t km_bs, int chunk,
-                                   hipStream_t stream) {
+                                   int q_begin, hipStream_t stream) {
     MMX_CHECK_ARG(q && k && vt && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0);
+    MMX_CHECK_ARG(q_begin >= 0 && q_begin < T_ && q_begin % 16 == 0);
     MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
     MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8);
     MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0);
     const int npairs = H * B;
-    const bool small = (long)npairs * ((T_ + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
-    const int qtile = small ? 64 : 128, nq = (T_ + qtile - 1) / qtile;
+    const int Tq = T_ - q_begin;
+    const bool small = (long)npairs * ((Tq + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
+    const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
     if (small)
         hipLaunchKernelGGL(attn_flash_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
-                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs);
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin);
     else
         hipLaunchKernelGGL(attn_flash_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
-                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs);
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
     float* patch = patch_all + wave * 16 * LDC;
-    const int b = blockIdx.y, t0 = blockIdx.x * BM, Tn = p.T;
+    const int b = blockIdx.y, t0 = p.t_begin + blockIdx.x * BM, Tn = p.T;
     const int col0 = wave * 64 + cq;                   // this lane's 16 columns of a 256-wide row
 
     const T* wo = reinterpret_cast<const T*>(p.wo) + (long)lane * E;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
     float* patch = patch_all + wave * 16 * LDC;
-    const int b = blockIdx.y, t0 = blockIdx.x * BM, Tn = p.T;
+    const int b = blockIdx.y, t0 = p.t_begin + blockIdx.x * BM, Tn = p.T;
     const int col0 = wave * 64 + cq;
     const int cs = cin / KB;                           // k-steps per tap
     const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
@@ -611,6 +611,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int p
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstTailParams& p = *pp;
     MMX_CHECK_ARG(p.ao && p.x && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.n3g && p.n3b && p.B > 0 && p.T > 0);
+    MMX_CHECK_ARG(p.t_begin >= 0 && p.t_begin < p.T && p.t_begin % 16 == 0);
     MMX_CHECK_ARG(p.ldao >= 512 && p.ldao % 8 == 0 && p.ao_bs % 8 == 0 && p.x_bs % 4 == 0);
     MMX_CHECK_ARG(((uintptr_t)p.ao % 16) == 0 && ((uintptr_t)p.x % 16) == 0);
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % 8 == 0 && p.act_bs % 8 == 0 && ((uintptr_t)p.act_out % 16) == 0));
@@ -620,7 +621,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int p
         const size_t lds = tail_lds<TT, BM>();                                                             \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_tail_kernel<TT, BM, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
     } while (0)
     // ring depth by tile height (see WRing); the stage k-step counts here are 8 / 16 (bf16) and 16 / 32 (fp32)
     // pf = 0: the default depth
@@ -643,6 +644,7 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstResnetParams& p = *pp;
     MMX_CHECK_ARG(p.a_in && p.x && p.w1 && p.w2 && p.wr && p.b1 && p.b2 && p.br && p.g1 && p.be1 && p.g2 && p.be2 && p.tv);
+    MMX_CHECK_ARG(p.t_begin >= 0 && p.t_begin < p.T && p.t_begin % 16 == 0);
     MMX_CHECK_ARG(p.B > 0 && p.T > 0 && p.cin >= 64 && p.cin % 32 == 0 && p.cin <= 512 && p.lda >= p.cin && p.lda % 8 == 0 && p.a_bs % 8 == 0);
     MMX_CHECK_ARG(((uintptr_t)p.a_in % 16) == 0 && ((uintptr_t)p.x % 16) == 0 && p.x_bs % 4 == 0 && p.tv_bs % 4 == 0 && ((uintptr_t)p.tv % 16) == 0);
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
@@ -652,7 +654,7 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_resnet_kernel<TT, BM, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
-        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF>), dim3((p.T + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
     } while (0)
     // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count
     // (conv k3 over cin, conv k3 over 256, 1x1 over cin, Q/K/V over 256); cin = 320 allows 2 (bf16) / 4 (fp32) only

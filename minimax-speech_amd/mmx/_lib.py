@@ -43,13 +43,13 @@ class EstNext(C.Structure):
 class EstTailParams(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("ao", "x", "wo", "w1", "w2", "bo", "b1", "b2", "n3g", "n3b", "rowmask", "act_out")] + \
                [(k, C.c_int64) for k in ("ao_bs", "x_bs", "rm_bs", "act_bs")] + \
-               [(k, C.c_int32) for k in ("ldao", "act_ld", "B", "T")] + [("eps", C.c_float), ("next", EstNext)]
+               [(k, C.c_int32) for k in ("ldao", "act_ld", "B", "T", "t_begin")] + [("eps", C.c_float), ("next", EstNext)]
 
 
 class EstResnetParams(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("a_in", "x", "w1", "w2", "wr", "b1", "g1", "be1", "b2", "g2", "be2", "br", "tv", "rowmask")] + \
                [(k, C.c_int64) for k in ("a_bs", "x_bs", "tv_bs", "rm_bs")] + \
-               [(k, C.c_int32) for k in ("lda", "cin", "B", "T")] + [("eps", C.c_float), ("next", EstNext)]
+               [(k, C.c_int32) for k in ("lda", "cin", "B", "T", "t_begin")] + [("eps", C.c_float), ("next", EstNext)]
 
 
 def fill_struct(st, **kw):

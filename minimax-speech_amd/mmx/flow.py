@@ -516,6 +516,138 @@ class FlowEngine:
         ops.conv1d(a, self.proj_w, T=T, Cin=C, k=1, dtype=dt, batch=B, bias=self.proj_b, rowmask=mask, out_f32=out)
         return out
 
+    # ------------------------------------------------------------------ streaming with cached state (BASELINE config 5)
+    class StreamState:
+        """What a streaming utterance keeps between hops so that a hop solves only its NEW frames.  The estimator is
+        chunk-causal in streaming mode (attention: query frame i sees keys < (i // 50 + 1) * 50, flow/decoder.py:441-445;
+        every conv is causal), its inputs for finished frames never change (the encoder is chunk-causal with a 3-token
+        look-ahead, the noise is fixed), and a hop adds exactly one 50-frame chunk.  So the trajectory of finished frames
+        is final, and per Euler step s and per layer only two things of theirs are ever read again: the K / V rows of every
+        transformer block and the last rows of every causal conv's input.  Both are kept, per Euler step, in buffers
+        indexed by absolute frame; the kernels take `t_begin` / `q_begin` and compute only rows from there on.
+        The reference recomputes every frame at every hop (cli/model.py:341-352): O(n^2) estimator work per utterance;
+        with the cache it is O(n) plus attention over the cached keys.  Exact: tests/test_gpu_stream.py compares the two.
+        Device memory per Euler step (bf16, B = 2): 56 blocks x (Q|K rows 4 KB + V^T 2 KB) + 16 conv inputs x ~0.6 KB per
+        frame = 0.36 MB per frame -> 10.8 GB for a 60 s utterance (3000 frames, 10 steps); fp32 twice that."""
+
+        def __init__(self, eng, Tcap):
+            self.eng, self.Tcap, self.T = eng, ops.round_up(Tcap, 64), 0
+            self.steps = [None] * eng.n_timesteps
+            self.lat = torch.zeros(self.Tcap, 80, device=eng.dev)
+            Tc, new = self.Tcap, eng._new
+            self.xs, self.c1 = new(2, Tc, eng.C, f32=True), new(2, Tc, eng.C, f32=True)
+            self.ao, self.afin, self.d = new(2, Tc, 512), new(2, Tc, eng.C), new(2, Tc, 80, f32=True)
+            tt, dd = eng.t_schedule()
+            self.t_all = torch.tensor([[v, v] for v in tt], dtype=torch.float32, device=eng.dev)
+            self.dt = dd
+
+        def step_buffers(self, s):
+            if self.steps[s] is None:
+                e, Tc = self.eng, self.Tcap
+                z = lambda *sh: torch.zeros(*sh, dtype=e.tdt, device=e.dev)
+                nblk = 4 * (2 + len(e.mid))
+                ldq = 1024 if e.dtype == BF16 else 1536
+                self.steps[s] = dict(h0=z(2, Tc, 320), amid=[z(2, Tc, e.C) for _ in e.mid], cat=z(2, Tc, 2 * e.C), aup=z(2, Tc, e.C),
+                                     a2=z(2, Tc, e.C), qk=[z(2, Tc, ldq) for _ in range(nblk)],
+                                     vt=([z(2, 512, Tc) for _ in range(nblk)] if e.dtype == BF16 else [None] * nblk))
+            return self.steps[s]
+
+    def stream_open(self, max_frames: int) -> "FlowEngine.StreamState":
+        return FlowEngine.StreamState(self, max_frames)
+
+    def _estimator_stream(self, st, s, x_new, mu_new, spks2, cond_new, tb, T):
+        """One estimator call of Euler step s on frames tb .. T-1 of a streaming utterance (CFG pair, B = 2), reading the
+        cached rows of earlier hops.  x_new [1, n, 80], mu_new / cond_new [2, n, 80] (row 1 zero), spks2 [2, 80].
+        Returns d fp32 [2, Tcap, 80] (valid rows tb .. T-1)."""
+        dt, C, Tc = self.dtype, self.C, st.Tcap
+        S = st.step_buffers(s)
+        B, n = 2, T - tb
+        r0 = tb // 16 * 16                                   # tiles start on a 16-frame boundary: <= 15 finished frames are
+        chunk = self.est_chunk                               # recomputed (same inputs, same values)
+        bm_t, bm_r = self._tile_rows(B, T - r0)
+        te = self._new(B, self.tdim)
+        ops.sinusoidal_emb(st.t_all[s], te, dim=self.tdim, dtype=dt)
+        t1 = self._new(B, 1024)
+        ops.linear(te, self.t_w1, self.tdim, dtype=dt, bias=self.t_b1, act="silu", out_act=t1)
+        t2 = self._new(B, 1024)
+        ops.linear(t1, self.t_w2, 1024, dtype=dt, bias=self.t_b2, act2="mish", out_act=t2)
+        ntv = self.mlp_w.shape[0]
+        tv = self._new(B, ntv, f32=True)
+        ops.linear(t2, self.mlp_w, 1024, dtype=dt, bias=self.mlp_b, out_f32=tv)
+        h0w = self._new(B, n, 320)
+        ops.est_pack(x_new, mu_new, spks2, cond_new, h0w, B=B, T=n, dtype=dt, x_bstride=n * 80, x_mod=1)
+        S["h0"][:, tb:T].copy_(h0w)
+        bf = dt == BF16
+        blk = [0]
+
+        def nxt(w, i):
+            qk, vt = S["qk"][i], S["vt"][i]
+            return ops.est_next(wqkv=w["wqkv_p"], n1g=w["n1g"], n1b=w["n1b"], q_out=qk, ldq=qk.shape[-1], q_bs=Tc * qk.shape[-1],
+                                vt_out=vt, ldvt=(Tc if bf else 0), vt_bs=512 * Tc)
+
+        def attention(i):
+            qk, vt = S["qk"][i], S["vt"][i]
+            if bf:
+                ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, st.ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tc, ldo=512, q_bs=Tc * 1024,
+                                    k_bs=Tc * 1024, vt_bs=512 * Tc, o_bs=Tc * 512, scale=0.125, chunk=chunk, q_begin=r0)
+            else:
+                ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], st.ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                               q_bs=Tc * 1536, k_bs=Tc * 1536, v_bs=Tc * 1536, o_bs=Tc * 512, scale=0.125, dtype=dt, chunk=chunk,
+                               q_begin=r0)
+
+        def stage(sw, a_in, lda, cin, act_out, act_ld):
+            r, blocks = sw["res"], sw["blocks"]
+            i0 = blk[0]
+            ops.est_resnet(a_in, lda, cin, st.xs, r, tv[:, r["idx"] * C:], ntv, B=B, T=T, dtype=dt, bm=bm_r, nxt=nxt(blocks[0], i0),
+                           t_begin=r0, Tcap=Tc)
+            for j, w in enumerate(blocks):
+                attention(i0 + j)
+                last = j == len(blocks) - 1
+                ops.est_tail(st.ao, st.xs, w, B=B, T=T, dtype=dt, bm=bm_t, act_out=(act_out if last else None), act_ld=act_ld,
+                             nxt=(None if last else nxt(blocks[j + 1], i0 + j + 1)), t_begin=r0, Tcap=Tc)
+            blk[0] += len(blocks)
+
+        def conv3(src, ld, col0, cin, wgt, bias, out_act=None, out_f32=None, ldo=None):
+            """causal conv k3 over frames r0 .. T-1 of a cached [2, Tcap, ld] buffer (rows before r0 are the halo)"""
+            N = wgt.shape[0]
+            ops.gemm(src[:, r0:, col0:], wgt, T - r0, N, dtype=dt, lda=ld, cin=cin, ntaps=3, row_off=-2, row_lo=-r0, row_hi=T - r0,
+                     batch=B, a_bstride=Tc * ld, bias=bias, out_act=(out_act[:, r0:] if out_act is not None else None), ldo_a=N,
+                     oa_bstride=Tc * N, out_f32=(out_f32[:, r0:] if out_f32 is not None else None), ldo_f=N, of_bstride=Tc * N)
+
+        stage(self.down, S["h0"], 320, 320, S["cat"][:, :, C:], 2 * C)
+        conv3(S["cat"], 2 * C, C, C, self.down_w, self.down_b, out_act=S["amid"][0])
+        for i, sw in enumerate(self.mid):
+            lastst = i == len(self.mid) - 1
+            stage(sw, S["amid"][i], C, C, S["cat"] if lastst else S["amid"][i + 1], 2 * C if lastst else C)
+        stage(self.up, S["cat"], 2 * C, 2 * C, S["aup"], C)
+        conv3(S["aup"], C, 0, C, self.up_w, self.up_b, out_act=S["a2"])
+        conv3(S["a2"], C, 0, C, self.fin_w, self.fin_b, out_f32=st.c1)
+        ops.rownorm(st.c1[:, r0:], self.fin_g, self.fin_be, 1e-5, rows=T - r0, C_=C, batch=B, x_bstride=Tc * C, act="mish",
+                    out_act=st.afin[:, r0:], o_bstride=Tc * C, dtype=dt)
+        ops.gemm(st.afin[:, r0:], self.proj_w, T - r0, 80, dtype=dt, lda=C, cin=C, batch=B, a_bstride=Tc * C, bias=self.proj_b,
+                 out_f32=st.d[:, r0:], ldo_f=80, of_bstride=Tc * 80)
+        return st.d
+
+    @torch.no_grad()
+    def cfm_stream(self, st, mu, spks, cond):
+        """Solves the frames st.T .. T-1 of a streaming utterance (mu / cond fp32 [T, 80] for ALL frames so far) and returns the
+        latents of all T frames (a view of the state).  Every hop must add whole 50-frame chunks."""
+        T, tb = mu.shape[0], st.T
+        assert tb < T <= st.Tcap and tb % self.est_chunk == 0 and T % self.est_chunk == 0, (tb, T, st.Tcap)
+        n = T - tb
+        x = self.rand_noise[0, :, tb:T].t().contiguous().to(self.dev).reshape(1, n, 80)
+        mu2, cond2 = torch.zeros(2, n, 80, device=self.dev), torch.zeros(2, n, 80, device=self.dev)
+        mu2[0].copy_(mu[tb:T])
+        cond2[0].copy_(cond[tb:T])
+        spks2 = torch.zeros(2, 80, device=self.dev)
+        spks2[0].copy_(spks.reshape(-1))
+        for s in range(self.n_timesteps):
+            d = self._estimator_stream(st, s, x, mu2, spks2, cond2, tb, T)
+            ops.cfg_euler(x, d[0, tb:T], d[1, tb:T], self.cfg, st.dt[s], n * 80)
+        st.lat[tb:T].copy_(x[0])
+        st.T = T
+        return st.lat[:T]
+
     @torch.no_grad()
     def estimator_channels_first(self, x, mask, mu, t, spks, cond, streaming=False):
         """The reference's estimator seam (flow_matching.py:128-131; ONNX names x, mask, mu, t, spks, cond):
@@ -622,10 +754,14 @@ class FlowEngine:
     # ------------------------------------------------------------------ flow.inference
     @torch.no_grad()
     def inference_time_major(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True,
-                             reference_mels=None):
+                             reference_mels=None, stream_state=None):
         """token [1,Lt], prompt_token [1,Lp] ints; prompt_feat [1,Tp,80]; embedding [1,192] (device tensors).
-        Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped)."""
+        Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped).  stream_state (a StreamState from
+        stream_open, streaming non-final calls): only the frames that state has not solved yet go through the ODE."""
         mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels)
+        if stream_state is not None and streaming and not finalize and mu.shape[0] % self.est_chunk == 0 \
+                and stream_state.T % self.est_chunk == 0 and mu.shape[0] <= stream_state.Tcap:
+            return self.cfm_stream(stream_state, mu, spks, cond)[mel_len1:]
         x = self.cfm(mu, spks, cond, streaming)
         return x[mel_len1:]
 

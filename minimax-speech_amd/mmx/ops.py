@@ -102,13 +102,14 @@ def convtranspose1d(x, Wp, *, T, Cin, Cout, stride, dtype, batch=1, bias=None, a
 
 # ----------------------------------------------------------------------------- row-wise / elementwise
 def rownorm(x, gamma, beta, eps, *, rows, C_, batch=1, x_bstride=None, rms=False, act="none", rowmask=None,
-            addvec=None, av_bstride=None, out_f32=None, out_act=None, dtype=F32, ldx=None):
+            addvec=None, av_bstride=None, out_f32=None, out_act=None, dtype=F32, ldx=None, o_bstride=None, rm_bstride=None):
     ldx = C_ if ldx is None else ldx
     xb = rows * ldx if x_bstride is None else x_bstride
+    ob = rows * C_ if o_bstride is None else o_bstride
     check(load().mmx_rownorm(_p(x), i64(ldx), i64(xb), rows, C_, batch, _p(gamma), _p(beta), C.c_float(eps), int(rms),
-                             ACT[act], _p(rowmask), i64(rows), _p(addvec), i64(C_ if av_bstride is None else av_bstride),
-                             _p(out_f32), i64(C_), i64(rows * C_), _p(out_act), i64(C_), i64(rows * C_),
-                             dtype, stream()), "mmx_rownorm")
+                             ACT[act], _p(rowmask), i64(rows if rm_bstride is None else rm_bstride), _p(addvec),
+                             i64(C_ if av_bstride is None else av_bstride), _p(out_f32), i64(C_), i64(ob), _p(out_act), i64(C_),
+                             i64(ob), dtype, stream()), "mmx_rownorm")
 
 
 def groupnorm(x, gamma, beta, out, *, B, T, C_, groups, dtype, eps=1e-5, act="none", rowmask=None):
@@ -167,20 +168,25 @@ def est_next(wqkv=None, n1g=None, n1b=None, q_out=None, ldq=0, q_bs=0, vt_out=No
                          ldq=ldq, ldvt=ldvt)
 
 
-def est_tail(ao, x, w, *, B, T, dtype, bm, rowmask=None, act_out=None, act_ld=0, nxt=None, eps=1e-5, pf=0):
-    """w: dict with packed wo_p / w1_p / w2_p and bo / b1 / b2 / n3g / n3b (mmx/flow.py)."""
+def est_tail(ao, x, w, *, B, T, dtype, bm, rowmask=None, act_out=None, act_ld=0, nxt=None, eps=1e-5, pf=0, t_begin=0,
+             Tcap=None):
+    """w: dict with packed wo_p / w1_p / w2_p and bo / b1 / b2 / n3g / n3b (mmx/flow.py).  Tcap: frames every buffer is
+    allocated for (batch stride; default T); t_begin: first frame to process (streaming hop)."""
+    Tc = T if Tcap is None else Tcap
     p = L.fill_struct(L.EstTailParams(), ao=ao, x=x, wo=w["wo_p"], w1=w["w1_p"], w2=w["w2_p"], bo=w["bo"], b1=w["b1"],
-                      b2=w["b2"], n3g=w["n3g"], n3b=w["n3b"], rowmask=rowmask, act_out=act_out, ao_bs=T * 512,
-                      x_bs=T * 256, rm_bs=T, act_bs=T * act_ld, ldao=512, act_ld=act_ld, B=B, T=T, eps=eps)
+                      b2=w["b2"], n3g=w["n3g"], n3b=w["n3b"], rowmask=rowmask, act_out=act_out, ao_bs=Tc * 512,
+                      x_bs=Tc * 256, rm_bs=Tc, act_bs=Tc * act_ld, ldao=512, act_ld=act_ld, B=B, T=T, t_begin=t_begin, eps=eps)
     if nxt is not None:
         p.next = nxt
     check(load().mmx_est_tail(C.byref(p), C.c_int(dtype), C.c_int(bm), C.c_int(pf), stream()), "mmx_est_tail")
 
 
-def est_resnet(a_in, lda, cin, x, r, tv, tv_bs, *, B, T, dtype, bm, rowmask=None, nxt=None, eps=1e-5, pf=0):
+def est_resnet(a_in, lda, cin, x, r, tv, tv_bs, *, B, T, dtype, bm, rowmask=None, nxt=None, eps=1e-5, pf=0, t_begin=0,
+               Tcap=None):
+    Tc = T if Tcap is None else Tcap
     p = L.fill_struct(L.EstResnetParams(), a_in=a_in, x=x, w1=r["w1_p"], w2=r["w2_p"], wr=r["wr_p"], b1=r["b1"], g1=r["g1"],
                       be1=r["be1"], b2=r["b2"], g2=r["g2"], be2=r["be2"], br=r["br"], tv=tv, rowmask=rowmask,
-                      a_bs=T * lda, x_bs=T * 256, tv_bs=tv_bs, rm_bs=T, lda=lda, cin=cin, B=B, T=T, eps=eps)
+                      a_bs=Tc * lda, x_bs=Tc * 256, tv_bs=tv_bs, rm_bs=Tc, lda=lda, cin=cin, B=B, T=T, t_begin=t_begin, eps=eps)
     if nxt is not None:
         p.next = nxt
     check(load().mmx_est_resnet(C.byref(p), C.c_int(dtype), C.c_int(bm), C.c_int(pf), stream()), "mmx_est_resnet")
@@ -188,18 +194,19 @@ def est_resnet(a_in, lda, cin, x, r, tv, tv_bs, *, B, T, dtype, bm, rowmask=None
 
 # ----------------------------------------------------------------------------- attention
 def attn_dense(q, k, v, out, *, B, H, Tq, Tk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, dtype,
-               keymask=None, chunk=0, pos=None, ldp=0, pos_u=None, pos_v=None, head_stride=0):
+               keymask=None, chunk=0, pos=None, ldp=0, pos_u=None, pos_v=None, head_stride=0, q_begin=0, km_bs=None):
     check(load().mmx_attn_dense(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(v), i64(ldv), i64(v_bs),
                                 _p(out), i64(ldo), i64(o_bs), B, H, 64, Tq, Tk, C.c_float(scale), _p(keymask),
-                                i64(Tk), chunk, _p(pos), i64(ldp), _p(pos_u), _p(pos_v), head_stride, dtype, stream()),
+                                i64(Tk if km_bs is None else km_bs), chunk, _p(pos), i64(ldp), _p(pos_u), _p(pos_v), head_stride,
+                                q_begin, dtype, stream()),
           "mmx_attn_dense")
 
 
 def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, keymask=None,
-                    chunk=0):
+                    chunk=0, q_begin=0, km_bs=None):
     check(load().mmx_attn_flash_bf16(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(vt), i64(ldvt),
                                      i64(vt_bs), _p(out), i64(ldo), i64(o_bs), B, H, T, C.c_float(scale),
-                                     _p(keymask), i64(T), chunk, stream()), "mmx_attn_flash_bf16")
+                                     _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, stream()), "mmx_attn_flash_bf16")
 
 
 # ----------------------------------------------------------------------------- LM decode

@@ -83,7 +83,8 @@ class TtsEngine:
         return self.token2wav(toks.reshape(1, -1), pt, pf, flow_embedding)
 
     @torch.no_grad()
-    def tts_stream(self, text, flow_embedding, seed=0, exact_steps=None, token_hop=25, latents_out=None, forced=None):
+    def tts_stream(self, text, flow_embedding, seed=0, exact_steps=None, token_hop=25, latents_out=None, forced=None,
+                   cache=True):
         """Streaming synthesis of one (long) utterance: BASELINE config 5 / cli/model.py:336-369 (`stream=True`).
         The AR decode runs ahead on its own stream (captured decode step); every `token_hop` tokens (+ the flow's
         look-ahead) the chunk-causal flow is solved over all tokens so far, as the reference does.  The DAC decoder is
@@ -93,7 +94,8 @@ class TtsEngine:
         the concatenated chunks equal the offline decode of the same latents sample for sample (this replaces the
         reference's HiFT mel / source cache and its cross-fade, cli/model.py:304-311).  Yields waveform chunks [1, n]
         (device); `latents_out` (a list) receives the latent frames [n, 80] behind each chunk; `forced` [1, steps]
-        teacher-forces the accepted ids (LlmEngine.start)."""
+        teacher-forces the accepted ids (LlmEngine.start).  cache=True: hops solve only their new frames (FlowEngine.StreamState);
+        cache=False recomputes all frames at every hop, as the reference does — the two agree (tests/test_gpu_stream.py)."""
         from .llm import ST_FIN, ST_NOUT
         assert self.llm.B == 1
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
@@ -111,6 +113,7 @@ class TtsEngine:
         with torch.cuda.stream(lm):
             self.llm.start([x], [mn], [mx], seed=seed, forced=forced)
         done, offset, emitted = 1, 0, 0                    # decode steps issued, tokens rendered, latent frames emitted
+        sstate = self.flow.stream_open(2 * mx) if cache else None
         tail = None                                        # the last ctx_left latent frames already emitted
 
         def render(n_tok, finalize):
@@ -122,7 +125,8 @@ class TtsEngine:
             # like the reference, the closing pass runs WITHOUT the chunk masks (cli/model.py:371-378 leaves `stream` at
             # its default False): its frames differ from what a streaming pass would give, so the left context of the
             # window is the emitted tail kept from the previous pass, not this pass's version of those frames
-            lat = self.flow.inference_time_major(tok, z, zf, flow_embedding, streaming=not finalize, finalize=finalize)
+            lat = self.flow.inference_time_major(tok, z, zf, flow_embedding, streaming=not finalize, finalize=finalize,
+                                                 stream_state=sstate)
             T2 = lat.shape[0]
             hi = T2 if finalize else T2 - CR               # frames whose right context is final
             if hi <= emitted:

@@ -61,6 +61,23 @@ def test_stream_chunks_equal_offline_decode_of_the_same_latents(weights, dt):
         assert d[lo:edge].max().item() < 0.5 and torch.isfinite(got).all()
 
 
+@pytest.mark.parametrize("dt,tol", [(0, 2e-5), (1, 2e-2)])
+def test_stream_cached_state_equals_recompute(weights, dt, tol):
+    """Config 5: hops that solve only their new frames from the cached K / V rows and conv inputs of earlier hops
+    (FlowEngine.StreamState) give the waveform of the reference's schedule, which re-solves every frame at every hop
+    (cli/model.py:341-352).  fp32: equal to rounding; bf16: to the rounding of bf16 activations."""
+    from mmx.pipeline import TtsEngine
+    eng = TtsEngine(*weights, dtype=dt, max_batch=1, max_ctx=512)
+    text, emb = _inputs()
+    la, lb = [], []
+    a = torch.cat([c.reshape(-1) for c in eng.tts_stream(text, emb, seed=3, exact_steps=118, latents_out=la, cache=True)])
+    b = torch.cat([c.reshape(-1) for c in eng.tts_stream(text, emb, seed=3, exact_steps=118, latents_out=lb, cache=False)])
+    dl = (torch.cat(la) - torch.cat(lb)).abs().max().item()
+    dw = (a - b).abs().max().item()
+    print(f"cached vs recomputed streaming dtype {dt}: latents max abs diff {dl:.3e}, waveform {dw:.3e}")
+    assert a.shape == b.shape and dw < tol and dl < 50 * tol, (dl, dw)
+
+
 def test_stream_tokens_equal_offline_tokens(weights):
     from mmx.pipeline import TtsEngine
     eng = TtsEngine(*weights, dtype=1, max_batch=1, max_ctx=512)
