@@ -610,7 +610,9 @@ class FlowEngine:
         def conv3(src, ld, col0, cin, wgt, bias, out_act=None, out_f32=None, ldo=None):
             """causal conv k3 over frames r0 .. T-1 of a cached [2, Tcap, ld] buffer (rows before r0 are the halo)"""
             N = wgt.shape[0]
-            ops.gemm(src[:, r0:, col0:], wgt, T - r0, N, dtype=dt, lda=ld, cin=cin, ntaps=3, row_off=-2, row_lo=-r0, row_hi=T - r0,
+            # A is addressed from frame 0 of the buffer (the kernel's buffer descriptor cannot reach below its base):
+            # output row m is frame r0 + m and reads frames r0 + m + tap - 2
+            ops.gemm(src[:, :, col0:], wgt, T - r0, N, dtype=dt, lda=ld, cin=cin, ntaps=3, row_off=r0 - 2, row_lo=0, row_hi=T,
                      batch=B, a_bstride=Tc * ld, bias=bias, out_act=(out_act[:, r0:] if out_act is not None else None), ldo_a=N,
                      oa_bstride=Tc * N, out_f32=(out_f32[:, r0:] if out_f32 is not None else None), ldo_f=N, of_bstride=Tc * N)
 
