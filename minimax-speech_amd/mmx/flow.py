@@ -325,6 +325,89 @@ class FlowEngine:
         ops.linear(hn, E["wproj"], 512, dtype=dt, bias=E["bproj"], out_f32=mu)
         return mu
 
+    # ------------------------------------------------------------------ streaming encoder with cached state
+    def _enc_stream_state(self, st):
+        """The conformer encoder is chunk-causal in streaming mode (25-token / 50-frame chunks, 3 tokens of look-ahead
+        supplied as context), so a hop only has to encode its new tokens: kept per utterance are every layer's Q|K|V
+        rows, the inputs of the three convs (look-ahead k4, causal k3, upsample k5) and the projected relative-position
+        tables (computed once for the whole capacity: row Tcap - 1 - r is relative distance r for every length)."""
+        if st.enc is None:
+            E, dt = self.enc, self.dtype
+            Tt, Tf = st.Tcap // 2 + self.L, st.Tcap          # token / frame capacity
+            z = lambda *sh, f32=False: torch.zeros(*sh, dtype=torch.float32 if f32 else self.tdt, device=self.dev)
+
+            def pos_tables(layers, T):
+                pe = espnet_rel_pe(T, 512).to(self.dev, self.tdt)
+                out = []
+                for lw in layers:
+                    p = z(2 * T - 1, 512)
+                    ops.linear(pe, lw["wpos"], 512, dtype=dt, out_act=p)
+                    out.append(p)
+                return out
+
+            st.enc = dict(T=0, xa=z(Tt, 512), x=z(Tt, 512, f32=True), h1=z(Tt, 512), up=z(Tf, 512), mu=z(Tf, 80, f32=True),
+                          qkv=[z(Tt, 1536) for _ in E["layers"]], qkv2=[z(Tf, 1536) for _ in E["up_layers"]],
+                          pos=pos_tables(E["layers"], Tt), pos2=pos_tables(E["up_layers"], Tf), Tt=Tt, Tf=Tf)
+        return st.enc
+
+    def _conformer_stream(self, lw, x, t0, T, qkv, pos_all, Tcap, chunk):
+        """One ConformerEncoderLayer on rows t0 .. T-1 (x fp32 [T - t0, 512] window, returned likewise); qkv [Tcap, 1536]
+        holds the Q|K|V rows of ALL positions, pos_all [2*Tcap - 1, 512] the projected rel-pos table of the capacity."""
+        dt, n = self.dtype, T - t0
+        hn = self._new(n, 512)
+        ops.rownorm(x, lw["n1g"], lw["n1b"], 1e-12, rows=n, C_=512, out_act=hn, dtype=dt)
+        ops.linear(hn, lw["wqkv"], 512, dtype=dt, bias=lw["bqkv"], out_act=qkv[t0:T])
+        ao = self._new(T, 512)
+        # the kernel indexes pos[T - 1 - i + j]: shift the base so that this is row Tcap - 1 - (i - j) of the full table
+        ops.attn_dense(qkv, qkv[:, 512:], qkv[:, 1024:], ao, B=1, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                       q_bs=0, k_bs=0, v_bs=0, o_bs=0, scale=0.125, dtype=dt, chunk=chunk, pos=pos_all[Tcap - T:], ldp=512,
+                       pos_u=lw["pu"], pos_v=lw["pv"], q_begin=t0)
+        x2 = self._new(n, 512, f32=True)
+        ops.linear(ao[t0:T], lw["wo"], 512, dtype=dt, bias=lw["bo"], residual=x, out_f32=x2)
+        ops.rownorm(x2, lw["n2g"], lw["n2b"], 1e-12, rows=n, C_=512, out_act=hn, dtype=dt)
+        ff = self._new(n, 2048)
+        ops.linear(hn, lw["w1"], 512, dtype=dt, bias=lw["b1"], act="silu", out_act=ff)
+        x3 = self._new(n, 512, f32=True)
+        ops.linear(ff, lw["w2"], 2048, dtype=dt, bias=lw["b2"], residual=x2, out_f32=x3)
+        return x3
+
+    def encode_stream(self, st, ids: torch.Tensor) -> torch.Tensor:
+        """Streaming, non-final encode of ids [Lt] (the last 3 are look-ahead context): only the tokens the state has
+        not encoded yet run through the layers.  Returns mu fp32 [2 * (Lt - 3), 80] for all tokens so far (a view)."""
+        dt, E, S = self.dtype, self.enc, self._enc_stream_state(st)
+        Lt = ids.numel()
+        T, tb = Lt - self.L, S["T"]
+        assert tb < T and Lt <= S["Tt"]
+        # embed the new tokens and the context rows (the previous hop's context rows are re-embedded: they are tokens now)
+        a0 = self._new(Lt - tb, 512)
+        ops.gather_rows(ids[tb:], self.emb_table, out_act=a0, dtype=dt)
+        tmp = self._new(Lt - tb, 512, f32=True)
+        ops.linear(a0, E["embed"]["w"], 512, dtype=dt, bias=E["embed"]["b"], out_f32=tmp)
+        ops.rownorm(tmp, E["embed"]["g"], E["embed"]["beta"], 1e-5, rows=Lt - tb, C_=512, out_f32=S["x"][tb:Lt], out_act=S["xa"][tb:Lt], dtype=dt)
+        # PreLookaheadLayer on rows tb .. T-1: conv k4 over [x ; context], leaky_relu, causal conv k3, + x
+        n = T - tb
+        ops.gemm(S["xa"], E["pl_w1"], n, 512, dtype=dt, lda=512, cin=512, ntaps=4, row_off=tb, row_lo=0, row_hi=Lt,
+                 bias=E["pl_b1"], act="lrelu", slope=0.01, out_act=S["h1"][tb:T], ldo_a=512)
+        x = self._new(n, 512, f32=True)
+        ops.gemm(S["h1"], E["pl_w2"], n, 512, dtype=dt, lda=512, cin=512, ntaps=3, row_off=tb - 2, row_lo=0, row_hi=T,
+                 bias=E["pl_b2"], residual=S["x"][tb:T], ldr=512, out_f32=x, ldo_f=512)
+        for lw, qkv, pos in zip(E["layers"], S["qkv"], S["pos"]):
+            x = self._conformer_stream(lw, x, tb, T, qkv, pos, S["Tt"], self.enc_chunk)
+        # Upsample1D: nearest x2, causal conv k5 (left pad 4) on frames 2tb .. 2T-1
+        f0, F = 2 * tb, 2 * T
+        ops.copy2d(x, F32, 0, 512, 1, S["up"][f0:F], dt, 0, 512, 1, rows=F - f0, cols=512, rep=2)
+        c5 = self._new(F - f0, 512)
+        ops.gemm(S["up"], E["up_w"], F - f0, 512, dtype=dt, lda=512, cin=512, ntaps=5, row_off=f0 - 4, row_lo=0, row_hi=F,
+                 bias=E["up_b"], out_act=c5, ldo_a=512)
+        x, _ = self._embed(E["up_embed"], c5, F - f0)
+        for lw, qkv, pos in zip(E["up_layers"], S["qkv2"], S["pos2"]):
+            x = self._conformer_stream(lw, x, f0, F, qkv, pos, S["Tf"], 2 * self.enc_chunk)
+        hn = self._new(F - f0, 512)
+        ops.rownorm(x, E["ang"], E["anb"], 1e-5, rows=F - f0, C_=512, out_act=hn, dtype=dt)
+        ops.linear(hn, E["wproj"], 512, dtype=dt, bias=E["bproj"], out_f32=S["mu"][f0:F])
+        S["T"] = T
+        return S["mu"][:F]
+
     # ------------------------------------------------------------------ estimator
     def _resnet(self, r, a_in, lda, B, T, tv, mask, out_x):
         """CausalResnetBlock1D; a_in: act [B,T,lda] holding x*mask; writes fp32 out_x [B,T,256]."""
@@ -540,6 +623,7 @@ class FlowEngine:
             tt, dd = eng.t_schedule()
             self.t_all = torch.tensor([[v, v] for v in tt], dtype=torch.float32, device=eng.dev)
             self.dt = dd
+            self.enc = None                                # encoder state (tokens), built by encode_stream
 
         def step_buffers(self, s):
             if self.steps[s] is None:
@@ -760,7 +844,8 @@ class FlowEngine:
         """token [1,Lt], prompt_token [1,Lp] ints; prompt_feat [1,Tp,80]; embedding [1,192] (device tensors).
         Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped).  stream_state (a StreamState from
         stream_open, streaming non-final calls): only the frames that state has not solved yet go through the ODE."""
-        mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels)
+        mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels,
+                                                   stream_state)
         if stream_state is not None and streaming and not finalize and mu.shape[0] % self.est_chunk == 0 \
                 and stream_state.T % self.est_chunk == 0 and mu.shape[0] <= stream_state.Tcap:
             return self.cfm_stream(stream_state, mu, spks, cond)[mel_len1:]
@@ -768,7 +853,8 @@ class FlowEngine:
         return x[mel_len1:]
 
     @torch.no_grad()
-    def conditions(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True, reference_mels=None):
+    def conditions(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True, reference_mels=None,
+                   stream_state=None):
         """Everything of flow.inference ahead of the ODE solve (flow.py:455-498): speaker projection, token
         embedding + conformer encoder -> mu, prompt condition.  Returns (mu [T,80], spks [1,80], cond [T,80], Tp).
         reference_mels ([1,N,80,T] or [1,80,T]) selects the learnable speaker encoder (flow.py:456-462)."""
@@ -783,7 +869,10 @@ class FlowEngine:
         spks = self._new(1, 80, f32=True)
         ops.linear(en, self.spk_w, self.spk_dim, dtype=dt, bias=self.spk_b, out_f32=spks)
         ids = torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).to(self.dev, torch.int64)
-        mu = self.encode(ids, finalize, streaming)
+        if stream_state is not None and streaming and not finalize and ids.numel() <= stream_state.Tcap // 2 + self.L:
+            mu = self.encode_stream(stream_state, ids)
+        else:
+            mu = self.encode(ids, finalize, streaming)
         T = mu.shape[0]
         mel_len1 = prompt_feat.shape[1]
         cond = torch.zeros(T, 80, device=self.dev)
