@@ -128,6 +128,7 @@ class FlowEngine:
         import copy
         c = copy.copy(self)
         c._plans, c._pe, c._vt, c.plan_bytes = OrderedDict(), OrderedDict(), {}, 0
+        c._stream_pool = {}
         return c
 
     def set_noise(self, noise: torch.Tensor):
@@ -371,12 +372,12 @@ class FlowEngine:
         ops.linear(ff, lw["w2"], 2048, dtype=dt, bias=lw["b2"], residual=x2, out_f32=x3)
         return x3
 
-    def encode_stream(self, st, ids: torch.Tensor) -> torch.Tensor:
-        """Streaming, non-final encode of ids [Lt] (the last 3 are look-ahead context): only the tokens the state has
-        not encoded yet run through the layers.  Returns mu fp32 [2 * (Lt - 3), 80] for all tokens so far (a view)."""
+    def _encode_stream_rows(self, st, ids: torch.Tensor, tb: int, Lt: int):
+        """Streaming, non-final encode of ids [Lt] (the last 3 are look-ahead context) given that tokens 0 .. tb-1 are
+        already encoded in the state: only tokens tb .. Lt-4 run through the layers; mu of their frames lands in the
+        state's mu buffer.  Pure device work on state buffers (recorded into the per-hop hipGraph)."""
         dt, E, S = self.dtype, self.enc, self._enc_stream_state(st)
-        Lt = ids.numel()
-        T, tb = Lt - self.L, S["T"]
+        T = Lt - self.L
         assert tb < T and Lt <= S["Tt"]
         # embed the new tokens and the context rows (the previous hop's context rows are re-embedded: they are tokens now)
         a0 = self._new(Lt - tb, 512)
@@ -405,8 +406,6 @@ class FlowEngine:
         hn = self._new(F - f0, 512)
         ops.rownorm(x, E["ang"], E["anb"], 1e-5, rows=F - f0, C_=512, out_act=hn, dtype=dt)
         ops.linear(hn, E["wproj"], 512, dtype=dt, bias=E["bproj"], out_f32=S["mu"][f0:F])
-        S["T"] = T
-        return S["mu"][:F]
 
     # ------------------------------------------------------------------ estimator
     def _resnet(self, r, a_in, lda, B, T, tv, mask, out_x):
@@ -623,7 +622,24 @@ class FlowEngine:
             tt, dd = eng.t_schedule()
             self.t_all = torch.tensor([[v, v] for v in tt], dtype=torch.float32, device=eng.dev)
             self.dt = dd
-            self.enc = None                                # encoder state (tokens), built by encode_stream
+            self.enc = None                                # encoder state (tokens), built on first use
+            self.tok_done = 0                              # tokens encoded and solved
+            self.z = eng.rand_noise[0, :, :self.Tcap].t().contiguous().to(eng.dev)      # [Tcap, 80] the fixed noise
+            self.spks2 = torch.zeros(2, 80, device=eng.dev)
+            self.ids = torch.zeros(self.Tcap // 2 + eng.L + 8, dtype=torch.int64, device=eng.dev)
+            self.graphs, self._win = {}, {}
+
+        def window(self, n):
+            """static per-hop windows: ODE state of the n new frames, CFG pair of mu / cond rows (row 1 stays zero)"""
+            if n not in self._win:
+                d = self.eng.dev
+                self._win[n] = dict(x=torch.zeros(1, n, 80, device=d), mu2=torch.zeros(2, n, 80, device=d),
+                                    cond2=torch.zeros(2, n, 80, device=d))
+            return self._win[n]
+
+        def reset(self):
+            """a new utterance on the same buffers and recorded hop graphs"""
+            self.T = self.tok_done = 0
 
         def step_buffers(self, s):
             if self.steps[s] is None:
@@ -637,7 +653,16 @@ class FlowEngine:
             return self.steps[s]
 
     def stream_open(self, max_frames: int) -> "FlowEngine.StreamState":
-        return FlowEngine.StreamState(self, max_frames)
+        """State for one streaming utterance of up to max_frames frames.  States are pooled per capacity: buffers and the
+        recorded per-hop graphs are reused by the next utterance (one utterance at a time per state)."""
+        cap = ops.round_up(max_frames, 64)
+        if not hasattr(self, "_stream_pool"):
+            self._stream_pool = {}
+        st = self._stream_pool.get(cap)
+        if st is None:
+            st = self._stream_pool[cap] = FlowEngine.StreamState(self, cap)
+        st.reset()
+        return st
 
     def _estimator_stream(self, st, s, x_new, mu_new, spks2, cond_new, tb, T):
         """One estimator call of Euler step s on frames tb .. T-1 of a streaming utterance (CFG pair, B = 2), reading the
@@ -714,25 +739,44 @@ class FlowEngine:
                  out_f32=st.d[:, r0:], ldo_f=80, of_bstride=Tc * 80)
         return st.d
 
-    @torch.no_grad()
-    def cfm_stream(self, st, mu, spks, cond):
-        """Solves the frames st.T .. T-1 of a streaming utterance (mu / cond fp32 [T, 80] for ALL frames so far) and returns the
-        latents of all T frames (a view of the state).  Every hop must add whole 50-frame chunks."""
-        T, tb = mu.shape[0], st.T
+    def _cfm_stream_rows(self, st, tb: int, T: int):
+        """Euler-solves frames tb .. T-1 (whole 50-frame chunks) from the state's mu / speaker rows; the latents land in
+        st.lat.  Pure device work on state buffers (recorded into the per-hop hipGraph)."""
         assert tb < T <= st.Tcap and tb % self.est_chunk == 0 and T % self.est_chunk == 0, (tb, T, st.Tcap)
         n = T - tb
-        x = self.rand_noise[0, :, tb:T].t().contiguous().to(self.dev).reshape(1, n, 80)
-        mu2, cond2 = torch.zeros(2, n, 80, device=self.dev), torch.zeros(2, n, 80, device=self.dev)
-        mu2[0].copy_(mu[tb:T])
-        cond2[0].copy_(cond[tb:T])
-        spks2 = torch.zeros(2, 80, device=self.dev)
-        spks2[0].copy_(spks.reshape(-1))
+        W = st.window(n)
+        W["x"].copy_(st.z[tb:T].reshape(1, n, 80))
+        W["mu2"][0].copy_(st.enc["mu"][tb:T])
         for s in range(self.n_timesteps):
-            d = self._estimator_stream(st, s, x, mu2, spks2, cond2, tb, T)
-            ops.cfg_euler(x, d[0, tb:T], d[1, tb:T], self.cfg, st.dt[s], n * 80)
-        st.lat[tb:T].copy_(x[0])
-        st.T = T
-        return st.lat[:T]
+            d = self._estimator_stream(st, s, W["x"], W["mu2"], st.spks2, W["cond2"], tb, T)
+            ops.cfg_euler(W["x"], d[0, tb:T], d[1, tb:T], self.cfg, st.dt[s], n * 80)
+        st.lat[tb:T].copy_(W["x"][0])
+
+    @torch.no_grad()
+    def stream_hop(self, st, ids: torch.Tensor, embedding: torch.Tensor) -> torch.Tensor:
+        """One streaming hop without prompt: ids [Lt] = all tokens so far + 3 look-ahead tokens.  Encodes and solves only
+        what the state has not seen; each (done, Lt) pair is one recorded hipGraph over the state's buffers (a hop is
+        ~1 500 short launches), reused by every later utterance that runs on this state.  Returns latents fp32 [2(Lt-3), 80]."""
+        Lt = ids.numel()
+        T, tb = Lt - self.L, st.tok_done
+        if tb == 0:                                          # speaker projection, once per utterance
+            st.spks2.zero_()
+            en = self._new(1, self.spk_dim)
+            ops.rownorm(embedding.to(self.dev, torch.float32).contiguous(), self.spk_gamma, None, 1e-30, rows=1, C_=self.spk_dim,
+                        rms=True, out_act=en, dtype=self.dtype)
+            ops.linear(en, self.spk_w, self.spk_dim, dtype=self.dtype, bias=self.spk_b, out_f32=st.spks2[0:1])
+        self._enc_stream_state(st)
+        st.ids[:Lt].copy_(ids.reshape(-1))
+        key = (tb, Lt)
+        if key not in st.graphs:
+            def hop(tb=tb, Lt=Lt, T=T):
+                self._encode_stream_rows(st, st.ids[:Lt], tb, Lt)
+                self._cfm_stream_rows(st, 2 * tb, 2 * T)
+            st.graphs[key] = Graphed(hop, self.use_graphs)
+        st.graphs[key]()
+        st.tok_done = T
+        st.T = 2 * T
+        return st.lat[:2 * T]
 
     @torch.no_grad()
     def estimator_channels_first(self, x, mask, mu, t, spks, cond, streaming=False):
@@ -844,17 +888,17 @@ class FlowEngine:
         """token [1,Lt], prompt_token [1,Lp] ints; prompt_feat [1,Tp,80]; embedding [1,192] (device tensors).
         Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped).  stream_state (a StreamState from
         stream_open, streaming non-final calls): only the frames that state has not solved yet go through the ODE."""
-        mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels,
-                                                   stream_state)
-        if stream_state is not None and streaming and not finalize and mu.shape[0] % self.est_chunk == 0 \
-                and stream_state.T % self.est_chunk == 0 and mu.shape[0] <= stream_state.Tcap:
-            return self.cfm_stream(stream_state, mu, spks, cond)[mel_len1:]
+        Lt = token.numel()
+        if (stream_state is not None and streaming and not finalize and prompt_token.numel() == 0 and prompt_feat.shape[1] == 0
+                and reference_mels is None and (2 * (Lt - self.L)) % self.est_chunk == 0 and 2 * (Lt - self.L) <= stream_state.Tcap
+                and stream_state.tok_done < Lt - self.L):
+            return self.stream_hop(stream_state, token.reshape(-1).to(self.dev, torch.int64), embedding)
+        mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels)
         x = self.cfm(mu, spks, cond, streaming)
         return x[mel_len1:]
 
     @torch.no_grad()
-    def conditions(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True, reference_mels=None,
-                   stream_state=None):
+    def conditions(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True, reference_mels=None):
         """Everything of flow.inference ahead of the ODE solve (flow.py:455-498): speaker projection, token
         embedding + conformer encoder -> mu, prompt condition.  Returns (mu [T,80], spks [1,80], cond [T,80], Tp).
         reference_mels ([1,N,80,T] or [1,80,T]) selects the learnable speaker encoder (flow.py:456-462)."""
@@ -869,10 +913,7 @@ class FlowEngine:
         spks = self._new(1, 80, f32=True)
         ops.linear(en, self.spk_w, self.spk_dim, dtype=dt, bias=self.spk_b, out_f32=spks)
         ids = torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).to(self.dev, torch.int64)
-        if stream_state is not None and streaming and not finalize and ids.numel() <= stream_state.Tcap // 2 + self.L:
-            mu = self.encode_stream(stream_state, ids)
-        else:
-            mu = self.encode(ids, finalize, streaming)
+        mu = self.encode(ids, finalize, streaming)
         T = mu.shape[0]
         mel_len1 = prompt_feat.shape[1]
         cond = torch.zeros(T, 80, device=self.dev)
