@@ -366,6 +366,195 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ flash, keys split over waves
+// Few queries against many keys (a streaming hop: ~64 new frames x up to 3 000 cached keys per (batch, head) pair): the
+// kernel above gives such a launch 32 workgroups that each walk every key tile in turn (47 tiles, 42 us per launch, 30 %
+// of the GPU time of a 60 s streaming utterance).  Here a workgroup takes ONE 16-query fragment and its 4 waves take
+// key tiles w, w+4, w+8, ... (flash decoding inside the workgroup): each wave stages its own K / V^T tiles in its own
+// LDS region (register-staged prefetch of its next tile, no workgroup barrier in the loop), keeps its own running
+// (max, sum, O^T), and the four partial results are merged once through LDS.  Same arithmetic per tile as above.
+__global__ __launch_bounds__(256) void attn_flash_splitk_kernel(
+    const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
+    const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
+    int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
+    int q_begin) {
+    constexpr int D = 64, KT = 64, LDK = 80, LD = 72;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    bf16_t* Kw = reinterpret_cast<bf16_t*>(smem_raw) + wave * (2 * KT * LDK + 16 * LD);   // this wave's K tile
+    bf16_t* Vw = Kw + KT * LDK;                                                         // ... V^T tile
+    bf16_t* Pw = Vw + D * LDK;                                                          // ... P patch
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / nq) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int qt = slot % nq;
+    const int b = pair / nheads, h = pair % nheads;
+    const int qb = q_begin + qt * 16;                  // the workgroup's 16 queries
+    q += (long)b * q_bs + h * D;
+    k += (long)b * k_bs + h * D;
+    vt += (long)b * vt_bs + (long)h * D * ldvt;
+    out += (long)b * o_bs + h * D;
+    const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
+    const float sc2 = scale * 1.44269504088896341f;
+
+    short8_t aq[2];
+    {
+        int row = qb + l16;
+        row = row < Tn ? row : Tn - 1;
+        const bf16_t* qp = q + (long)row * ldq + 8 * g;
+        aq[0] = *reinterpret_cast<const short8_t*>(qp);
+        aq[1] = *reinterpret_cast<const short8_t*>(qp + 32);
+    }
+    float4_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    int lim = Tn;
+    {
+        const int i = qb + l16;
+        if (chunk > 0) { int c2 = (i / chunk + 1) * chunk; lim = c2 < lim ? c2 : lim; }
+    }
+    int kend = Tn;
+    if (chunk > 0) {
+        int qlast = qb + 15;
+        if (qlast > Tn - 1) qlast = Tn - 1;
+        int e = (qlast / chunk + 1) * chunk;
+        if (e < kend) kend = e;
+    }
+    const int ntile = (kend + KT - 1) / KT;
+
+    uint4 kreg[8], vreg[8];
+    auto load_tiles = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = lane + i * 64;              // 512 chunks of 16 B per tile, all on this wave
+            const int r = id >> 3, c = (id & 7) * 8;
+            const int key = j0 + r;
+            kreg[i] = key < Tn ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
+            vreg[i] = (j0 + c < Tn) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = lane + i * 64;
+            const int r = id >> 3, c = (id & 7) * 8;
+            *reinterpret_cast<uint4*>(Kw + r * LDK + c) = kreg[i];
+            *reinterpret_cast<uint4*>(Vw + r * LDK + c) = vreg[i];
+        }
+    };
+    if (wave < ntile) load_tiles(wave * KT);
+    for (int jt = wave; jt < ntile; jt += 4) {
+        const int j0 = jt * KT;
+        __builtin_amdgcn_wave_barrier();               // every lane is done reading the previous tile
+        store_tiles();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (jt + 4 < ntile) load_tiles(j0 + 4 * KT);
+        float4_t s[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            s[nf] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const short8_t bk = *reinterpret_cast<const short8_t*>(Kw + (nf * 16 + l16) * LDK + ks * 32 + 8 * g);
+                s[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, aq[ks], s[nf], 0, 0, 0);
+            }
+        }
+        const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = s[nf][r];
+                if (need_mask) {
+                    const int j = j0 + nf * 16 + 4 * g + r;
+                    const bool vis = j < lim && j < Tn && (!km || km[j] != 0.f);
+                    x = vis ? x : -INFINITY;
+                    s[nf][r] = x;
+                }
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx *= sc2;
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+        l_run *= alpha;
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[df][r] *= alpha;
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][0], sc2, -m_safe));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][1], sc2, -m_safe));
+            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][2], sc2, -m_safe));
+            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][3], sc2, -m_safe));
+            rs += (p0 + p1) + (p2 + p3);
+            uint2 pk;
+            pk.x = pack_bf16x2(p0, p1);
+            pk.y = pack_bf16x2(p2, p3);
+            *reinterpret_cast<uint2*>(Pw + l16 * LD + nf * 16 + 4 * g) = pk;
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run += rs;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const short8_t ap0 = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 8 * g);
+        const short8_t ap1 = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 32 + 8 * g);
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const short8_t bv0 = *reinterpret_cast<const short8_t*>(Vw + (df * 16 + l16) * LDK + 8 * g);
+            const short8_t bv1 = *reinterpret_cast<const short8_t*>(Vw + (df * 16 + l16) * LDK + 32 + 8 * g);
+            o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv0, ap0, o[df], 0, 0, 0);
+            o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv1, ap1, o[df], 0, 0, 0);
+        }
+    }
+    // ---- merge the four waves' partial results: part[w][q][d] fp32, (m, l) per (w, q)
+    __syncthreads();                                   // every wave is done with its tiles: the region is reused
+    float* part = reinterpret_cast<float*>(smem_raw);  // [4][16][64 + 1]
+    float* pm = part + 4 * 16 * 65;                    // [4][16]
+    float* pl = pm + 64;                               // [4][16]
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(wave * 16 + l16) * 65 + df * 16 + 4 * g + r] = o[df][r];
+    if (g == 0) { pm[wave * 16 + l16] = m_run; pl[wave * 16 + l16] = l_run; }
+    __syncthreads();
+    {
+        // thread -> (query qi = tid >> 4, 4 channels d0 = (tid & 15) * 4)
+        const int qi = tid >> 4, d0 = (tid & 15) * 4;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, pm[w * 16 + qi]);
+        float L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = pm[w * 16 + qi];
+            const float wgt = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
+            L += pl[w * 16 + qi] * wgt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += part[(w * 16 + qi) * 65 + d0 + e] * wgt;
+        }
+        const int i = qb + qi;
+        if (i < Tn) {
+            const float inv = L > 0.f ? 1.f / L : 0.f;
+            uint2 pk;
+            pk.x = pack_bf16x2(acc[0] * inv, acc[1] * inv);
+            pk.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
+            *reinterpret_cast<uint2*>(out + (long)i * ldo + d0) = pk;
+        }
+    }
+}
+
 extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                                    const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                                    int B, int H, int T_, float scale, const float* keymask, int64_t km_bs, int chunk,
@@ -377,6 +566,18 @@ extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, con
     MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0);
     const int npairs = H * B;
     const int Tq = T_ - q_begin;
+    if ((long)npairs * ((Tq + 63) / 64) < 96 && T_ >= 512) {            // few queries, many keys: split the keys over waves
+        const int nq16 = (Tq + 15) / 16;
+        const size_t lds = 4 * (2 * 64 * 80 + 16 * 72) * sizeof(bf16_t);   // >= the merge buffers (4*16*65 + 128 floats)
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_splitk_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_ != hipSuccess) return -(int)attr_ - 1000;
+        hipLaunchKernelGGL(attn_flash_splitk_kernel, dim3(8 * ((npairs + 7) / 8) * nq16), dim3(256), lds, stream, (const bf16_t*)q, ldq,
+                           q_bs, (const bf16_t*)k, ldk, k_bs, (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask,
+                           km_bs, chunk, nq16, H, npairs, q_begin);
+        MMX_LAUNCH_CHECK();
+        return MMX_OK;
+    }
     const bool small = (long)npairs * ((Tq + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
