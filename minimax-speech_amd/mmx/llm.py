@@ -23,10 +23,34 @@ from .flow import Graphed
 ST_POS, ST_STEP, ST_NOUT, ST_FIN, ST_MINLEN, ST_MAXLEN, ST_SEQ, ST_ERR = range(8)
 
 
+class PageAllocator:
+    """Free list of physical KV pages (the vLLM seam of the reference, cli/model.py:274-283 / llm.py:715-743, keeps its KV
+    cache in such pages).  A sequence holds pages for the rows it has written plus a look-ahead; pages return to the list
+    when it finishes, and a queued request is admitted into the freed slot (LlmEngine.admit)."""
+
+    def __init__(self, n_pages: int):
+        self.free_pages = list(range(n_pages - 1, -1, -1))
+        self.n_pages = n_pages
+
+    @property
+    def n_free(self) -> int:
+        return len(self.free_pages)
+
+    def alloc(self, n: int) -> List[int]:
+        if n > len(self.free_pages):
+            raise RuntimeError(f"KV cache exhausted: {n} pages wanted, {len(self.free_pages)} free of {self.n_pages}")
+        out = self.free_pages[-n:][::-1]
+        del self.free_pages[-n:]
+        return out
+
+    def free(self, pages: List[int]):
+        self.free_pages.extend(reversed(pages))
+
+
 class LlmEngine:
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
-                 prefix="llm.model.model", share_from=None):
+                 prefix="llm.model.model", share_from=None, kv_pages=None):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.Hq, self.Hkv, self.D, self.eps = heads, kv_heads, head_dim, eps
         self.page, self.use_graphs = page, use_graphs
@@ -38,10 +62,11 @@ class LlmEngine:
             # (used to continue a partly finished batch at a smaller, cheaper batch size: see compact_from)
             o = share_from
             for k in ("n_layers", "H", "I", "layers", "wdec", "bdec", "embed_tokens", "speech_emb", "llm_emb", "inv_freq",
-                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page", "pf_layers", "norm_w"):
+                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page", "pf_layers", "norm_w", "pages"):
                 setattr(self, k, getattr(o, k))
             self.B = max_batch
-            self.block_table = torch.zeros(self.B, self.max_pages, dtype=torch.int32, device=self.dev)
+            self.block_table = torch.full((self.B, self.max_pages), self.trash_page, dtype=torch.int32, device=self.dev)
+            self.slot_pages = [[] for _ in range(self.B)]
             self._alloc_state()
             return
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
@@ -86,13 +111,16 @@ class LlmEngine:
         max_ctx = self.max_pages * page
         ang = torch.arange(max_ctx, dtype=torch.float32)[:, None] * self.inv_freq.cpu()[None, :]
         self.rope_tab = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous().to(self.dev)
-        # paged KV cache: [layers][pages][Hkv][page][D]; sequence b owns table row b (static allocation for now)
+        # paged KV cache: [layers][pages][Hkv][page][D]; pages are handed out by a free-list allocator, a slot's block
+        # table row lists the pages of the sequence it currently runs (idle slots point at the scratch page)
         self.B = max_batch
-        npages = self.B * self.max_pages
-        self.trash_page = npages                  # scratch page for unused slots of a compacted batch
+        npages = self.B * self.max_pages if kv_pages is None else int(kv_pages)
+        self.trash_page = npages                  # scratch page: idle slots append their (ignored) KV here
         self.kc = torch.zeros(self.n_layers, npages + 1, kv_heads, page, head_dim, dtype=self.tdt, device=self.dev)
         self.vc = torch.zeros_like(self.kc)
-        self.block_table = torch.arange(npages, dtype=torch.int32, device=self.dev).reshape(self.B, self.max_pages).contiguous()
+        self.pages = PageAllocator(npages)
+        self.block_table = torch.full((self.B, self.max_pages), self.trash_page, dtype=torch.int32, device=self.dev)
+        self.slot_pages = [[] for _ in range(self.B)]
         self.max_out = max_ctx
         self._alloc_state()
 
@@ -114,6 +142,7 @@ class LlmEngine:
         self.seed = 0
         self.top_p, self.top_k, self.win_size, self.tau_r = 0.8, 25, 10, 0.1     # config.yaml:46-50
         self._decode = None
+        self.reserve_ahead = 1 << 30               # start(): rows reserved past the prompt (default: the whole max_len)
 
     # ------------------------------------------------------------------ one transformer pass over `rows` tokens/seq
     def _layers(self, h, ha, B, rows, pos, block_table, packed=False):
@@ -196,6 +225,50 @@ class LlmEngine:
         ops.linear(en, sd_linear_w, d, dtype=self.dtype, bias=sd_linear_b, out_f32=out)
         return out
 
+    # ------------------------------------------------------------------ KV pages
+    def _set_pages(self, slot: int, rows: int):
+        """Makes sure slot `slot` owns pages for `rows` cache rows (allocating what is missing)."""
+        need = min((rows + self.page - 1) // self.page, self.max_pages)
+        have = self.slot_pages[slot]
+        if need > len(have):
+            new = self.pages.alloc(need - len(have))
+            self.block_table[slot, len(have):need] = torch.tensor(new, dtype=torch.int32)
+            have.extend(new)
+
+    def release(self, slot: int):
+        """Returns the slot's pages to the free list; the slot idles on the scratch page until the next admit."""
+        if self.slot_pages[slot]:
+            self.pages.free(self.slot_pages[slot])
+            self.slot_pages[slot] = []
+            self.block_table[slot].fill_(self.trash_page)
+
+    def ensure_capacity(self, ahead: int, pos: Optional[List[int]] = None, active: Optional[List[int]] = None):
+        """Called by the host loop between decode steps: every active slot must own pages for the next `ahead` rows
+        (the loop polls every few steps, so it allocates that far ahead; a full page list raises)."""
+        pos = self.state[ST_POS].tolist() if pos is None else pos
+        for s_ in (range(self.B) if active is None else active):
+            if self.slot_pages[s_]:
+                self._set_pages(s_, pos[s_] + 1 + ahead)
+
+    @torch.no_grad()
+    def admit(self, slot: int, x: torch.Tensor, min_len: int, max_len: int, seq_id: int, ahead: int = 32):
+        """Continuous batching: puts a new request into an idle slot while the other slots keep decoding.  All prompt
+        rows but the last are prefetched into freshly allocated pages; the last row becomes the slot's next input, so the
+        next ordinary decode step of the batch computes its logits and draws its first token (same Philox key (seed,
+        seq id, step 0) as a fixed-batch start) — no separate sampling pass, nothing of the other sequences is touched."""
+        L = x.shape[0]
+        if L + max_len > self.max_pages * self.page:
+            raise RuntimeError("sequence exceeds the KV cache")
+        self.release(slot)
+        self._set_pages(slot, L + ahead)
+        x = x.to(self.dev, torch.float32).contiguous()
+        for c0 in range(0, L - 1, 64):
+            self._prefill_chunk(x[c0:min(L - 1, c0 + 64)], c0, slot)
+        self.x_in[slot].copy_(x[L - 1])
+        st = torch.tensor([L - 1, 0, 0, 0, min_len, max_len, seq_id, 0], dtype=torch.int32)
+        self.state[:, slot].copy_(st)
+        self.sampled[slot].fill_(-1)
+
     def start(self, lm_inputs: List[torch.Tensor], min_lens: List[int], max_lens: List[int], seed=0, seq_ids=None,
               forced: Optional[torch.Tensor] = None, want_logp=False):
         """Prefills every sequence (prompt rows in chunks of <= 64 through the same kernels as decode) and samples
@@ -218,6 +291,8 @@ class LlmEngine:
         self.sampled.fill_(-1)
         for b, x in enumerate(lm_inputs):
             assert x.shape[0] + max_lens[b] <= self.max_pages * self.page, "sequence exceeds the KV cache"
+            self.release(b)
+            self._set_pages(b, x.shape[0] + min(max_lens[b], self.reserve_ahead))
         if B >= 4 and self.pf_layers:
             self._prefill_batch(lm_inputs)
             lm_inputs = []
@@ -313,6 +388,9 @@ class LlmEngine:
         if pos0 + n > self.max_pages * self.page:
             raise RuntimeError("sequence exceeds the KV cache")
         x = x.to(self.dev, torch.float32).contiguous()
+        if pos0 == 0:
+            self.release(0)
+        self._set_pages(0, pos0 + n)
         out = torch.empty(n, self.H, device=self.dev)
         for c0 in range(0, n, 64):
             c1 = min(n, c0 + 64)
@@ -349,12 +427,53 @@ class LlmEngine:
         done = 1                                          # start() already sampled step 0
         while done < max_steps:
             n = min(poll_every, max_steps - done)
+            if self.reserve_ahead < (1 << 30):
+                self.ensure_capacity(n + 1)
             for _ in range(n):
                 self._decode()
             done += n
             if bool(self.state[ST_FIN].all().item()):
                 break
         return self.tokens()
+
+    @torch.no_grad()
+    def run_queue(self, requests, seed=0, poll_every: int = 8, ahead: int = 32):
+        """Continuous batching over a queue of requests [(lm_input [L, H], min_len, max_len)]: up to B run at a time; when
+        a sequence finishes its pages go back to the allocator and the next queued request is admitted into its slot
+        between two decode steps.  Returns the accepted tokens per request (seq id = request index, so the result equals
+        running every request alone under the same seed)."""
+        self.seed, self.want_logp, self.forced = int(seed), False, None
+        key = (True, False, self.seed)
+        if self._decode is None or getattr(self, "_graph_key", None) != key:
+            self._decode = Graphed(self._decode_step, self.use_graphs)
+        self._graph_key = key
+        st = torch.zeros(8, self.B, dtype=torch.int32)
+        st[ST_FIN] = 1
+        self.state.copy_(st)
+        for s_ in range(self.B):
+            self.release(s_)
+        out: List[Optional[List[int]]] = [None] * len(requests)
+        owner = [-1] * self.B
+        nxt = 0
+        while True:
+            fin = self.state[ST_FIN].tolist()
+            nout = self.state[ST_NOUT].tolist()
+            for s_ in range(self.B):
+                if owner[s_] >= 0 and fin[s_]:
+                    out[owner[s_]] = self.out_tokens[s_, :nout[s_]].tolist()
+                    owner[s_] = -1
+                    self.release(s_)
+                if owner[s_] < 0 and nxt < len(requests):
+                    x, mn, mx = requests[nxt]
+                    self.admit(s_, x, mn, mx, seq_id=nxt, ahead=ahead + poll_every)
+                    owner[s_] = nxt
+                    nxt += 1
+            active = [s_ for s_ in range(self.B) if owner[s_] >= 0]
+            if not active:
+                return out
+            self.ensure_capacity(ahead + poll_every, active=active)
+            for _ in range(poll_every):
+                self._decode()
 
     # ------------------------------------------------------------------ host-driven stream (bistream decode, llm.py:762-870)
     def open_stream(self, seed=0, seq_id=0, want_logp=False):
@@ -363,6 +482,8 @@ class LlmEngine:
         the sampler stays on the device.  The loop state (fields of include/mmx_hip.h) is mirrored on the host and
         uploaded before each pass."""
         assert self.B == 1, "bistream decode is single-sequence (cli/model.py:105-112)"
+        self.release(0)
+        self._set_pages(0, self.max_pages * self.page)        # the text arrives incrementally: reserve the whole context
         self.seed, self.want_logp, self.forced = int(seed), bool(want_logp), None
         self._st = dict(rows=0, calls=0, hist=0, seq=int(seq_id), last=None)
         self.sampled.fill_(-1)

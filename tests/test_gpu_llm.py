@@ -194,3 +194,25 @@ def test_batched_prefill_matches_per_sequence_prefill(dt, tol):
     assert err < tol, err
     if dt == 0:
         assert outs[0][1] == outs[1][1]
+
+
+def test_continuous_batching_equals_per_request_decode(llm_sd):
+    """§8e "continuous batching": 9 requests through a 4-slot engine whose KV pool holds fewer pages than 9 sequences need
+    at once — finished sequences return their pages to the allocator and queued requests are admitted into the freed
+    slots between decode steps.  Every request's tokens equal its stand-alone decode (same seed and sequence id)."""
+    from mmx.llm import LlmEngine
+    g = torch.Generator().manual_seed(21)
+    z = torch.zeros(1, 0, dtype=torch.long).cuda()
+    lens = [9, 31, 14, 40, 7, 22, 35, 12, 18]
+    texts = [torch.randint(0, 151936, (1, 4 + i % 5), generator=g).cuda() for i in range(len(lens))]
+    e1 = LlmEngine(llm_sd, dtype=1, max_batch=1, max_ctx=128)
+    want = []
+    for i, (t, n) in enumerate(zip(texts, lens)):
+        e1.start([e1.build_lm_input(t, z, z)], [n], [n], seed=6, seq_ids=[i])
+        want.append(e1.run(n)[0])
+    eng = LlmEngine(llm_sd, dtype=1, max_batch=4, max_ctx=128, kv_pages=14)      # 14 pages of 16 rows: < 9 x 4 pages
+    reqs = [(eng.build_lm_input(t, z, z), n, n) for t, n in zip(texts, lens)]
+    for rep in range(2):                                                         # second pass: recorded graphs, reused pages
+        got = eng.run_queue(reqs, seed=6, poll_every=4, ahead=8)
+        assert got == want, rep
+        assert eng.pages.n_free == 14 and all(not p for p in eng.slot_pages)
