@@ -196,21 +196,34 @@ def test_batched_prefill_matches_per_sequence_prefill(dt, tol):
         assert outs[0][1] == outs[1][1]
 
 
-def test_continuous_batching_equals_per_request_decode(llm_sd):
+@pytest.mark.parametrize("dt", [0, 1])
+def test_continuous_batching_equals_per_request_decode(llm_sd, dt):
     """§8e "continuous batching": 9 requests through a 4-slot engine whose KV pool holds fewer pages than 9 sequences need
     at once — finished sequences return their pages to the allocator and queued requests are admitted into the freed
-    slots between decode steps.  Every request's tokens equal its stand-alone decode (same seed and sequence id)."""
+    slots between decode steps.  Every request's tokens equal its decode in a fixed batch under the same seed and
+    sequence id: fp32 against the stand-alone single-sequence decode, bf16 against fixed batches on the same 4-slot
+    engine (the 4-slot step keeps its activations in MFMA-fragment order, whose RMSNorm sum of squares runs on the bf16
+    copy: not bit-identical to the single-sequence kernels, so ids are compared like with like)."""
     from mmx.llm import LlmEngine
     g = torch.Generator().manual_seed(21)
     z = torch.zeros(1, 0, dtype=torch.long).cuda()
     lens = [9, 31, 14, 40, 7, 22, 35, 12, 18]
     texts = [torch.randint(0, 151936, (1, 4 + i % 5), generator=g).cuda() for i in range(len(lens))]
-    e1 = LlmEngine(llm_sd, dtype=1, max_batch=1, max_ctx=128)
     want = []
-    for i, (t, n) in enumerate(zip(texts, lens)):
-        e1.start([e1.build_lm_input(t, z, z)], [n], [n], seed=6, seq_ids=[i])
-        want.append(e1.run(n)[0])
-    eng = LlmEngine(llm_sd, dtype=1, max_batch=4, max_ctx=128, kv_pages=14)      # 14 pages of 16 rows: < 9 x 4 pages
+    if dt == 0:
+        e1 = LlmEngine(llm_sd, dtype=0, max_batch=1, max_ctx=128)
+        for i, (t, n) in enumerate(zip(texts, lens)):
+            e1.start([e1.build_lm_input(t, z, z)], [n], [n], seed=6, seq_ids=[i])
+            want.append(e1.run(n)[0])
+    else:
+        e4 = LlmEngine(llm_sd, dtype=1, max_batch=4, max_ctx=128)
+        idx = list(range(len(lens))) + [0, 1, 2]                                # pad the last group to 4
+        for g0 in range(0, 12, 4):
+            grp = idx[g0:g0 + 4]
+            e4.start([e4.build_lm_input(texts[i], z, z) for i in grp], [lens[i] for i in grp], [lens[i] for i in grp], seed=6, seq_ids=grp)
+            toks = e4.run(max(lens[i] for i in grp))
+            want.extend(toks if g0 < 8 else toks[:1])
+    eng = LlmEngine(llm_sd, dtype=dt, max_batch=4, max_ctx=128, kv_pages=14)     # 14 pages of 16 rows: < 9 x 4 pages
     reqs = [(eng.build_lm_input(t, z, z), n, n) for t, n in zip(texts, lens)]
     for rep in range(2):                                                         # second pass: recorded graphs, reused pages
         got = eng.run_queue(reqs, seed=6, poll_every=4, ahead=8)
