@@ -231,7 +231,8 @@ class TtsEngine:
         import threading
         from .llm import ST_FIN, ST_NOUT
         B = len(texts)
-        assert B == self.llm.B
+        NS = self.llm.B                                   # decode slots; more utterances than slots queue up and are admitted
+        assert B >= NS and (overlap or B == NS)           # into slots as they free (continuous batching, LlmEngine.admit)
         if exact_steps is not None and not isinstance(exact_steps, (list, tuple)):
             exact_steps = [exact_steps] * B
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
@@ -299,7 +300,8 @@ class TtsEngine:
         free_at = [0.0] * flow_workers
         STEP_MS, GROUP_MS, FRAME_MS = 1.45, 45.0, 0.037
 
-        cur = [self.llm, list(range(B))]                            # active engine, slot -> utterance index
+        cur = [self.llm, list(range(NS))]                           # active engine, slot -> utterance index
+        queue = list(range(NS, B))                                  # utterances waiting for a slot
 
         def harvest(final):
             eng, slots = cur
@@ -313,7 +315,15 @@ class TtsEngine:
                 toks[b] = eng.out_tokens[s_, :n[s_]].to(torch.int64)
                 pending.append(b)
                 arrived[b] = steps_done[0]
-            if (not final and self.llm_small is not None and eng is self.llm and B - len(seen) <= self.llm_small.B
+            while queue and not final:                              # a freed slot takes the next queued utterance
+                free = [s_ for s_ in range(len(slots)) if fin[s_] and slots[s_] in seen and slots[s_] >= 0]
+                if not free:
+                    break
+                s_, b = free[0], queue.pop(0)
+                eng.admit(s_, xs[b], mins[b], maxs[b], seq_id=b)
+                slots[s_] = b
+                fin[s_] = 0
+            if (not final and not queue and self.llm_small is not None and eng is self.llm and B - len(seen) <= self.llm_small.B
                     and B - len(seen) > 0):
                 act = [s_ for s_ in range(len(slots)) if slots[s_] not in seen]
                 self.llm_small.compact_from(self.llm, act)
@@ -353,8 +363,8 @@ class TtsEngine:
                     pending.remove(b)
 
         with torch.cuda.stream(main):
-            self.llm.start(xs, mins, maxs, seed=seed)          # (captures serialise themselves: mmx/flow.py, Graphed)
-            done, max_steps = 1, max(maxs)
+            self.llm.start(xs[:NS], mins[:NS], maxs[:NS], seed=seed)   # (captures serialise themselves: mmx/flow.py, Graphed)
+            done, max_steps = 1, (max(maxs) if B == NS else sum(maxs))      # with a queue the loop ends when all are seen
             while done < max_steps:
                 k = min(poll_every, max_steps - done)
                 for _ in range(k):

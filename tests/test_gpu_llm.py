@@ -227,3 +227,25 @@ def test_continuous_batching_equals_per_request_decode(llm_sd, dt):
         got = eng.run_queue(reqs, seed=6, poll_every=4, ahead=8)
         assert got == want, rep
         assert eng.pages.n_free == 14 and all(not p for p in eng.slot_pages)
+
+
+def test_tts_batch_with_more_utterances_than_slots():
+    """tts_batch on a 3-slot engine with 7 utterances (the rest queue and are admitted as slots free) returns the
+    waveforms of the 7-slot run (fp32 build, reduced-depth models): same ids, same audio."""
+    from mmx import shapes, synth
+    from mmx.pipeline import TtsEngine
+    llm_sd = synth.synth_state_dict(shapes.llm_manifest(layers=2, vocab=4096), 0)
+    flow_sd = synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0)
+    dac_sd = synth.synth_state_dict(shapes.dac_decoder_manifest(80), 0)
+    g = torch.Generator().manual_seed(2)
+    texts = [torch.randint(0, 4096, (1, 8), generator=g).cuda() for _ in range(7)]
+    emb = [torch.randn(1, 192, generator=g).cuda() for _ in range(7)]
+    lens = [12, 30, 9, 21, 16, 27, 10]
+    e7 = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=7, max_ctx=128)
+    ref = [w.clone() for w in e7.tts_batch(texts, emb, seed=3, exact_steps=lens, group_size=2)]
+    e3 = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=3, max_ctx=128)
+    for rep in range(2):
+        got = e3.tts_batch(texts, emb, seed=3, exact_steps=lens, group_size=2, poll_every=4)
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4, (rep, a.shape, b.shape)
