@@ -250,6 +250,7 @@ class TtsEngine:
             order = sorted(range(B), key=lambda b: (n[b], b))
             for grp in self._groups(order, [2 * v for v in n], group_size, max_pad_ratio, frame_quantum):
                 self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum)
+            self.last_tokens = toks
             return wavs
 
         if not hasattr(self, "_sides") or len(self._sides) != flow_workers:
@@ -396,4 +397,5 @@ class TtsEngine:
         for sd in self._sides:
             caller.wait_stream(sd)
         caller.wait_stream(main)
+        self.last_tokens = toks                          # accepted ids per utterance (device int64 tensors)
         return wavs

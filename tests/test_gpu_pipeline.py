@@ -114,3 +114,42 @@ def test_drop_in_modules_compose_like_the_engine(case):
     err = (wav - case["wav"][0]).abs().max().item()
     print(f"drop-in composed (fp32): waveform max abs err {err:.3e}")
     assert wav.shape[1] == case["wav"].shape[2] and err <= WAV_TOL_F32, err
+
+
+def test_config4_rank_share_full_size(case):
+    """BASELINE config 4, one rank's share at full size: 32 utterances, lengths U{50..500} tokens (seed 3), 24-layer LM.
+    (a) bf16: the overlapped schedule (decode loop + flow / DAC workers on other streams, compaction to the 16-slot engine)
+    produces the token ids of the back-to-back schedule, utterance by utterance;
+    (b) fp32: the two shortest utterances out of the overlapped 32-batch equal the CPU oracle's composed path — ids
+    identical, waveform within 1e-3 (sequence id = position in the batch keys the Philox stream on both sides)."""
+    from mmx.pipeline import TtsEngine
+    from oracle import dac as ODAC, flow as OFLOW, llm as OLLM
+    lens = torch.randint(50, 501, (32,), generator=torch.Generator().manual_seed(3)).tolist()
+    g = torch.Generator().manual_seed(2)
+    texts = [torch.randint(0, 151936, (1, 48), generator=g) for _ in range(32)]
+    emb = case["emb"].cuda()
+    tc = [t.cuda() for t in texts]
+    eng = TtsEngine(case["llm_sd"], case["flow_sd"], case["dac_sd"], dtype=1, max_batch=32, max_ctx=640)
+    ref = [w.clone() for w in eng.tts_batch(tc, [emb] * 32, seed=0, exact_steps=lens, overlap=False)]
+    want = [t.tolist() for t in eng.last_tokens]
+    for rep in range(2):
+        wavs = eng.tts_batch(tc, [emb] * 32, seed=0, exact_steps=lens, overlap=True)
+        torch.cuda.synchronize()
+        assert [t.tolist() for t in eng.last_tokens] == want, rep
+        for b in range(32):                                  # same ids; other flow groups -> bf16 rounding only
+            assert wavs[b].shape == ref[b].shape and wavs[b].shape[-1] == 2 * len(want[b]) * 480
+            assert (wavs[b] - ref[b]).abs().max().item() < 3e-2, (rep, b)
+    del eng
+    torch.cuda.empty_cache()
+    ef = TtsEngine(case["llm_sd"], case["flow_sd"], case["dac_sd"], dtype=0, max_batch=32, max_ctx=640)
+    wf = ef.tts_batch(tc, [emb] * 32, seed=0, exact_steps=lens, overlap=True)
+    torch.cuda.synchronize()
+    z = torch.zeros(1, 0, dtype=torch.long)
+    for b in sorted(range(32), key=lambda i: lens[i])[:2]:
+        with torch.no_grad():
+            toks = OLLM.lm_inference(case["llm_sd"], OLLM.QwenCfg(), texts[b], z, z, seed=0, seq=b, max_steps=lens[b], ignore_eos_always=True)
+            lat = OFLOW.flow_inference(case["flow_sd"], torch.tensor(toks).reshape(1, -1), z, torch.zeros(1, 0, 80), case["emb"])
+            wav = ODAC.decode(case["dac_sd"], lat, [5, 4, 4, 3, 2])
+        err = (wf[b].cpu() - wav).abs().max().item()
+        print(f"config-4 share, utterance {b} ({lens[b]} steps, {len(toks)} ids): fp32 waveform max abs err {err:.3e}")
+        assert wf[b].shape == wav.shape and err <= WAV_TOL_F32, (b, err)
