@@ -204,11 +204,14 @@ def _time_steps(fn, build, warmup, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+ATTN = "bf16"
+
+
 def make_engine(dt, device, max_batch, max_ctx):
     """The engine under test (full-size synthetic weights).  A function of its own so that the 2-rank CPU rehearsal of
     this script's launch / shard / barrier / gather contract can substitute a stub (tests/test_cpu_host.py)."""
     from mmx.pipeline import TtsEngine
-    return TtsEngine(*build_weights(0), dtype=dt, device=device, max_batch=max_batch, max_ctx=max_ctx)
+    return TtsEngine(*build_weights(0), dtype=dt, device=device, max_batch=max_batch, max_ctx=max_ctx, attn=ATTN)
 
 
 def main():
@@ -218,6 +221,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"], help="fp8: estimator attention on the fp8 MFMA (config 5)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-utterance and fp32-build extra measurements")
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
@@ -228,6 +232,8 @@ def main():
     ap.add_argument("--hold-steps", type=int, default=40, help="decode steps a finished utterance waits for a fuller flow group")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
+    global ATTN
+    ATTN = a.attn
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -337,7 +343,7 @@ def main():
         out = {"metric": "24 kHz audio-seconds generated per wall-second per node (CosyVoice2-0.5B-shaped LM + flow + DAC-VAE, end to end)",
                "value": round(audio_s / el, 3), "unit": "audio_s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": a.dtype, "data": "synthetic text ids, random-init weights (deterministic synth init)",
+               "dtype": a.dtype + ("+fp8 attention" if a.attn == "fp8" else ""), "data": "synthetic text ids, random-init weights (deterministic synth init)",
                "rtf": round(el / audio_s * world, 5),
                "config": {"workload": wl, "utterances_per_gpu": PER_GPU, "audio_s_per_step": round(audio_s / a.steps, 2),
                           "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}

@@ -141,7 +141,27 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
 // v_mfma_f32_16x16x32_bf16; online softmax in registers (exp2 with log2e folded into the scale), row reductions
 // over the 16 lanes that share a query row via 4 xor-shuffles; P goes through a per-wave LDS patch (wave-local
 // ordering only) to turn the C-layout tile into the A-operand layout.
-template <int MF>
+// FP8 (BASELINE config 5 "fp8 MFMA attention"): Q, K and V^T are quantised to OCP e4m3 and P to e5m2 on the fly (bf16 in
+// HBM either way) and both products run on v_mfma_f32_16x16x32_{fp8_fp8, fp8_bf8}: half the LDS bytes per tile and per
+// fragment read.  On gfx950 the non-scaled fp8 MFMA has the bf16 rate and a 64-wide head cannot fill the K = 128 of the
+// block-scaled form, so the gain is LDS traffic, not matrix throughput; the price is 3-bit (K, V, Q) / 2-bit (P) mantissas.
+__device__ __forceinline__ unsigned pk_fp8x4(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+__device__ __forceinline__ unsigned pk_bf8x4(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(c, d, r, true);
+}
+__device__ __forceinline__ uint2 bf16x8_to_fp8(uint4 v) {      // 8 bf16 -> 8 e4m3 bytes
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    return make_uint2(pk_fp8x4(f[0], f[1], f[2], f[3]), pk_fp8x4(f[4], f[5], f[6], f[7]));
+}
+
+template <int MF, bool FP8>
 __global__ __launch_bounds__(256) void attn_flash_kernel(
     const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
     const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
@@ -155,6 +175,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     // MF query fragments of 16 per wave: 2 for long / batched problems (every K / V^T fragment read feeds two MFMAs),
     // 1 when the grid would otherwise leave most CUs idle (one 10 s utterance: 16 (batch, head) pairs x 4 tiles of 128)
     constexpr int D = 64, KT = 64, LDK = 80, LD = 72, QW = 16 * MF;
+    constexpr int LD8 = 72;                            // byte pitch of the fp8 tiles and of the fp8 P patch
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KT * LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[2][D * LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Ps[4][QW * LD];
@@ -181,6 +202,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     // into one 8-byte LDS write.  O^T = V^T P^T (A = V^T fragment, B = P fragment read like an A operand) keeps the
     // query on the lane for the rescale and yields 4 consecutive channels per lane for 8-byte output stores.
     short8_t aq[MF][2];                                // lane (q = l16, k-group g): Q[q][ks*32 + 8g .. +7]
+    long aq8[MF][2];                                   // the same as 8 e4m3 bytes
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         int row = qb + mf * 16 + l16;
@@ -188,6 +210,10 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         const bf16_t* qp = q + (long)row * ldq + 8 * g;
         aq[mf][0] = *reinterpret_cast<const short8_t*>(qp);
         aq[mf][1] = *reinterpret_cast<const short8_t*>(qp + 32);
+        if constexpr (FP8) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) aq8[mf][ks] = __builtin_bit_cast(long, bf16x8_to_fp8(__builtin_bit_cast(uint4, aq[mf][ks])));
+        }
     }
     float4_t o[MF][4];                                 // O^T: [mf][df] rows d = df*16 + 4g + r, column q = l16
     float m_run[MF], l_run[MF];
@@ -231,8 +257,13 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         for (int i = 0; i < 2; ++i) {
             int id = tid + i * 256;
             int r = id >> 3, c = (id & 7) * 8;
-            *reinterpret_cast<uint4*>(Ks[buf] + r * LDK + c) = kreg[i];
-            *reinterpret_cast<uint4*>(Vs[buf] + r * LDK + c) = vreg[i];
+            if constexpr (FP8) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(Ks[buf]) + r * LD8 + c) = bf16x8_to_fp8(kreg[i]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(Vs[buf]) + r * LD8 + c) = bf16x8_to_fp8(vreg[i]);
+            } else {
+                *reinterpret_cast<uint4*>(Ks[buf] + r * LDK + c) = kreg[i];
+                *reinterpret_cast<uint4*>(Vs[buf] + r * LDK + c) = vreg[i];
+            }
         }
     };
     load_tiles(0);
@@ -251,10 +282,17 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
             for (int mf = 0; mf < MF; ++mf) s[mf][nf] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                short8_t bk = *reinterpret_cast<const short8_t*>(Ks[buf] + (nf * 16 + l16) * LDK + ks * 32 + 8 * g);
+                if constexpr (FP8) {
+                    const long bk = *reinterpret_cast<const long*>(reinterpret_cast<const char*>(Ks[buf]) + (nf * 16 + l16) * LD8 + ks * 32 + 8 * g);
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf)
-                    s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, aq[mf][ks], s[mf][nf], 0, 0, 0);
+                    for (int mf = 0; mf < MF; ++mf)
+                        s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bk, aq8[mf][ks], s[mf][nf], 0, 0, 0);
+                } else {
+                    short8_t bk = *reinterpret_cast<const short8_t*>(Ks[buf] + (nf * 16 + l16) * LDK + ks * 32 + 8 * g);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+                        s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, aq[mf][ks], s[mf][nf], 0, 0, 0);
+                }
             }
         }
         const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);       // uniform per tile
@@ -316,10 +354,14 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][3], sc2, -m_use));
                 rs += (p0 + p1) + (p2 + p3);
                 // 4 consecutive keys of query l16 -> one 8-byte write into the row-major [q][key] patch
-                uint2 pk;
-                pk.x = pack_bf16x2(p0, p1);
-                pk.y = pack_bf16x2(p2, p3);
-                *reinterpret_cast<uint2*>(Pw + (mf * 16 + l16) * LD + nf * 16 + 4 * g) = pk;
+                if constexpr (FP8) {
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(Pw) + (mf * 16 + l16) * LD8 + nf * 16 + 4 * g) = pk_bf8x4(p0, p1, p2, p3);
+                } else {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(p0, p1);
+                    pk.y = pack_bf16x2(p2, p3);
+                    *reinterpret_cast<uint2*>(Pw + (mf * 16 + l16) * LD + nf * 16 + 4 * g) = pk;
+                }
             }
             rs += __shfl_xor(rs, 16, 64);
             rs += __shfl_xor(rs, 32, 64);
@@ -334,6 +376,23 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (FP8) {
+            long ap8[MF][2];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    ap8[mf][ks] = *reinterpret_cast<const long*>(reinterpret_cast<const char*>(Pw) + (mf * 16 + l16) * LD8 + ks * 32 + 8 * g);
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const long bv = *reinterpret_cast<const long*>(reinterpret_cast<const char*>(Vs[buf]) + (df * 16 + l16) * LD8 + ks * 32 + 8 * g);
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf)
+                        o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bv, ap8[mf][ks], o[mf][df], 0, 0, 0);
+                }
+        } else {
         short8_t ap[MF][2];                            // lane (q = l16, g): P[q][ks*32 + 8g .. +7]
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
@@ -349,6 +408,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 for (int mf = 0; mf < MF; ++mf)
                     o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, ap[mf][ks], o[mf][df], 0, 0, 0);
             }
+        }
         __builtin_amdgcn_wave_barrier();               // the patch is rewritten in the next tile
     }
 #pragma unroll
@@ -582,10 +642,34 @@ extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, con
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
     if (small)
-        hipLaunchKernelGGL(attn_flash_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+        hipLaunchKernelGGL((attn_flash_kernel<1, false>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
                            (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin);
     else
-        hipLaunchKernelGGL(attn_flash_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+        hipLaunchKernelGGL((attn_flash_kernel<2, false>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+
+extern "C" int mmx_attn_flash_fp8(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
+                                  const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
+                                  int B, int H, int T_, float scale, const float* keymask, int64_t km_bs, int chunk,
+                                  int q_begin, hipStream_t stream) {
+    MMX_CHECK_ARG(q && k && vt && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0);
+    MMX_CHECK_ARG(q_begin >= 0 && q_begin < T_ && q_begin % 16 == 0);
+    MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
+    MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8);
+    MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0);
+    const int npairs = H * B, Tq = T_ - q_begin;
+    const bool small = (long)npairs * ((Tq + 127) / 128) < 192;
+    const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
+    dim3 grid(8 * ((npairs + 7) / 8) * nq);
+    if (small)
+        hipLaunchKernelGGL((attn_flash_kernel<1, true>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin);
+    else
+        hipLaunchKernelGGL((attn_flash_kernel<2, true>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
                            (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin);
     MMX_LAUNCH_CHECK();
     return MMX_OK;

@@ -92,7 +92,7 @@ class Graphed:
 class FlowEngine:
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", n_timesteps=10, cfg_rate=0.7,
                  enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True, parts=("encoder", "estimator"),
-                 fused=None):
+                 fused=None, attn="bf16"):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
         self.enc_chunk, self.est_chunk = enc_chunk, est_chunk
@@ -104,6 +104,10 @@ class FlowEngine:
         # workgroup (64 workgroups for one 10 s utterance) leaves 3/4 of the matrix cores idle, while the per-op launches
         # split N over all CUs (measured, one 10 s utterance, fp32: 175 ms fused, 104 ms per-op)
         self.fused = fused
+        # attn="fp8": the estimator's full-length attention launches run the fp8 MFMA variant (bf16 build only; BASELINE
+        # config 5).  The split-key launches of streaming hops stay bf16.
+        assert attn in ("bf16", "fp8")
+        self.attn_fp8 = attn == "fp8" and dtype == BF16
         dt = dtype
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         lin = lambda k: ops.pack_linear(f(k), dt)
@@ -563,7 +567,8 @@ class FlowEngine:
         def attention():
             if bf:
                 ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
-                                    k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, keymask=mask, chunk=chunk)
+                                    k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, keymask=mask, chunk=chunk,
+                                    fp8=self.attn_fp8)
             else:
                 ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
                                q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, keymask=mask,

@@ -23,7 +23,7 @@ SAMPLE_RATE = 24000
 
 class TtsEngine:
     def __init__(self, llm_sd, flow_sd, dac_sd, dtype=BF16, device="cuda", max_batch=1, max_ctx=2048,
-                 dac_rates=(5, 4, 4, 3, 2), use_graphs=True):
+                 dac_rates=(5, 4, 4, 3, 2), use_graphs=True, attn="bf16"):
         self.dtype, self.dev = dtype, torch.device(device)
         if self.dev.type == "cuda" and self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())
@@ -33,7 +33,7 @@ class TtsEngine:
         # sequences are still running the batch continues in a 16-slot engine over the same weights and KV pages
         self.llm_small = (LlmEngine(None, dtype=dtype, device=device, max_batch=16, max_ctx=max_ctx, use_graphs=use_graphs,
                                     share_from=self.llm) if max_batch > 16 else None)
-        self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs)
+        self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs, attn=attn)
         self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device)
         self.hop = self.dac.hop
 

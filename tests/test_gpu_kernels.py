@@ -177,7 +177,8 @@ def test_attn_dense(env, dt, T, chunk, relpos):
 
 @pytest.mark.parametrize("T,chunk,q_begin", [(64, 0, 0), (500, 0, 0), (137, 50, 0), (1000, 0, 0), (1000, 50, 944), (1450, 50, 1392),
                                               (600, 50, 544), (2999, 0, 2960)])
-def test_attn_flash_bf16(env, T, chunk, q_begin):
+@pytest.mark.parametrize("fp8", [False, True])
+def test_attn_flash_bf16(env, T, chunk, q_begin, fp8):
     """Every variant of the MFMA flash kernel: 32- and 16-query fragments per wave, and (q_begin > 0, many keys) the
     split-key variant a streaming hop uses; rows before q_begin must stay untouched."""
     from oracle import flow as OF
@@ -193,7 +194,7 @@ def test_attn_flash_bf16(env, T, chunk, q_begin):
     out = torch.zeros(B, T, H * D, device="cuda", dtype=torch.bfloat16)
     ops.attn_flash_bf16(q, k, vt, out, B=B, H=H, T=T, ldq=H * D, ldk=H * D, ldvt=Tp, ldo=H * D, q_bs=T * H * D,
                         k_bs=T * H * D, vt_bs=H * D * Tp, o_bs=T * H * D, scale=D ** -0.5, keymask=km.cuda(), chunk=chunk,
-                        q_begin=q_begin)
+                        q_begin=q_begin, fp8=fp8)
     qh, kh, vh = (t.float().cpu().view(B, T, H, D).transpose(1, 2) for t in (q, k, v))
     s = (qh @ kh.transpose(-2, -1)) * D ** -0.5
     vis = km.bool()[:, None, :].expand(B, T, T).clone()
@@ -201,7 +202,10 @@ def test_attn_flash_bf16(env, T, chunk, q_begin):
         vis = vis & OF.subsequent_chunk_mask(T, chunk)[None]
     s = s.masked_fill(~vis[:, None], float("-inf"))
     ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, H * D)
-    assert rel_err(out.cpu()[:, q_begin:], ref[:, q_begin:]) < 2e-2
+    err = rel_err(out.cpu()[:, q_begin:], ref[:, q_begin:])
+    if fp8:
+        print(f"fp8 flash T={T} chunk={chunk} q_begin={q_begin}: max abs err / max |ref| = {err:.3e}")
+    assert err < (1e-1 if fp8 else 2e-2), err          # fp8: e4m3 Q / K / V (3-bit mantissa), e5m2 P (2-bit)
     assert float(out[:, :q_begin].abs().max() if q_begin else 0.0) == 0.0
 
 

@@ -1,24 +1,24 @@
-"""Does running two B=16 decode graphs concurrently on two streams beat one B=32 graph? (latency-bound kernels)"""
-import os, sys, time
+"""Does running two 16-sequence decode graphs concurrently on two streams beat one 32-sequence graph?  The decode step is
+a chain of ~120 latency-bound kernels that leave most of the chip idle; two independent chains overlap their latencies
+and pay for it with a second pass over the weights (HBM has the room)."""
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "minimax-speech_amd"))
-import torch
-from mmx import shapes, synth
-from mmx.llm import LlmEngine
+import torch  # noqa: E402
+from mmx import shapes, synth  # noqa: E402
+from mmx.llm import LlmEngine  # noqa: E402
 
 sd = synth.synth_state_dict(shapes.llm_manifest(), 0)
 z = torch.zeros(1, 0, dtype=torch.long).cuda()
 g = torch.Generator().manual_seed(0)
 
 
-def mk(B, share=None):
-    e = LlmEngine(sd if share is None else None, dtype=1, max_batch=B, max_ctx=640, share_from=share)
-    if share is not None:   # own KV pages for an independent batch
-        e.kc = torch.zeros_like(share.kc[:, : B * e.max_pages + 1]); e.vc = torch.zeros_like(e.kc)
-        e.block_table = torch.arange(B * e.max_pages, dtype=torch.int32, device="cuda").reshape(B, e.max_pages).contiguous()
-        e.trash_page = B * e.max_pages
-    xs = [e.build_lm_input(torch.randint(0, 151936, (1, 48), generator=g).cuda(), z, z) for _ in range(B)]
-    e.start(xs, [500] * B, [500] * B, seed=1)
+def begin(e):
+    xs = [e.build_lm_input(torch.randint(0, 151936, (1, 48), generator=g).cuda(), z, z) for _ in range(e.B)]
+    e.start(xs, [500] * e.B, [500] * e.B, seed=1)
     for _ in range(3):
         e.step()
     torch.cuda.synchronize()
@@ -26,24 +26,30 @@ def mk(B, share=None):
 
 
 def timed(fn, n=200):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(n):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
 
-e32 = mk(32)
-print("B=32 one stream      : %.3f ms/step" % timed(e32.step))
-a = mk(16, share=e32); b = mk(16, share=e32)
-print("B=16 one stream      : %.3f ms/step" % timed(a.step))
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+e32 = begin(LlmEngine(sd, dtype=1, max_batch=32, max_ctx=640))
+print("32 sequences, one stream          : %.3f ms/step" % timed(e32.step), flush=True)
+a = LlmEngine(None, dtype=1, max_batch=16, max_ctx=640, share_from=e32)
+b = LlmEngine(None, dtype=1, max_batch=16, max_ctx=640, share_from=e32)
+for s_ in range(32):
+    e32.release(s_)
+begin(a), begin(b)
+print("16 sequences, one stream          : %.3f ms/step" % timed(a.step), flush=True)
+s1, s2 = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
+
+
 def pair():
-    with torch.cuda.stream(s1): a.step()
-    with torch.cuda.stream(s2): b.step()
-print("2 x B=16, two streams: %.3f ms/step-pair" % timed(pair))
-c = [mk(8, share=e32) for _ in range(4)]; ss = [torch.cuda.Stream() for _ in range(4)]
-def quad():
-    for e, s in zip(c, ss):
-        with torch.cuda.stream(s): e.step()
-print("4 x B=8, four streams: %.3f ms/step-quad" % timed(quad))
+    with torch.cuda.stream(s1):
+        a.step()
+    with torch.cuda.stream(s2):
+        b.step()
+
+
+print("2 x 16 sequences, two streams     : %.3f ms/step-pair" % timed(pair), flush=True)
