@@ -75,22 +75,23 @@ def graph_time(fn, reps=20, iters=10):
     return timeit(g.replay, iters=iters, warm=2) / reps
 
 
-def flash_case(B, T, chunk=0):
+def flash_case(B, T, chunk=0, fp8=False):
     H, D = 8, 64
     q, k = (torch.randn(B, T, H * D, device="cuda").bfloat16() for _ in range(2))
     Tp = ops.round_up(T, 8)
     vt = torch.randn(B, H * D, Tp, device="cuda").bfloat16()
     out = torch.empty(B, T, H * D, device="cuda", dtype=torch.bfloat16)
     fn = lambda: ops.attn_flash_bf16(q, k, vt, out, B=B, H=H, T=T, ldq=H * D, ldk=H * D, ldvt=Tp, ldo=H * D, q_bs=T * H * D,
-                                     k_bs=T * H * D, vt_bs=H * D * Tp, o_bs=T * H * D, scale=0.125, chunk=chunk)
+                                     k_bs=T * H * D, vt_bs=H * D * Tp, o_bs=T * H * D, scale=0.125, chunk=chunk, fp8=fp8)
     us = graph_time(fn)
     fl = 4.0 * B * H * T * T * D
-    print(f"flash B={B:3d} T={T:5d} chunk={chunk}: {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s")
+    print(f"flash{' fp8' if fp8 else '    '} B={B:3d} T={T:5d} chunk={chunk}: {us:8.2f} us  {fl / us / 1e6:8.1f} TFLOP/s")
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "flash":
-    for B, T in ((2, 128), (2, 512), (2, 1024), (16, 512), (16, 1024), (64, 512)):
+    for B, T in ((2, 128), (2, 512), (2, 1024), (2, 3000), (16, 512), (16, 1024), (64, 512)):
         flash_case(B, T)
+        flash_case(B, T, fp8=True)
     flash_case(16, 512, 50)
 
 
