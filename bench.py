@@ -221,6 +221,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flow-bm", type=int, default=0, help="cap the fused flow kernels' tile height (tuning: 32 leaves registers for co-resident decode waves)")
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"], help="fp8: estimator attention on the fp8 MFMA (config 5)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-utterance and fp32-build extra measurements")
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
@@ -260,6 +261,8 @@ def main():
     dt = 1 if a.dtype == "bf16" else 0
     PER_GPU = 1 if a.workload in ("single", "longform") else a.per_gpu
     eng = make_engine(dt, dev, PER_GPU, 2048 if a.workload == "longform" else 640)
+    if a.flow_bm:
+        eng.flow.max_tile_rows = a.flow_bm
     emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).to(dev)
     if a.workload == "longform":
         # BASELINE config 5: one 60 s utterance per GPU, streaming (25-token hops, chunk-causal flow with the estimator /

@@ -530,6 +530,7 @@ class FlowEngine:
         tiles = lambda bm: B * ((T + bm - 1) // bm)
         if self.dtype == BF16:
             bm = 64 if tiles(64) >= 160 else (32 if tiles(32) >= 128 else 16)
+            bm = min(bm, getattr(self, "max_tile_rows", 64))
             return bm, bm
         return (32 if tiles(32) >= 128 else 16), 16            # fp32: tail, resnet (LDS: fp32 tiles are twice as large)
 
