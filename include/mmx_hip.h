@@ -306,9 +306,11 @@ typedef struct MmxEstResnetParams {
     float eps;
     MmxEstNext next;
 } MmxEstResnetParams;
-/* pf: k-steps of weight fragments a wave keeps in flight (2 / 4 / 8; 0 = the library's default for that tile). */
-int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, int pf, hipStream_t stream);
-int mmx_est_resnet(const MmxEstResnetParams* p, int dtype, int bm, int pf, hipStream_t stream);
+/* cfg = pf + 16 * waves (0 = the library's defaults): pf = k-steps of weight fragments a wave keeps in flight (2 / 4 / 8);
+ * waves = 4 (one wave per SIMD, 64-column slices) or 8 (two per SIMD, 32-column slices: one wave's epilogue runs under the
+ * other's MFMA stage; bf16 only). */
+int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, int cfg, hipStream_t stream);
+int mmx_est_resnet(const MmxEstResnetParams* p, int dtype, int bm, int cfg, hipStream_t stream);
 
 #ifdef __cplusplus
 }

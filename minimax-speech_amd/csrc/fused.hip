@@ -31,6 +31,7 @@
 // bf16 build: v_mfma_f32_16x16x32_bf16; fp32 parity build: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), fp32 tiles.
 #include "common.h"
 #include "../../include/mmx_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -61,16 +62,18 @@ __host__ __device__ constexpr int tile_pitch(int K, int esz) { return ((K * esz 
 // PF: k-steps the ring runs ahead.  One k-step of a wave is MF*NF MFMAs (16 cycles each), an L2 hit takes ~500-800
 // cycles: a 16-row tile (MF = 1) needs ~8 k-steps in flight, a 64-row tile 2.  Every stage's k-step count must be a
 // multiple of PF (checked on the host).
+// The ring is 4 n-fragments wide; a stage that owns fewer (nf = 2: 32 columns per wave in the 8-wave kernels) uses the
+// first nf slots, and head loads for the unused slots repeat fragment 0 (no branch around a load).
 template <typename T, int NF, int PF_>
 struct WRing {
     static constexpr int E = FT<T>::E, PF = PF_;
     u32x4_t w[PF][NF];
-    __device__ __forceinline__ void prime(const T* wb, long ns, int nk) {
+    __device__ __forceinline__ void prime(const T* wb, long ns, int nk, int nf) {
 #pragma unroll
         for (int p = 0; p < PF; ++p)
 #pragma unroll
             for (int j = 0; j < NF; ++j)
-                w[p][j] = *reinterpret_cast<const u32x4_t*>(wb + j * ns + (long)(p < nk ? p : nk - 1) * 64 * E);
+                w[p][j] = *reinterpret_cast<const u32x4_t*>(wb + (j < nf ? j : 0) * ns + (long)(p < nk ? p : nk - 1) * 64 * E);
     }
 };
 
@@ -79,13 +82,13 @@ struct WRing {
 // taps = 3; Linear: taps = 1).  wb / ns / nk: packed weights of this stage for this wave (lane offset included),
 // elements between n-fragments, k-steps (even).  wbn / nsn: the next stage's (NULL: none).
 template <typename T, int MF, int NF, int PF>
-__device__ __forceinline__ void stage_run(WRing<T, NF, PF>& ring, const char* a_lane, int pitch, int cin_steps,
-                                          const T* wb, long ns, int nk, const T* wbn, long nsn, int nkn,
+__device__ __forceinline__ void stage_run(WRing<T, 4, PF>& ring, const char* a_lane, int pitch, int cin_steps,
+                                          const T* wb, long ns, int nk, const T* wbn, long nsn, int nkn, int nfn,
                                           float4_t (&acc)[MF][NF]) {
     constexpr int E = FT<T>::E, KB = FT<T>::KB;
     typedef typename FT<T>::frag_t frag_t;
-    // A fragments come from LDS AD - 1 k-steps ahead of their use (one wave per SIMD: nothing else hides the ~130
-    // cycle LDS latency; a k-step is MF*NF MFMAs = 64 cycles at MF = 1, 256 at MF = 4)
+    // A fragments come from LDS AD - 1 k-steps ahead of their use (a k-step is MF*NF MFMAs = 64 cycles at MF = 1,
+    // 256 at MF = 4; the LDS latency is ~130 cycles)
     constexpr int AD = (MF == 1 && PF >= 4) ? 4 : 2;
     static_assert(PF % AD == 0, "ring depths");
     frag_t a[AD][MF];
@@ -99,24 +102,28 @@ __device__ __forceinline__ void stage_run(WRing<T, NF, PF>& ring, const char* a_
             if (++rc == cin_steps) { rc = 0; ++rt; }
         }
     };
-#pragma unroll
-    for (int s = 0; s < AD - 1; ++s) read_a(a[s]);
-    for (int ks = 0; ks < nk; ks += PF) {
+    // one group of PF k-steps.  LAST: the refills of this group are the head of the NEXT stage (k-steps 0 .. PF-1 of wbn,
+    // nfn fragments wide); otherwise k-steps ks+PF .. of this stage, NF fragments wide.  No load sits under a branch
+    // that depends on the k-step, so the compiler keeps counted vmcnt waits.
+    auto group = [&](int ks, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             read_a(a[(p + AD - 1) % AD]);
             frag_t b[NF];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) b[j] = __builtin_bit_cast(frag_t, ring.w[p][j]);
-            // refill this ring slot: k-step ks+p+PF of this stage, or the head of the next stage (uniform select,
-            // no branch around the loads: the compiler then keeps counted vmcnt waits)
-            const int nx = ks + p + PF;
-            const bool here = nx < nk;
-            const int nxn = wbn ? (nx - nk < nkn ? nx - nk : nkn - 1) : nk - 1;
-            const T* src = here ? wb + (long)nx * 64 * E : (wbn ? wbn + (long)nxn * 64 * E : wb + (long)nxn * 64 * E);
-            const long sst = here ? ns : (wbn ? nsn : ns);
+            for (int jj = 0; jj < NF; ++jj) b[jj] = __builtin_bit_cast(frag_t, ring.w[p][jj]);
+            if constexpr (LAST) {
+                if (wbn) {                             // uniform per stage
+                    const T* src = wbn + (long)(p < nkn ? p : nkn - 1) * 64 * E;
 #pragma unroll
-            for (int j = 0; j < NF; ++j) ring.w[p][j] = *reinterpret_cast<const u32x4_t*>(src + j * sst);
+                    for (int jj = 0; jj < 4; ++jj) ring.w[p][jj] = *reinterpret_cast<const u32x4_t*>(src + (jj < nfn ? jj : 0) * nsn);
+                }
+            } else {
+                const T* src = wb + (long)(ks + p + PF) * 64 * E;
+#pragma unroll
+                for (int jj = 0; jj < NF; ++jj) ring.w[p][jj] = *reinterpret_cast<const u32x4_t*>(src + jj * ns);
+            }
             // keep the refill (and the A read-ahead) HERE: left alone, the scheduler sinks these loads down to their
             // first use PF k-steps later (register pressure), which turns the ring into load-then-wait every k-step
             // (measured: the same kernel time at ring depth 2, 4 and 8)
@@ -124,10 +131,14 @@ __device__ __forceinline__ void stage_run(WRing<T, NF, PF>& ring, const char* a_
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) acc[i][j] = mma<T>(a[p % AD][i], b[j], acc[i][j]);
+                for (int jj = 0; jj < NF; ++jj) acc[i][jj] = mma<T>(a[p % AD][i], b[jj], acc[i][jj]);
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < AD - 1; ++s_) read_a(a[s_]);
+    for (int ks = 0; ks + PF < nk; ks += PF) group(ks, std::false_type{});
+    group(nk - PF, std::true_type{});
 }
 
 template <int MF, int NF>
@@ -139,42 +150,47 @@ __device__ __forceinline__ void zero_acc(float4_t (&acc)[MF][NF]) {
 }
 
 // MFMA C layout (lane = column l16 of n-fragment j, rows 4g..4g+3) -> row layout: lane owns row (lane >> 2) of the
-// 16-row fragment and the 16 consecutive columns (lane & 3)*16 .. +15 of the wave's 64-column slice.
-constexpr int LDC = 68;                                // fp32 patch row: 64 + 4 pad (conflict-free ds_write_b32)
-__device__ __forceinline__ void to_rows(const float4_t (&acc)[4], float* patch, int lane, float (&v)[16]) {
+// 16-row fragment and NF*4 consecutive columns (lane & 3)*NF*4 .. of the wave's NF*16-column slice, through the wave's
+// private fp32 patch (16 rows of NF*16 + 4 floats: conflict-free ds_write_b32).
+constexpr int PATCH_FLOATS = 16 * 68;                  // per wave: the widest slice is 64 columns
+template <int NF>
+__device__ __forceinline__ void to_rows(const float4_t (&acc)[NF], float* patch, int lane, float (&v)[NF * 4]) {
+    constexpr int LDC = NF * 16 + 4;
     const int g = lane >> 4, l16 = lane & 15;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) patch[(4 * g + r) * LDC + j * 16 + l16] = acc[j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const float* src = patch + (lane >> 2) * LDC + (lane & 3) * 16;
+    const float* src = patch + (lane >> 2) * LDC + (lane & 3) * (NF * 4);
 #pragma unroll
-    for (int c = 0; c < 16; c += 4) {
+    for (int c = 0; c < NF * 4; c += 4) {
         const float4_t t = *reinterpret_cast<const float4_t*>(src + c);
         v[c] = t[0]; v[c + 1] = t[1]; v[c + 2] = t[2]; v[c + 3] = t[3];
     }
     __builtin_amdgcn_wave_barrier();                   // the patch is rewritten by the next fragment
 }
 
-__device__ __forceinline__ void load16(const float* p, float (&v)[16]) {
+template <int N>
+__device__ __forceinline__ void loadn(const float* p, float (&v)[N]) {
 #pragma unroll
-    for (int c = 0; c < 16; c += 4) {
+    for (int c = 0; c < N; c += 4) {
         const float4_t t = *reinterpret_cast<const float4_t*>(p + c);
         v[c] = t[0]; v[c + 1] = t[1]; v[c + 2] = t[2]; v[c + 3] = t[3];
     }
 }
-__device__ __forceinline__ void store16(float* p, const float (&v)[16]) {
+template <int N>
+__device__ __forceinline__ void storen(float* p, const float (&v)[N]) {
 #pragma unroll
-    for (int c = 0; c < 16; c += 4) *reinterpret_cast<float4_t*>(p + c) = float4_t{v[c], v[c + 1], v[c + 2], v[c + 3]};
+    for (int c = 0; c < N; c += 4) *reinterpret_cast<float4_t*>(p + c) = float4_t{v[c], v[c + 1], v[c + 2], v[c + 3]};
 }
-// 16 consecutive values as T (global or LDS destination, 16-byte aligned)
-template <typename T>
-__device__ __forceinline__ void store16_T(T* p, const float (&v)[16]) {
+// N (8 or 16) consecutive values as T (global or LDS destination, 16-byte aligned)
+template <typename T, int N>
+__device__ __forceinline__ void storen_T(T* p, const float (&v)[N]) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int c = 0; c < 16; c += 8) {
+        for (int c = 0; c < N; c += 8) {
             uint4 pk;
             pk.x = pack_bf16x2(v[c], v[c + 1]);
             pk.y = pack_bf16x2(v[c + 2], v[c + 3]);
@@ -183,64 +199,69 @@ __device__ __forceinline__ void store16_T(T* p, const float (&v)[16]) {
             *reinterpret_cast<uint4*>(p + c) = pk;
         }
     } else {
-        store16(p, v);
+        storen<N>(p, v);
     }
 }
 
-// LayerNorm of the rows of a [BMR x 256] tile held in the row layout (v[i][16] per wave, 4 waves x 64 columns).
+// LayerNorm of the rows of a [rows x 256] tile held in the row layout (v[i][CW] per wave, NW waves x 256/NW columns).
 // Two-pass statistics like torch (mean, then the mean of squared deviations), partial sums exchanged through
-// stats[BMR][4].  Contains 3 workgroup barriers; all waves must call it.  Leaves normalised*gamma+beta in v.
-// gamma / beta: this lane's 16 columns, loaded by the caller BEFORE the preceding MFMA stage (see "epilogue operands").
-template <int MFR>
-__device__ __forceinline__ void layernorm_rows(float (&v)[MFR][16], float* stats, const float (&g)[16], const float (&be)[16],
+// stats[rows][NW].  Contains 4 workgroup barriers; all waves must call it.  Leaves normalised*gamma+beta in v.
+// gamma / beta: this lane's CW columns, loaded by the caller BEFORE the preceding MFMA stage (see "epilogue operands").
+template <int MFR, int CW, int NW>
+__device__ __forceinline__ void layernorm_rows(float (&v)[MFR][CW], float* stats, const float (&g)[CW], const float (&be)[CW],
                                                float eps, int wave, int lane) {
     const int rl = lane >> 2;
     float mean[MFR];
+    auto total = [&](int row) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) {
+            const float4_t q = *reinterpret_cast<const float4_t*>(stats + row * NW + w);
+            t += (q[0] + q[1]) + (q[2] + q[3]);
+        }
+        return t;
+    };
     __syncthreads();                                   // stats free (previous readers done)
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s += v[i][c];
+        for (int c = 0; c < CW; ++c) s += v[i][c];
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
-        if ((lane & 3) == 0) stats[(i * 16 + rl) * 4 + wave] = s;
+        if ((lane & 3) == 0) stats[(i * 16 + rl) * NW + wave] = s;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < MFR; ++i) {
-        const float4_t t = *reinterpret_cast<const float4_t*>(stats + (i * 16 + rl) * 4);
-        mean[i] = ((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 256.0f);
-    }
+    for (int i = 0; i < MFR; ++i) mean[i] = total(i * 16 + rl) * (1.0f / 256.0f);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
         float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { const float d = v[i][c] - mean[i]; q += d * d; }
+        for (int c = 0; c < CW; ++c) { const float d = v[i][c] - mean[i]; q += d * d; }
         q += __shfl_xor(q, 1, 64);
         q += __shfl_xor(q, 2, 64);
-        if ((lane & 3) == 0) stats[(i * 16 + rl) * 4 + wave] = q;
+        if ((lane & 3) == 0) stats[(i * 16 + rl) * NW + wave] = q;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
-        const float4_t t = *reinterpret_cast<const float4_t*>(stats + (i * 16 + rl) * 4);
-        const float rstd = rsqrtf(((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 256.0f) + eps);
+        const float rstd = rsqrtf(total(i * 16 + rl) * (1.0f / 256.0f) + eps);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[i][c] = (v[i][c] - mean[i]) * rstd * g[c] + be[c];
+        for (int c = 0; c < CW; ++c) v[i][c] = (v[i][c] - mean[i]) * rstd * g[c] + be[c];
     }
 }
 
-// cooperative copy of `rows` rows x K elements (global row stride ld, first row index r0 of `nrows_valid` valid
-// rows starting at `src`; rows outside [0, nvalid) read zero) into an LDS tile with `pitch` bytes per row
+// cooperative copy of `rows` rows x K elements (global row stride ld, first row index r0 of `nvalid` valid rows
+// starting at `src`; rows outside [0, nvalid) read zero) into an LDS tile with `pitch` bytes per row
 template <typename T>
 __device__ __forceinline__ void load_tile(const T* __restrict__ src, long ld, int r0, int nvalid, int rows, int K,
-                                          char* tile, int pitch, int tid) {
+                                          char* tile, int pitch, int tid, int nthreads) {
     constexpr int E = FT<T>::E;
     const int cpr = K / E;                             // 16-byte chunks per row
     const int total = rows * cpr;
-    for (int id = tid; id < total; id += 256) {
+    for (int id = tid; id < total; id += nthreads) {
         const int r = id / cpr, ch = id - r * cpr;
         const int gr = r0 + r;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -250,104 +271,109 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ src, long ld, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Shared tail of both kernels: x (row layout, 64 columns per wave) -> LayerNorm(n1) -> A1 tile -> Q/K/V projection.
+// Shared tail of both kernels: x (row layout) -> LayerNorm(n1) -> A1 tile -> Q/K/V projection.
 // bf16: Q,K row-major [B][T][1024] and V TRANSPOSED vt[b][512][Tp] (what the flash kernel reads);
 // fp32: q|k|v row-major [B][T][1536] (the dense attention kernel reads strided heads).
-// Q/K/V pass p (0..5) of a wave: kind = p >> 1 (Q, K, V), 64 columns at kind*512 + wave*128 + (p & 1)*64 of the
-// packed [1536][256] projection; returns the wave's (lane-offset) fragment pointer.
-template <typename T>
+// Every wave takes 64-column passes: pass p of wave w is kind p / PPK (Q, K, V), columns kind*512 + (w*PPK + p % PPK)*64
+// of the packed [1536][256] projection, PPK = 512 / (64 * NW) passes per kind (2 with 4 waves, 1 with 8).
+template <typename T, int NW>
 __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lane, int p) {
-    constexpr int E = FT<T>::E, KB = FT<T>::KB;
+    constexpr int E = FT<T>::E, KB = FT<T>::KB, PPK = 512 / (64 * NW);
     return reinterpret_cast<const T*>(wqkv) + (long)lane * E +
-           (long)(((p >> 1) * 512 + wave * 128 + (p & 1) * 64) / 16) * ((long)(256 / KB) * 64 * E);
+           (long)(((p / PPK) * 512 + (wave * PPK + p % PPK) * 64) / 16) * ((long)(256 / KB) * 64 * E);
 }
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
-template <typename T, int MF, int PF>
-__device__ __forceinline__ void ln_qkv(float (&xv)[MF][16], const float (&n1g)[16], const float (&n1b)[16], const MmxEstNext& nx,
-                                       float eps, char* a1, char* vp, float* patch, float* stats, WRing<T, 4, PF>& ring, int b,
-                                       int t0, int Tn, int wave, int lane, int tid) {
-    constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256;
+template <typename T, int MF, int PF, int NW>
+__device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n1g)[64 / NW], const float (&n1b)[64 / NW],
+                                       const MmxEstNext& nx, float eps, char* a1, float* patch, float* stats,
+                                       WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane) {
+    constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256, CW = 64 / NW, PPK = 512 / (64 * NW), NP = 3 * PPK;
     constexpr int P1 = tile_pitch(C, sizeof(T));
     constexpr int NK = C / KB;
-    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
+    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
+    const int col0 = wave * (256 / NW) + (lane & 3) * CW;
     const long ns = (long)NK * 64 * E;
-    auto pass_w = [&](int p) { return qkv_pass<T>(nx.wqkv, wave, lane, p); };
-    layernorm_rows<MF>(xv, stats, n1g, n1b, eps, wave, lane);
+    layernorm_rows<MF, CW, NW>(xv, stats, n1g, n1b, eps, wave, lane);
 #pragma unroll
-    for (int i = 0; i < MF; ++i)
-        store16_T<T>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + wave * 64 + cq, xv[i]);
+    for (int i = 0; i < MF; ++i) storen_T<T, CW>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + col0, xv[i]);
     __syncthreads();
     const char* a_lane = a1 + l16 * P1 + g * 16;
     constexpr bool VT = sizeof(T) == 2;
-    constexpr int PV = MF * 16 * (int)sizeof(T) + 16;  // V^T patch row pitch: [64 columns][BM frames]
-    for (int p = 0; p < 6; ++p) {
+    constexpr int PV = 16 * (int)sizeof(T) + 16;       // V^T patch pitch: [64 columns][16 frames] inside the wave's patch
+    for (int p = 0; p < NP; ++p) {
         float4_t acc[MF][4];
         zero_acc(acc);
-        const T* wn = p < 5 ? pass_w(p + 1) : nullptr;
-        stage_run<T, MF, 4, PF>(ring, a_lane, P1, NK, pass_w(p), ns, NK, wn, ns, NK, acc);
-        const int kind = p >> 1, cw = wave * 128 + (p & 1) * 64;   // column inside the 512-wide Q / K / V
+        const T* wn = p + 1 < NP ? qkv_pass<T, NW>(nx.wqkv, wave, lane, p + 1) : nullptr;
+        stage_run<T, MF, 4, PF>(ring, a_lane, P1, NK, qkv_pass<T, NW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, 4, acc);
+        const int kind = p / PPK, cw = (wave * PPK + p % PPK) * 64;     // 64 columns at cw inside the 512-wide Q / K / V
         if (VT && kind == 2) {
-            // C layout -> [column][frame] patch: a lane holds 4 consecutive frames of one column
-            char* vw = vp + wave * 64 * PV;
+            // C layout -> [column][frame] patch, one 16-frame fragment at a time: a lane holds 4 consecutive frames of
+            // one column; then lane = column writes two 16-byte chunks of 8 frames (frames >= Tn as zeros: the pad of
+            // the transposed buffer stays finite)
+            char* vw = reinterpret_cast<char*>(patch);
+            bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)(cw + lane) * nx.ldvt + t0;
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
+            for (int i = 0; i < MF; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint2 pk;
                     pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
                     pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                    *reinterpret_cast<uint2*>(vw + (j * 16 + l16) * PV + (i * 16 + 4 * g) * 2) = pk;
+                    *reinterpret_cast<uint2*>(vw + (j * 16 + l16) * PV + (4 * g) * 2) = pk;
                 }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // lane = column; 16-byte chunks of 8 frames; frames >= Tn are written as zeros (the pad stays finite)
-            bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)(cw + lane) * nx.ldvt + t0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c8 = 0; c8 < MF * 2; ++c8) {
-                uint4 v = *reinterpret_cast<const uint4*>(vw + lane * PV + c8 * 16);
-                const int t = t0 + c8 * 8;
-                if (t >= Tn) continue;
-                if (t + 8 > Tn) {
-                    unsigned short* h = reinterpret_cast<unsigned short*>(&v);
+                for (int c8 = 0; c8 < 2; ++c8) {
+                    uint4 v = *reinterpret_cast<const uint4*>(vw + lane * PV + c8 * 16);
+                    const int t = t0 + i * 16 + c8 * 8;
+                    if (t >= Tn) continue;
+                    if (t + 8 > Tn) {
+                        unsigned short* h = reinterpret_cast<unsigned short*>(&v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (t + e >= Tn) h[e] = 0;
+                        for (int e = 0; e < 8; ++e)
+                            if (t + e >= Tn) h[e] = 0;
+                    }
+                    *reinterpret_cast<uint4*>(dst + i * 16 + c8 * 8) = v;
                 }
-                *reinterpret_cast<uint4*>(dst + c8 * 8) = v;
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         } else {
             T* out = reinterpret_cast<T*>(nx.q_out) + (long)b * nx.q_bs;
-            const int col = kind * 512 + cw + cq;
+            const int col = kind * 512 + cw + (lane & 3) * 16;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[16];
-                to_rows(acc[i], patch, lane, v);
+                to_rows<4>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
-                if (t < Tn) store16_T<T>(out + (long)t * nx.ldq + col, v);
+                if (t < Tn) storen_T<T, 16>(out + (long)t * nx.ldq + col, v);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int PF>
-__global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
+// NW = 4: one wave per SIMD, every wave a 64-column slice of the 256-wide stages.  NW = 8: two waves per SIMD, 32-column
+// slices: the VALU-heavy epilogues (GELU, layout changes, LayerNorm) of one wave run under the MFMA stage of the other,
+// which a single wave per SIMD cannot do for itself (measured at 64 rows: 60 us = weight stream 23 + MFMA 17 + VALU ~20,
+// one after the other).
+template <typename T, int BM, int PF, int NW>
+__global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
+    constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PPC = CH / (64 * NW);
     constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
     constexpr bool PRECISE = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* buf0 = smem;                                 // [BM][512] attention output, then the FF intermediate chunk,
-                                                       // then the V^T patches
+    char* buf0 = smem;                                 // [BM][512] attention output, then the FF intermediate chunk
     char* a1 = buf0 + BM * P0;                         // [BM][256] LayerNorm output (A operand of FF1 / QKV)
     float* patch_all = reinterpret_cast<float*>(a1 + BM * P1);
-    float* stats = patch_all + 4 * 16 * LDC;           // [BM][4]
+    float* stats = patch_all + NW * PATCH_FLOATS;      // [BM][NW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
-    float* patch = patch_all + wave * 16 * LDC;
+    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
+    float* patch = patch_all + wave * PATCH_FLOATS;
     const int b = blockIdx.y, t0 = p.t_begin + blockIdx.x * BM, Tn = p.T;
-    const int col0 = wave * 64 + cq;                   // this lane's 16 columns of a 256-wide row
+    const int col0 = wave * WC + (lane & 3) * CW;      // this lane's CW columns of a 256-wide row
 
     const T* wo = reinterpret_cast<const T*>(p.wo) + (long)lane * E;
     const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
@@ -355,85 +381,85 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
     constexpr int NK0 = CI / KB, NK1 = C / KB, NK2 = CH / KB, NK2T = CF / KB;
     const long ns0 = (long)NK0 * 64 * E, ns1 = (long)NK1 * 64 * E, ns2 = (long)NK2T * 64 * E;
     WRing<T, 4, PF> ring;
-    const T* wo_w = wo + (long)(wave * 4) * ns0;       // n-fragments 4*wave .. +3 (64 columns)
-    ring.prime(wo_w, ns0, NK0);
+    const T* wo_w = wo + (long)(wave * NFN) * ns0;     // this wave's NFN n-fragments of the 256 output columns
+    ring.prime(wo_w, ns0, NK0, NFN);
 
     // Epilogue operands (residual rows, biases, LayerNorm weights, row mask) are loaded BEFORE the MFMA stage whose
     // epilogue uses them.  A wave waits for a load with s_waitcnt vmcnt(N), which counts in issue order: a load issued
-    // in the epilogue would wait for itself AND drain the weight ring that is running ahead for the next stage
-    // (measured: ~25 exposed L2 / HBM round trips per workgroup, half of the kernel's time).
+    // in the epilogue would wait for itself AND drain the weight ring that is running ahead for the next stage.
     // ---- attention output projection + bias + residual  (transformer.py:290-297: attn1 -> + hidden_states)
-    // FF1 pass q (0..3): chunk q >> 1, 64 columns at chunk*512 + wave*128 + (q & 1)*64
-    auto w1_pass = [&](int q) { return w1 + (long)(((q >> 1) * CH + wave * 128 + (q & 1) * 64) / 16) * ns1; };
-    float x1[MF][16], bo[16], n3g[16], n3b[16];
+    // FF1 pass q = ch*PPC + h: 64 columns at ch*512 + (wave*PPC + h)*64 of the 1024-wide intermediate
+    auto w1_pass = [&](int q) { return w1 + (long)(((q / PPC) * CH + (wave * PPC + q % PPC) * 64) / 16) * ns1; };
+    float x1[MF][CW], bo[CW], n3g[CW], n3b[CW];
     {
         const float* xr = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int t = t0 + i * 16 + rl;
-            if (t < Tn) load16(xr + (long)t * C + col0, x1[i]);
+            if (t < Tn) loadn<CW>(xr + (long)t * C + col0, x1[i]);
             else {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) x1[i][c] = 0.f;
+                for (int c = 0; c < CW; ++c) x1[i][c] = 0.f;
             }
         }
-        load16(p.bo + col0, bo);
-        load16(p.n3g + col0, n3g);
-        load16(p.n3b + col0, n3b);
-        load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid);
+        loadn<CW>(p.bo + col0, bo);
+        loadn<CW>(p.n3g + col0, n3g);
+        loadn<CW>(p.n3b + col0, n3b);
+        load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
         __syncthreads();
-        float4_t acc[MF][4];
+        float4_t acc[MF][NFN];
         zero_acc(acc);
-        stage_run<T, MF, 4, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, acc);
+        stage_run<T, MF, NFN, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, 4, acc);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            float v[16];
-            to_rows(acc[i], patch, lane, v);
+            float v[CW];
+            to_rows<NFN>(acc[i], patch, lane, v);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x1[i][c] += v[c] + bo[c];
+            for (int c = 0; c < CW; ++c) x1[i][c] += v[c] + bo[c];
         }
     }
     // ---- LayerNorm (norm3) -> A1
     {
-        float hn[MF][16];
+        float hn[MF][CW];
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) hn[i][c] = x1[i][c];
-        layernorm_rows<MF>(hn, stats, n3g, n3b, p.eps, wave, lane);
+            for (int c = 0; c < CW; ++c) hn[i][c] = x1[i][c];
+        layernorm_rows<MF, CW, NW>(hn, stats, n3g, n3b, p.eps, wave, lane);
 #pragma unroll
-        for (int i = 0; i < MF; ++i) store16_T<T>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + col0, hn[i]);
+        for (int i = 0; i < MF; ++i) storen_T<T, CW>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + col0, hn[i]);
     }
     __syncthreads();                                   // A1 complete; every wave is done with the attention tile
     // ---- FF1 + GELU -> LDS chunk -> FF2 accumulate  (transformer.py:306-313, diffusers GELU = Linear + exact gelu)
-    float4_t acc2[MF][4];
+    float4_t acc2[MF][NFN];
     zero_acc(acc2);
-    const T* w2_w = w2 + (long)(wave * 4) * ns2;       // FF2: 64 output columns per wave, K walked per chunk
-    float b2[16], n1g[16], n1b[16], rm[MF];
+    const T* w2_w = w2 + (long)(wave * NFN) * ns2;     // FF2: this wave's output columns, K walked per chunk
+    float b2[CW], n1g[CW], n1b[CW], rm[MF];
     for (int ch = 0; ch < 2; ++ch) {
-        for (int h = 0; h < 2; ++h) {
-            const int q = ch * 2 + h;
-            const int hc = wave * 128 + h * 64 + cq;   // column inside the chunk
+        for (int h = 0; h < PPC; ++h) {
+            const int q = ch * PPC + h;
+            const int hc = (wave * PPC + h) * 64 + (lane & 3) * 16;   // column inside the chunk
             float b1[16];
-            load16(p.b1 + ch * CH + hc, b1);
+            loadn<16>(p.b1 + ch * CH + hc, b1);
             float4_t acc[MF][4];
             zero_acc(acc);
-            const T* wn = h == 0 ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
-            stage_run<T, MF, 4, PF>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, h == 0 ? ns1 : ns2,
-                                    h == 0 ? NK1 : NK2, acc);
+            const bool more = h + 1 < PPC;
+            const T* wn = more ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
+            stage_run<T, MF, 4, PF>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
+                                    more ? NK1 : NK2, more ? 4 : NFN, acc);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[16];
-                to_rows(acc[i], patch, lane, v);
+                to_rows<4>(acc[i], patch, lane, v);
 #pragma unroll
                 for (int c = 0; c < 16; ++c) v[c] = act_c<ACT_GELU, PRECISE>(v[c] + b1[c], 0.f);
-                store16_T<T>(reinterpret_cast<T*>(buf0 + (i * 16 + rl) * P0) + hc, v);
+                storen_T<T, 16>(reinterpret_cast<T*>(buf0 + (i * 16 + rl) * P0) + hc, v);
             }
         }
         __syncthreads();                               // the chunk is complete
         if (ch == 1) {                                 // operands of the closing epilogue and of the next LayerNorm
-            load16(p.b2 + col0, b2);
-            if (p.next.wqkv) { load16(p.next.n1g + col0, n1g); load16(p.next.n1b + col0, n1b); }
+            loadn<CW>(p.b2 + col0, b2);
+            if (p.next.wqkv) { loadn<CW>(p.next.n1g + col0, n1g); loadn<CW>(p.next.n1b + col0, n1b); }
             const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
@@ -441,8 +467,8 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
                 rm[i] = (rmk && t < Tn) ? rmk[t] : 1.f;
             }
         }
-        const T* wn = ch == 0 ? w1_pass(2) : (p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr);
-        stage_run<T, MF, 4, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, acc2);
+        const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW>(p.next.wqkv, wave, lane, 0) : nullptr);
+        stage_run<T, MF, NFN, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, 4, acc2);
         __syncthreads();                               // every wave is done reading the chunk
     }
     // ---- + bias + residual -> x (fp32 residual stream, in place)
@@ -450,146 +476,147 @@ __global__ __launch_bounds__(256) void est_tail_kernel(MmxEstTailParams p) {
         float* xw = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            float v[16];
-            to_rows(acc2[i], patch, lane, v);
+            float v[CW];
+            to_rows<NFN>(acc2[i], patch, lane, v);
             const int t = t0 + i * 16 + rl;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x1[i][c] = (x1[i][c] + v[c] + b2[c]) * rm[i];
+            for (int c = 0; c < CW; ++c) x1[i][c] = (x1[i][c] + v[c] + b2[c]) * rm[i];
             if (t < Tn) {
-                store16(xw + (long)t * C + col0, x1[i]);
+                storen<CW>(xw + (long)t * C + col0, x1[i]);
                 if (p.act_out)
-                    store16_T<T>(reinterpret_cast<T*>(p.act_out) + (long)b * p.act_bs + (long)t * p.act_ld + col0, x1[i]);
+                    storen_T<T, CW>(reinterpret_cast<T*>(p.act_out) + (long)b * p.act_bs + (long)t * p.act_ld + col0, x1[i]);
             }
         }
     }
-    if (p.next.wqkv) ln_qkv<T, MF, PF>(x1, n1g, n1b, p.next, p.eps, a1, buf0, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+    if (p.next.wqkv) ln_qkv<T, MF, PF, NW>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int PF>
-__global__ __launch_bounds__(256) void est_resnet_kernel(MmxEstResnetParams p) {
+template <typename T, int BM, int PF, int NW>
+__global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams p) {
     constexpr int MF = BM / 16, MH = MF + 1, E = FT<T>::E, KB = FT<T>::KB, C = 256;
+    constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16;
     constexpr int P1 = tile_pitch(C, sizeof(T));
     constexpr bool PRECISE = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cin = p.cin;
     const int PA = tile_pitch(cin, sizeof(T));
-    char* ain = smem;                                  // [BM + 18][cin]: input rows t0-18 .. t0+BM-1; later V^T patches
+    char* ain = smem;                                  // [BM + 18][cin]: input rows t0-18 .. t0+BM-1
     char* h1 = ain + (BM + 18) * PA;                   // [BM + 16][256]: block1 output rows t0-16 ..; later the A1 tile
     float* patch_all = reinterpret_cast<float*>(h1 + (BM + 16) * P1);
-    float* stats = patch_all + 4 * 16 * LDC;           // [BM + 16][4]
+    float* stats = patch_all + NW * PATCH_FLOATS;      // [BM + 16][NW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2, cq = (lane & 3) * 16;
-    float* patch = patch_all + wave * 16 * LDC;
+    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
+    float* patch = patch_all + wave * PATCH_FLOATS;
     const int b = blockIdx.y, t0 = p.t_begin + blockIdx.x * BM, Tn = p.T;
-    const int col0 = wave * 64 + cq;
+    const int col0 = wave * WC + (lane & 3) * CW;
     const int cs = cin / KB;                           // k-steps per tap
     const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
     const T* w2 = reinterpret_cast<const T*>(p.w2) + (long)lane * E;
     const T* wr = reinterpret_cast<const T*>(p.wr) + (long)lane * E;
     const int nk1 = 3 * cs, nk2 = 3 * (C / KB), nkr = cs;
     const long ns1 = (long)nk1 * 64 * E, ns2 = (long)nk2 * 64 * E, nsr = (long)nkr * 64 * E;
-    const T* w1_w = w1 + (long)(wave * 4) * ns1;
-    const T* w2_w = w2 + (long)(wave * 4) * ns2;
-    const T* wr_w = wr + (long)(wave * 4) * nsr;
+    const T* w1_w = w1 + (long)(wave * NFN) * ns1;
+    const T* w2_w = w2 + (long)(wave * NFN) * ns2;
+    const T* wr_w = wr + (long)(wave * NFN) * nsr;
     WRing<T, 4, PF> ring;
-    ring.prime(w1_w, ns1, nk1);
+    ring.prime(w1_w, ns1, nk1, NFN);
     const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
     // epilogue operands first (see est_tail_kernel): block1's bias, LayerNorm weights, time embedding, row mask
-    float bb[16], tv[16], gg[16], be[16], rm1[MH];
-    load16(p.b1 + col0, bb);
-    load16(p.tv + (long)b * p.tv_bs + col0, tv);
-    load16(p.g1 + col0, gg);
-    load16(p.be1 + col0, be);
+    float bb[CW], tv[CW], gg[CW], be[CW], rm1[MH];
+    loadn<CW>(p.b1 + col0, bb);
+    loadn<CW>(p.tv + (long)b * p.tv_bs + col0, tv);
+    loadn<CW>(p.g1 + col0, gg);
+    loadn<CW>(p.be1 + col0, be);
 #pragma unroll
     for (int i = 0; i < MH; ++i) {
         const int t = t0 - 16 + i * 16 + rl;
         rm1[i] = (t >= 0 && t < Tn) ? (rmk ? rmk[t] : 1.f) : 0.f;
     }
-    load_tile<T>(reinterpret_cast<const T*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, tid);
+    load_tile<T>(reinterpret_cast<const T*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, tid, 64 * NW);
     __syncthreads();
 
     // ---- block1: causal conv k3 (cin -> 256) + bias -> LayerNorm -> Mish -> * mask, + time embedding, * mask
     //      (flow/decoder.py:65-85 with matcha decoder.py:56-61) for rows t0-16 .. t0+BM-1 (conv2 needs 2 rows of halo)
     {
-        float4_t acc[MH][4];
+        float4_t acc[MH][NFN];
         zero_acc(acc);
-        stage_run<T, MH, 4, PF>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, acc);
-        float hv[MH][16];
+        stage_run<T, MH, NFN, PF>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, NFN, acc);
+        float hv[MH][CW];
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
-            to_rows(acc[i], patch, lane, hv[i]);
+            to_rows<NFN>(acc[i], patch, lane, hv[i]);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) hv[i][c] += bb[c];
+            for (int c = 0; c < CW; ++c) hv[i][c] += bb[c];
         }
-        layernorm_rows<MH>(hv, stats, gg, be, p.eps, wave, lane);
+        layernorm_rows<MH, CW, NW>(hv, stats, gg, be, p.eps, wave, lane);
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
             const int t = t0 - 16 + i * 16 + rl;
-            float o[16];
+            float o[CW];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int c = 0; c < CW; ++c) {
                 const float y = act_c<ACT_MISH, PRECISE>(hv[i][c], 0.f) * rm1[i];
                 o[c] = t >= 0 ? (y + tv[c]) * rm1[i] : 0.f;           // rows before the sequence start are conv padding
             }
-            store16_T<T>(reinterpret_cast<T*>(h1 + (i * 16 + rl) * P1) + col0, o);
+            storen_T<T, CW>(reinterpret_cast<T*>(h1 + (i * 16 + rl) * P1) + col0, o);
         }
     }
     // operands of block2's epilogue and of the residual conv's
-    float br[16];
-    load16(p.b2 + col0, bb);
-    load16(p.g2 + col0, gg);
-    load16(p.be2 + col0, be);
-    load16(p.br + col0, br);
+    float br[CW];
+    loadn<CW>(p.b2 + col0, bb);
+    loadn<CW>(p.g2 + col0, gg);
+    loadn<CW>(p.be2 + col0, be);
+    loadn<CW>(p.br + col0, br);
     __syncthreads();
     // ---- block2: causal conv k3 (256 -> 256) -> LayerNorm -> Mish -> * mask
-    float h2[MF][16];
+    float h2[MF][CW];
     {
-        float4_t acc[MF][4];
+        float4_t acc[MF][NFN];
         zero_acc(acc);
-        stage_run<T, MF, 4, PF>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, acc);
+        stage_run<T, MF, NFN, PF>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, NFN, acc);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            to_rows(acc[i], patch, lane, h2[i]);
+            to_rows<NFN>(acc[i], patch, lane, h2[i]);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) h2[i][c] += bb[c];
+            for (int c = 0; c < CW; ++c) h2[i][c] += bb[c];
         }
-        layernorm_rows<MF>(h2, stats, gg, be, p.eps, wave, lane);
+        layernorm_rows<MF, CW, NW>(h2, stats, gg, be, p.eps, wave, lane);
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) h2[i][c] = act_c<ACT_MISH, PRECISE>(h2[i][c], 0.f) * rm1[i + 1];
+            for (int c = 0; c < CW; ++c) h2[i][c] = act_c<ACT_MISH, PRECISE>(h2[i][c], 0.f) * rm1[i + 1];
     }
     // ---- + res_conv(x) (1x1) -> x (fp32 residual stream)
     {
-        if (p.next.wqkv) { load16(p.next.n1g + col0, gg); load16(p.next.n1b + col0, be); }
-        float4_t acc[MF][4];
+        if (p.next.wqkv) { loadn<CW>(p.next.n1g + col0, gg); loadn<CW>(p.next.n1b + col0, be); }
+        float4_t acc[MF][NFN];
         zero_acc(acc);
-        const T* wq0 = p.next.wqkv ? qkv_pass<T>(p.next.wqkv, wave, lane, 0) : nullptr;
-        stage_run<T, MF, 4, PF>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, acc);
+        const T* wq0 = p.next.wqkv ? qkv_pass<T, NW>(p.next.wqkv, wave, lane, 0) : nullptr;
+        stage_run<T, MF, NFN, PF>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, 4, acc);
         float* xw = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            float v[16];
-            to_rows(acc[i], patch, lane, v);
+            float v[CW];
+            to_rows<NFN>(acc[i], patch, lane, v);
             const int t = t0 + i * 16 + rl;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) h2[i][c] += v[c] + br[c];
-            if (t < Tn) store16(xw + (long)t * C + col0, h2[i]);
+            for (int c = 0; c < CW; ++c) h2[i][c] += v[c] + br[c];
+            if (t < Tn) storen<CW>(xw + (long)t * C + col0, h2[i]);
         }
     }
-    __syncthreads();                                   // every wave is done with ain / h1 (reused by ln_qkv)
-    if (p.next.wqkv) ln_qkv<T, MF, PF>(h2, gg, be, p.next, p.eps, h1, ain, patch, stats, ring, b, t0, Tn, wave, lane, tid);
+    __syncthreads();                                   // every wave is done with ain / h1 (h1 is reused by ln_qkv)
+    if (p.next.wqkv) ln_qkv<T, MF, PF, NW>(h2, gg, be, p.next, p.eps, h1, patch, stats, ring, b, t0, Tn, wave, lane);
 }
 
-template <typename T, int BM>
+template <typename T, int BM, int NW>
 size_t tail_lds() {
-    return (size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T)) + 4 * 16 * LDC * 4 + (size_t)BM * 16;
+    return (size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T)) + (size_t)NW * PATCH_FLOATS * 4 + (size_t)BM * NW * 4;
 }
-template <typename T, int BM>
+template <typename T, int BM, int NW>
 size_t resnet_lds(int cin) {
-    return (size_t)(BM + 18) * tile_pitch(cin, sizeof(T)) + (size_t)(BM + 16) * tile_pitch(256, sizeof(T)) + 4 * 16 * LDC * 4 +
-           (size_t)(BM + 16) * 16;
+    return (size_t)(BM + 18) * tile_pitch(cin, sizeof(T)) + (size_t)(BM + 16) * tile_pitch(256, sizeof(T)) + (size_t)NW * PATCH_FLOATS * 4 +
+           (size_t)(BM + 16) * NW * 4;
 }
 
 int check_next(const MmxEstNext& nx, int dtype, int T_) {
@@ -607,7 +634,9 @@ int check_next(const MmxEstNext& nx, int dtype, int T_) {
 
 }  // namespace
 
-extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int pf, hipStream_t stream) {
+// cfg = pf + 16 * waves: pf = k-steps of weight fragments a wave keeps in flight (2 / 4 / 8, 0 = default for the tile),
+// waves = 4 or 8 per workgroup (0 = default)
+extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int cfg, hipStream_t stream) {
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstTailParams& p = *pp;
     MMX_CHECK_ARG(p.ao && p.x && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.n3g && p.n3b && p.B > 0 && p.T > 0);
@@ -616,23 +645,31 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int p
     MMX_CHECK_ARG(((uintptr_t)p.ao % 16) == 0 && ((uintptr_t)p.x % 16) == 0);
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % 8 == 0 && p.act_bs % 8 == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
-#define TAIL(TT, BM, PF)                                                                                  \
+    const int pf = cfg & 15, nw = cfg >> 4;
+#define TAIL(TT, BM, PF, NW)                                                                              \
     do {                                                                                                   \
-        const size_t lds = tail_lds<TT, BM>();                                                             \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_tail_kernel<TT, BM, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        const size_t lds = tail_lds<TT, BM, NW>();                                                         \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_tail_kernel<TT, BM, PF, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
-    // ring depth by tile height (see WRing); the stage k-step counts here are 8 / 16 (bf16) and 16 / 32 (fp32)
-    // pf = 0: the default depth
     if (dtype == MMX_BF16) {
-        if (bm == 64) { if (pf == 4) TAIL(bf16_t, 64, 4); else if (pf == 0 || pf == 2) TAIL(bf16_t, 64, 2); else return MMX_EARG; }
-        else if (bm == 32) { if (pf == 2) TAIL(bf16_t, 32, 2); else if (pf == 0 || pf == 4) TAIL(bf16_t, 32, 4); else return MMX_EARG; }
-        else if (bm == 16 && (pf == 0 || pf == 8)) TAIL(bf16_t, 16, 8);
-        else return MMX_EARG;
+        if (bm == 64) {
+            if (nw == 4) { if (pf == 4) TAIL(bf16_t, 64, 4, 4); else TAIL(bf16_t, 64, 2, 4); }
+            else if (nw == 0 || nw == 8) TAIL(bf16_t, 64, 2, 8);
+            else return MMX_EARG;
+        } else if (bm == 32) {
+            if (nw == 8) { if (pf == 2) TAIL(bf16_t, 32, 2, 8); else TAIL(bf16_t, 32, 4, 8); }
+            else if (nw == 0 || nw == 4) { if (pf == 2) TAIL(bf16_t, 32, 2, 4); else TAIL(bf16_t, 32, 4, 4); }
+            else return MMX_EARG;
+        } else if (bm == 16) {
+            if (nw == 8) TAIL(bf16_t, 16, 4, 8);
+            else if (nw == 0 || nw == 4) TAIL(bf16_t, 16, 8, 4);
+            else return MMX_EARG;
+        } else return MMX_EARG;
     } else if (dtype == MMX_F32) {
-        if (bm == 32 && (pf == 0 || pf == 4)) TAIL(float, 32, 4);
-        else if (bm == 16 && (pf == 0 || pf == 8)) TAIL(float, 16, 8);
+        if (bm == 32 && (nw == 0 || nw == 4)) TAIL(float, 32, 4, 4);
+        else if (bm == 16 && (nw == 0 || nw == 4)) TAIL(float, 16, 8, 4);
         else return MMX_EARG;
     } else return MMX_EARG;
 #undef TAIL
@@ -640,7 +677,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int p
     return MMX_OK;
 }
 
-extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, int pf_req, hipStream_t stream) {
+extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, int cfg, hipStream_t stream) {
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstResnetParams& p = *pp;
     MMX_CHECK_ARG(p.a_in && p.x && p.w1 && p.w2 && p.wr && p.b1 && p.b2 && p.br && p.g1 && p.be1 && p.g2 && p.be2 && p.tv);
@@ -648,29 +685,38 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     MMX_CHECK_ARG(p.B > 0 && p.T > 0 && p.cin >= 64 && p.cin % 32 == 0 && p.cin <= 512 && p.lda >= p.cin && p.lda % 8 == 0 && p.a_bs % 8 == 0);
     MMX_CHECK_ARG(((uintptr_t)p.a_in % 16) == 0 && ((uintptr_t)p.x % 16) == 0 && p.x_bs % 4 == 0 && p.tv_bs % 4 == 0 && ((uintptr_t)p.tv % 16) == 0);
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
-#define RESN(TT, BM, PF)                                                                                  \
+    const int pf_req = cfg & 15, nw = cfg >> 4;
+#define RESN(TT, BM, PF, NW)                                                                              \
     do {                                                                                                   \
-        const size_t lds = resnet_lds<TT, BM>(p.cin);                                                      \
+        const size_t lds = resnet_lds<TT, BM, NW>(p.cin);                                                  \
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_resnet_kernel<TT, BM, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_resnet_kernel<TT, BM, PF, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
-        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(256), lds, stream, p); \
+        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF, NW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
     // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count
     // (conv k3 over cin, conv k3 over 256, 1x1 over cin, Q/K/V over 256); cin = 320 allows 2 (bf16) / 4 (fp32) only
     const int kb = dtype == MMX_BF16 ? 32 : 16;
-    const int want = pf_req > 0 ? pf_req : (bm == 16 ? 8 : 4);
+    const bool w8 = dtype == MMX_BF16 && (nw == 8 || (nw == 0 && bm == 64));
+    const int want = pf_req > 0 ? pf_req : (w8 ? (bm == 64 ? 2 : 4) : (bm == 16 ? 8 : 4));
     MMX_CHECK_ARG(want == 2 || want == 4 || want == 8);
     int pf = want;
     while (pf > 2 && ((3 * p.cin / kb) % pf || (p.cin / kb) % pf || (256 / kb) % pf)) pf /= 2;
-    MMX_CHECK_ARG((p.cin / kb) % 2 == 0);
+    MMX_CHECK_ARG((p.cin / kb) % 2 == 0 && (nw == 0 || nw == 4 || nw == 8));
     if (dtype == MMX_BF16) {
-        if (bm == 64) { if (pf >= 4) RESN(bf16_t, 64, 4); else RESN(bf16_t, 64, 2); }
-        else if (bm == 32) { if (pf >= 4) RESN(bf16_t, 32, 4); else RESN(bf16_t, 32, 2); }
-        else if (bm == 16) { if (pf == 8) RESN(bf16_t, 16, 8); else if (pf == 4) RESN(bf16_t, 16, 4); else RESN(bf16_t, 16, 2); }
-        else return MMX_EARG;
+        if (w8) {
+            if (bm == 64) RESN(bf16_t, 64, 2, 8);
+            else if (bm == 32) { if (pf >= 4) RESN(bf16_t, 32, 4, 8); else RESN(bf16_t, 32, 2, 8); }
+            else if (bm == 16) { if (pf >= 4) RESN(bf16_t, 16, 4, 8); else RESN(bf16_t, 16, 2, 8); }
+            else return MMX_EARG;
+        } else {
+            if (bm == 64) { if (pf >= 4) RESN(bf16_t, 64, 4, 4); else RESN(bf16_t, 64, 2, 4); }
+            else if (bm == 32) { if (pf >= 4) RESN(bf16_t, 32, 4, 4); else RESN(bf16_t, 32, 2, 4); }
+            else if (bm == 16) { if (pf == 8) RESN(bf16_t, 16, 8, 4); else if (pf == 4) RESN(bf16_t, 16, 4, 4); else RESN(bf16_t, 16, 2, 4); }
+            else return MMX_EARG;
+        }
     } else if (dtype == MMX_F32) {
-        if (bm == 16) { if (pf == 8) RESN(float, 16, 8); else if (pf == 4) RESN(float, 16, 4); else RESN(float, 16, 2); }
+        if (bm == 16 && (nw == 0 || nw == 4)) { if (pf == 8) RESN(float, 16, 8, 4); else if (pf == 4) RESN(float, 16, 4, 4); else RESN(float, 16, 2, 4); }
         else return MMX_EARG;
     } else return MMX_EARG;
 #undef RESN
