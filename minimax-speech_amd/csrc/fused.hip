@@ -655,8 +655,8 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     } while (0)
     if (dtype == MMX_BF16) {
         if (bm == 64) {
-            if (nw == 4) { if (pf == 4) TAIL(bf16_t, 64, 4, 4); else TAIL(bf16_t, 64, 2, 4); }
-            else if (nw == 0 || nw == 8) TAIL(bf16_t, 64, 2, 8);
+            if (nw == 0 || nw == 4) { if (pf == 4) TAIL(bf16_t, 64, 4, 4); else TAIL(bf16_t, 64, 2, 4); }
+            else if (nw == 8) TAIL(bf16_t, 64, 2, 8);
             else return MMX_EARG;
         } else if (bm == 32) {
             if (nw == 8) { if (pf == 2) TAIL(bf16_t, 32, 2, 8); else TAIL(bf16_t, 32, 4, 8); }
@@ -697,7 +697,9 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count
     // (conv k3 over cin, conv k3 over 256, 1x1 over cin, Q/K/V over 256); cin = 320 allows 2 (bf16) / 4 (fp32) only
     const int kb = dtype == MMX_BF16 ? 32 : 16;
-    const bool w8 = dtype == MMX_BF16 && (nw == 8 || (nw == 0 && bm == 64));
+    // 8 waves (two per SIMD) measured faster for the 64-row ResNet tile (50.6 vs 59.7 us at 14 336 rows); they need 17 KB
+    // more LDS for the per-wave patches, which the 512-channel input tile (up block) does not leave
+    const bool w8 = dtype == MMX_BF16 && (nw == 8 || (nw == 0 && bm == 64 && resnet_lds<bf16_t, 64, 8>(p.cin) <= 160 * 1024));
     const int want = pf_req > 0 ? pf_req : (w8 ? (bm == 64 ? 2 : 4) : (bm == 16 ? 8 : 4));
     MMX_CHECK_ARG(want == 2 || want == 4 || want == 8);
     int pf = want;
