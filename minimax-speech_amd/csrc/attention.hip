@@ -141,17 +141,13 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
 // v_mfma_f32_16x16x32_bf16; online softmax in registers (exp2 with log2e folded into the scale), row reductions
 // over the 16 lanes that share a query row via 4 xor-shuffles; P goes through a per-wave LDS patch (wave-local
 // ordering only) to turn the C-layout tile into the A-operand layout.
-// FP8 (BASELINE config 5 "fp8 MFMA attention"): Q, K and V^T are quantised to OCP e4m3 and P to e5m2 on the fly (bf16 in
-// HBM either way) and both products run on v_mfma_f32_16x16x32_{fp8_fp8, fp8_bf8}: half the LDS bytes per tile and per
+// FP8 (BASELINE config 5 "fp8 MFMA attention"): Q, K, V^T and P (scaled by 4) are quantised to OCP e4m3 on the fly (bf16 in
+// HBM either way) and both products run on v_mfma_f32_16x16x32_fp8_fp8: half the LDS bytes per tile and per
 // fragment read.  On gfx950 the non-scaled fp8 MFMA has the bf16 rate and a 64-wide head cannot fill the K = 128 of the
-// block-scaled form, so the gain is LDS traffic, not matrix throughput; the price is 3-bit (K, V, Q) / 2-bit (P) mantissas.
+// block-scaled form, so the gain is LDS traffic, not matrix throughput; the price is 3-bit mantissas.
 __device__ __forceinline__ unsigned pk_fp8x4(float a, float b, float c, float d) {
     int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-}
-__device__ __forceinline__ unsigned pk_bf8x4(float a, float b, float c, float d) {
-    int r = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
-    return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(c, d, r, true);
 }
 __device__ __forceinline__ uint2 bf16x8_to_fp8(uint4 v) {      // 8 bf16 -> 8 e4m3 bytes
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -346,17 +342,25 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 m_use = m_safe;
             }
             float rs = 0.f;
+            // FP8: P is stored as e4m3 scaled by 4 (values reach 64 under the lazy rescale, e4m3 holds 448; the small end
+            // then goes down to 2^-11) - the scale cancels because the denominator sums the same scaled values
+            const float m_exp = FP8 ? m_use - 2.0f : m_use;
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][0], sc2, -m_use));
-                float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][1], sc2, -m_use));
-                float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][2], sc2, -m_use));
-                float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][3], sc2, -m_use));
-                rs += (p0 + p1) + (p2 + p3);
+                float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][0], sc2, -m_exp));
+                float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][1], sc2, -m_exp));
+                float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][2], sc2, -m_exp));
+                float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][3], sc2, -m_exp));
                 // 4 consecutive keys of query l16 -> one 8-byte write into the row-major [q][key] patch
                 if constexpr (FP8) {
-                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(Pw) + (mf * 16 + l16) * LD8 + nf * 16 + 4 * g) = pk_bf8x4(p0, p1, p2, p3);
+                    // the denominator sums the ROUNDED probabilities (what the PV product multiplies): a 3-bit mantissa
+                    // rounds a row of similar values all the same way, and an unrounded sum would leave that as a bias
+                    const unsigned pk8 = pk_fp8x4(p0, p1, p2, p3);
+                    rs += (__builtin_amdgcn_cvt_f32_fp8(pk8, 0) + __builtin_amdgcn_cvt_f32_fp8(pk8, 1)) +
+                          (__builtin_amdgcn_cvt_f32_fp8(pk8, 2) + __builtin_amdgcn_cvt_f32_fp8(pk8, 3));
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(Pw) + (mf * 16 + l16) * LD8 + nf * 16 + 4 * g) = pk8;
                 } else {
+                    rs += (p0 + p1) + (p2 + p3);
                     uint2 pk;
                     pk.x = pack_bf16x2(p0, p1);
                     pk.y = pack_bf16x2(p2, p3);
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                     const long bv = *reinterpret_cast<const long*>(reinterpret_cast<const char*>(Vs[buf]) + (df * 16 + l16) * LD8 + ks * 32 + 8 * g);
 #pragma unroll
                     for (int mf = 0; mf < MF; ++mf)
-                        o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bv, ap8[mf][ks], o[mf][df], 0, 0, 0);
+                        o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bv, ap8[mf][ks], o[mf][df], 0, 0, 0);
                 }
         } else {
         short8_t ap[MF][2];                            // lane (q = l16, g): P[q][ks*32 + 8g .. +7]

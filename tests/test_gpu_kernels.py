@@ -203,13 +203,13 @@ def test_attn_flash_bf16(env, T, chunk, q_begin, fp8):
     s = s.masked_fill(~vis[:, None], float("-inf"))
     ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, H * D)
     err = rel_err(out.cpu()[:, q_begin:], ref[:, q_begin:])
+    # fp8: e4m3 Q / K / V / P (3-bit mantissas): requirement 10 % of max |ref| at the worst element, 6 % of the RMS overall
+    assert err < (1e-1 if fp8 else 2e-2), err
     if fp8:
-        print(f"fp8 flash T={T} chunk={chunk} q_begin={q_begin}: max abs err / max |ref| = {err:.3e}")
-    # fp8: e4m3 Q / K / V (3-bit mantissa), e5m2 P (2-bit): requirement 15 % of max |ref| at the worst element, 6 % on average
-    assert err < (1.5e-1 if fp8 else 2e-2), err
-    if fp8:
-        mean = float((out.cpu()[:, q_begin:].float() - ref[:, q_begin:]).abs().mean() / ref[:, q_begin:].abs().mean())
-        assert mean < 6e-2, mean
+        d = out.cpu()[:, q_begin:].float() - ref[:, q_begin:]
+        rms = float(d.pow(2).mean().sqrt() / ref[:, q_begin:].pow(2).mean().sqrt())
+        print(f"fp8 flash T={T} chunk={chunk} q_begin={q_begin}: max abs err / max |ref| = {err:.3e}, rms err / rms ref = {rms:.3e}")
+        assert rms < 6e-2, rms
     assert float(out[:, :q_begin].abs().max() if q_begin else 0.0) == 0.0
 
 

@@ -16,7 +16,7 @@ for k in agg:
     if not any(s in k for s in keep):
         continue
     n = max(cnt[k].values())
-    if n < 20:
+    if n < 3:
         continue
     print(k, "dispatches", n)
     for c in sorted(agg[k]):
