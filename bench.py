@@ -231,10 +231,15 @@ def main():
     ap.add_argument("--flow-workers", type=int, default=2, help="host threads / streams solving flow groups concurrently")
     ap.add_argument("--poll-every", type=int, default=8, help="decode steps between two polls of the finished flags")
     ap.add_argument("--hold-steps", type=int, default=40, help="decode steps a finished utterance waits for a fuller flow group")
+    ap.add_argument("--gqa-min-batch", type=int, default=None, help="decode batches of at least this size use the GQA-shared attention kernel")
+    ap.add_argument("--tail-active", type=int, default=0, help="with at most this many sequences still decoding, finished utterances go to an idle flow worker at once")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
     global ATTN
     ATTN = a.attn
+    if a.gqa_min_batch is not None:
+        from mmx.llm import LlmEngine
+        LlmEngine.gqa_min_batch = a.gqa_min_batch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -297,7 +302,7 @@ def main():
                     first_chunk_ms.append((time.perf_counter() - t_in) * 1e3)
                 n += w.shape[-1]
             return n
-        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps, poll_every=a.poll_every)
+        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps, poll_every=a.poll_every, tail_active=a.tail_active)
         if world > 1:                                              # the path's one exchange step (RCCL all-gather)
             gather_audio([w.cpu() for w in wavs] if rehearse else wavs, mine, len(lens_all), max_samples)
         return sum(w.shape[-1] for w in wavs)

@@ -215,7 +215,9 @@ int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, in
 /* Single-token decode: RoPE(q), RoPE(k_new), KV append and causal GQA attention in ONE launch per layer
  * (same arithmetic as mmx_rope_kv_store + mmx_paged_attn with rows = 1).  qkv fp32 [B][ldqkv], out T [B][ldo].
  * rope_tab (optional, fp32 [max_pos][D] = cos | sin per position, as HF's rotary embedding computes them) replaces
- * the in-kernel cosf/sinf of pos * inv_freq.  out_packed: write out in the MMX_OUT_PACKED order (K = Hq*D). */
+ * the in-kernel cosf/sinf of pos * inv_freq.  out_packed: bit 0 = write out in the MMX_OUT_PACKED order (K = Hq*D);
+ * bit 1 = use the one-workgroup-per-query-head kernel even where the GQA-shared one applies (bf16, page = 16, Hq = 7 Hkv:
+ * one workgroup per kv head serves its 7 query heads, Q K^T on the MFMA with the queries split into bf16 hi + lo). */
 int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                     const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
                     float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream);

@@ -648,18 +648,256 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
         out[OPK ? act_packed_index<T>(b, h * D + tid, Hq * D) : (long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
     }
 }
+
+// GQA-shared decode attention (bf16 build): ONE workgroup per (sequence, kv head) serves all G query heads of the group,
+// so every cached K / V row is read once (the per-head kernel above reads it G = 7 times, from L2 after the first, and
+// needs 7 x the workgroups: 448 on 256 CUs at batch 32 - two rounds).
+//   * S^T = K Q^T on v_mfma_f32_16x16x32_bf16: the A operand is a 16-key page straight from HBM (lane (key, g) holds 8
+//     consecutive channels = one 16-byte load, no LDS staging); the B operand is the G roped queries (rows G..15 zero),
+//     split into bf16 hi + lo so the product keeps fp32-grade queries; C layout: lane (head, g) holds 4 keys of a page.
+//   * page t goes to wave t % 4; a wave holds up to 8 pages (128 keys) of K and V in registers per round, all loads
+//     in flight before the first MFMA; online softmax per wave and round (one max / rescale per 128 keys).
+//   * P V on the VALU, shared across heads: lane (key sub-row, 8-channel chunk) loads 16 bytes of a V row once and
+//     feeds G accumulators; P reaches those lanes through a wave-private LDS patch [key][8 heads].
+//   * the 4 waves x 8 key sub-rows are merged once through LDS.
+template <bool OPK, int G>
+__global__ __launch_bounds__(256) void decode_attn_gqa_kernel(
+    const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
+    const float* __restrict__ rope_tab, const int32_t* __restrict__ pos, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+    const int32_t* __restrict__ block_table, int max_pages, float scale, bf16_t* __restrict__ out, long ldo, int nseq) {
+    constexpr int D = 64, HALF = 32, PAGE = 16, NS = 8;             // NS page slots per wave and round
+    static_assert(G <= 8, "one 8-float row of P per key");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* qh = reinterpret_cast<bf16_t*>(smem);                    // [16][D] rope(q) * scale * log2(e), high part
+    bf16_t* ql = qh + 16 * D;                                        // [16][D] low part
+    bf16_t* kn = ql + 16 * D;                                        // [D] new key
+    bf16_t* vn = kn + D;                                             // [D] new value
+    float* Pw = reinterpret_cast<float*>(vn + D);                    // [4 waves][NS*16 keys][8 heads]
+    float* Aw = Pw + 4 * NS * 16 * 8;                                // [4][8] rescale factor of the round
+    float* gm = Aw + 32;                                             // [4][8] wave max
+    float* gl = gm + 32;                                             // [4][8] wave sum
+    float* part = gl + 32;                                           // [4 waves * 8 sub-rows][G][D]
+    int* bts = reinterpret_cast<int*>(part + 32 * G * D);            // [max_pages]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
+    const int32_t* bt = block_table + (long)b * max_pages;
+    const int p = pos[b];
+    const int NT = p / PAGE + 1;                                     // pages that hold keys 0 .. p
+    for (int i = tid; i < NT; i += 256) bts[i] = bt[i];
+    for (int i = tid; i < 2 * 16 * D / 2; i += 256) reinterpret_cast<unsigned*>(qh)[i] = 0u;       // rows G..15 of qh / ql
+    __syncthreads();
+    const float* src = qkv + (long)b * ldqkv;
+    const float sc2 = scale * 1.44269504088896341f;
+    {
+        // tid < G*32: query head tid/32, channel pair (d, d+32); the next 32 threads rope the new key
+        const int which = tid >> 5, d = tid & 31;
+        if (which <= G) {
+            const float* x = src + (which < G ? (hk * G + which) * D : (Hq + hk) * D);
+            float c, s;
+            if (rope_tab) {
+                c = rope_tab[(long)p * D + d];
+                s = rope_tab[(long)p * D + HALF + d];
+            } else {
+                const float ang = (float)p * inv_freq[d];
+                c = cosf(ang);
+                s = sinf(ang);
+            }
+            const float y0 = x[d] * c - x[d + HALF] * s, y1 = x[d + HALF] * c + x[d] * s;
+            if (which < G) {
+                const float a0 = y0 * sc2, a1 = y1 * sc2;
+                const bf16_t h0 = f2bf(a0), h1 = f2bf(a1);
+                qh[which * D + d] = h0;
+                qh[which * D + d + HALF] = h1;
+                ql[which * D + d] = f2bf(a0 - bf2f(h0));
+                ql[which * D + d + HALF] = f2bf(a1 - bf2f(h1));
+            } else {
+                kn[d] = f2bf(y0);
+                kn[d + HALF] = f2bf(y1);
+            }
+        }
+        if (tid < D) vn[tid] = f2bf(src[(Hq + Hkv + hk) * D + tid]);
+    }
+    __syncthreads();
+    if (tid < D) {                                                   // append the new token to the cache
+        const long o = (((long)bts[p / PAGE] * Hkv + hk) * PAGE + p % PAGE) * D + tid;
+        kc[o] = kn[tid];
+        vc[o] = vn[tid];
+    }
+    short8_t bqh[2], bql[2];                                         // B operand: lane (head l16, g) -> channels ks*32 + 8g ..
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bqh[ks] = *reinterpret_cast<const short8_t*>(qh + l16 * D + ks * 32 + 8 * g);
+        bql[ks] = *reinterpret_cast<const short8_t*>(ql + l16 * D + ks * 32 + 8 * g);
+    }
+    const int ksub = lane >> 3, dc = lane & 7;                       // P V role: key sub-row (0..7), channel chunk
+    const int tp = p / PAGE, rp = p % PAGE;                          // where the new token sits
+    float* Pme = Pw + wave * NS * 16 * 8;
+    float m_run = -INFINITY, l_part = 0.f;                           // lane (head l16, g): running max, partial sum
+    typedef __attribute__((ext_vector_type(2))) float float2_t;
+    float2_t acc[G][4];
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[h][e] = float2_t{0.f, 0.f};
+
+    for (int r0 = 0; r0 < NT; r0 += 4 * NS) {
+        if (r0 + wave >= NT) break;                                  // wave-uniform: no page left for this wave
+        uint4 rk[NS][2], rv[NS][2];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int t = r0 + 4 * i + wave;
+            if (t < NT) {
+                const long base = ((long)bts[t] * Hkv + hk) * PAGE * D;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) rk[i][ks] = *reinterpret_cast<const uint4*>(kc + base + l16 * D + ks * 32 + 8 * g);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) rv[i][hf] = *reinterpret_cast<const uint4*>(vc + base + (ksub + 8 * hf) * D + dc * 8);
+            }
+        }
+        float4_t sacc[NS];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int t = r0 + 4 * i + wave;
+            sacc[i] = float4_t{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < NT) {
+                if (t == tp) {                                       // the new token's row comes from LDS (its cache write is not ordered with these loads)
+                    if (l16 == rp) {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) rk[i][ks] = *reinterpret_cast<const uint4*>(kn + ks * 32 + 8 * g);
+                    }
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        if (ksub + 8 * hf == rp) rv[i][hf] = *reinterpret_cast<const uint4*>(vn + dc * 8);
+                        // rows beyond the new token have P = 0 but hold whatever the page held: keep NaN / inf out
+                        if (ksub + 8 * hf > rp) rv[i][hf] = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+                float4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const short8_t ak = __builtin_bit_cast(short8_t, rk[i][ks]);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bqh[ks], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bql[ks], c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = (t * PAGE + 4 * g + r <= p) ? c[r] : -INFINITY;
+                    sacc[i][r] = x;
+                    bm = fmaxf(bm, x);
+                }
+            }
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float m_new = fmaxf(m_run, bm);                        // finite: the wave's first page has a key <= p
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (r0 + 4 * i + wave < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = __builtin_amdgcn_exp2f(sacc[i][r] - m_new);
+                    rs += pj;
+                    if (l16 < 8) Pme[(i * 16 + 4 * g + r) * 8 + l16] = pj;
+                }
+            }
+        }
+        l_part = l_part * alpha + rs;
+        if (l16 < 8 && g == 0) Aw[wave * 8 + l16] = alpha;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const float4 a0 = *reinterpret_cast<const float4*>(Aw + wave * 8), a1 = *reinterpret_cast<const float4*>(Aw + wave * 8 + 4);
+            const float al[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int h = 0; h < G; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[h][e] *= al[h];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (r0 + 4 * i + wave < NT) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float* pr = Pme + (i * 16 + ksub + 8 * hf) * 8;
+                    const float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
+                    const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                    const unsigned w[4] = {rv[i][hf].x, rv[i][hf].y, rv[i][hf].z, rv[i][hf].w};
+                    float2_t vv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] = float2_t{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)};
+#pragma unroll
+                    for (int h = 0; h < G; ++h) {
+                        const float2_t ph = {pv[h], pv[h]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[h][e] = __builtin_elementwise_fma(ph, vv[e], acc[h][e]);   // v_pk_fma_f32
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // Pme / Aw are rewritten by the next round
+        __builtin_amdgcn_wave_barrier();
+    }
+    l_part += __shfl_xor(l_part, 16, 64);
+    l_part += __shfl_xor(l_part, 32, 64);
+    if (l16 < 8 && g == 0) { gm[wave * 8 + l16] = m_run; gl[wave * 8 + l16] = l_part; }
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        float* pp = part + ((long)(wave * 8 + ksub) * G + h) * D + dc * 8;
+        *reinterpret_cast<float4*>(pp) = make_float4(acc[h][0].x, acc[h][0].y, acc[h][1].x, acc[h][1].y);
+        *reinterpret_cast<float4*>(pp + 4) = make_float4(acc[h][2].x, acc[h][2].y, acc[h][3].x, acc[h][3].y);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * D; idx += 256) {
+        const int h = idx / D, d = idx % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, gm[w * 8 + h]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float wt = __builtin_amdgcn_exp2f(gm[w * 8 + h] - M);  // a wave without pages: exp2(-inf) = 0
+            L += gl[w * 8 + h] * wt;
+            float sacc2 = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) sacc2 += part[((long)(w * 8 + k2) * G + h) * D + d];
+            o += sacc2 * wt;
+        }
+        const int col = (hk * G + h) * D + d;
+        out[OPK ? act_packed_index<bf16_t>(b, col, Hq * D) : (long)b * ldo + col] = f2bf(o / L);
+    }
+}
 extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                                const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages,
                                int page, float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream) {
     MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
-    MMX_CHECK_ARG(out_packed == 0 || out_packed == 1);
+    MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 3);
+    const bool gqa_shared = !(out_packed & 2);         // bit 1: force the per-head kernel (A/B measurements, tests)
+    out_packed &= 1;
     const size_t max_ctx = (size_t)max_pages * page;
     (void)max_ctx;
     size_t lds = (3 * 64 + 2 * 32 + 32 * 64 + (size_t)max_pages) * 4;
     MMX_CHECK_ARG(lds <= 160 * 1024);
     dim3 grid(8 * ((Hkv * B + 7) / 8) * (Hq / Hkv));
 #define DA(T, OPK) hipLaunchKernelGGL((decode_attn_kernel<T, OPK>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B)
-    if (dtype == MMX_BF16) { if (out_packed) DA(bf16_t, true); else DA(bf16_t, false); }
+    if (dtype == MMX_BF16 && page == 16 && Hq == 7 * Hkv && gqa_shared) {
+        const size_t lds2 = (2 * 16 * 64 + 2 * 64) * 2 + (4 * 8 * 16 * 8 + 3 * 32 + 32 * 7 * 64 + (size_t)max_pages) * 4;
+        MMX_CHECK_ARG(lds2 <= 160 * 1024);
+        if (lds2 > 64 * 1024) {
+            static bool raised[2] = {false, false};                  // idempotent: racing first calls set the same value
+            if (!raised[out_packed]) {
+                const void* fn = out_packed ? (const void*)decode_attn_gqa_kernel<true, 7> : (const void*)decode_attn_gqa_kernel<false, 7>;
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return -1000 - (int)e;
+                raised[out_packed] = true;
+            }
+        }
+#define DG(OPK) hipLaunchKernelGGL((decode_attn_gqa_kernel<OPK, 7>), dim3(Hkv * B), dim3(256), lds2, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, scale, (bf16_t*)out, ldo, B)
+        if (out_packed) DG(true); else DG(false);
+    } else if (dtype == MMX_BF16) { if (out_packed) DA(bf16_t, true); else DA(bf16_t, false); }
     else if (dtype == MMX_F32) { if (out_packed) DA(float, true); else DA(float, false); }
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();

@@ -48,6 +48,10 @@ class PageAllocator:
 
 
 class LlmEngine:
+    # decode attention: batches of at least this many sequences use the GQA-shared kernel (one workgroup per kv head serving
+    # its 7 query heads), smaller ones the per-head kernel (more workgroups for the few sequences there are)
+    gqa_min_batch = 1 << 30
+
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
                  prefix="llm.model.model", share_from=None, kv_pages=None):
@@ -166,7 +170,8 @@ class LlmEngine:
                             eps=self.eps, epi=0, out_f32=qkv, x_packed=pk and not first)
             if rows == 1:
                 ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
-                                Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, out_packed=pk)
+                                Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, out_packed=pk,
+                                per_head=B < self.gqa_min_batch)
             else:
                 ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=rows,
                                   Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)

@@ -274,10 +274,12 @@ def paged_attn(q, pos, kc, vc, block_table, out, *, B, rows, Hq, Hkv, page, dtyp
                                 i64(Hq * 64), i64(rows * Hq * 64), dtype, stream()), "mmx_paged_attn")
 
 
-def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None, out_packed=False):
+def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None, out_packed=False,
+                per_head=False):
+    """per_head: the one-workgroup-per-query-head kernel even where the GQA-shared one applies (measurements, tests)."""
     check(load().mmx_decode_attn(_p(qkv), i64((Hq + 2 * Hkv) * 64), B, Hq, Hkv, 64, _p(inv_freq), _p(rope_tab), _p(pos), _p(kc),
                                  _p(vc), _p(block_table), block_table.shape[1], page, C.c_float(0.125), _p(out),
-                                 i64(Hq * 64), dtype, int(out_packed), stream()), "mmx_decode_attn")
+                                 i64(Hq * 64), dtype, int(bool(out_packed)) | (2 if per_head else 0), stream()), "mmx_decode_attn")
 
 
 def swiglu(gu, out, *, rows, I, dtype):

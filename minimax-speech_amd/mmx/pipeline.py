@@ -216,7 +216,7 @@ class TtsEngine:
 
     @torch.no_grad()
     def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=(2, 2, 4, 8), max_pad_ratio=2.0,
-                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=40) -> List[torch.Tensor]:
+                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=40, tail_active=0) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
         conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
@@ -226,7 +226,10 @@ class TtsEngine:
         hold_steps > 0: a finished utterance waits at most that many decode steps for companions of similar length;
         then its (partial) group is issued, so the flow work of the long utterances is not left for after the last
         token (the rule counts decode steps, not wall time: the schedule, and with it the set of captured plans, is
-        the same from run to run)."""
+        the same from run to run).
+        tail_active > 0: once at most that many sequences are still decoding, a finished utterance no longer waits for
+        companions when a flow worker is (predicted) idle - the decode loop is the critical path, and whatever the last
+        utterances still have to do after their last token is what the step ends on."""
         import queue
         import threading
         from .llm import ST_FIN, ST_NOUT
@@ -332,12 +335,13 @@ class TtsEngine:
             frames = {b: 2 * toks[b].numel() for b in pending}
             groups = self._groups(pending, frames, group_size, max_pad_ratio, frame_quantum, first=issued[0])
             sizes = group_size if isinstance(group_size, (list, tuple)) else [group_size]
+            now = steps_done[0] * STEP_MS
             if not final and groups:
                 want = sizes[min(issued[0] + len(groups) - 1, len(sizes) - 1)]
                 waited = steps_done[0] - min(arrived[b] for b in groups[-1])
-                if len(groups[-1]) < want and not (hold_steps > 0 and waited >= hold_steps):
+                rush = 0 < B - len(seen) <= tail_active and any(free_at[w] <= now for w in range(flow_workers))
+                if len(groups[-1]) < want and not (hold_steps > 0 and waited >= hold_steps) and not rush:
                     groups = groups[:-1]                         # keep a partial group open for later arrivals
-            now = steps_done[0] * STEP_MS
             assign = None
             if final and hold_steps > 0 and len(groups) == 1 and len(groups[0]) >= 2:
                 # last arrivals: longest first, each to the worker predicted to finish it first (the other worker may

@@ -338,6 +338,60 @@ def test_rope_kv_paged_attention_matches_oracle(env, dt):
             assert rel_err(out.cpu(), ref) < (2e-2 if dt else 2e-5), (step, b)
 
 
+@pytest.mark.parametrize("dt,per_head", [(0, False), (1, True), (1, False)])
+@pytest.mark.parametrize("ctx", [0, 5, 15, 16, 63, 300, 511, 512, 700])
+def test_decode_attn_one_token(env, dt, per_head, ctx):
+    """mmx_decode_attn (RoPE of q and the new k, KV append, causal GQA attention of ONE new token over a paged cache) vs
+    torch: the per-head kernel (both dtypes) and the GQA-shared MFMA kernel (bf16), row-major and packed output, context
+    lengths around the page (16) and round (512 keys) boundaries, shuffled pages, sequences of different length."""
+    from oracle import llm as OL
+    L, ops = env
+    g = torch.Generator().manual_seed(ctx + 3)
+    Hq, Hkv, D, page = 14, 2, 64, 16
+    B = 5
+    maxp = 64
+    tdt = torch.bfloat16 if dt else torch.float32
+    lens = [ctx, max(ctx - 7, 0), ctx // 2, ctx, min(ctx + 9, maxp * page - 1)]
+    perm = torch.randperm(B * maxp, generator=g).to(torch.int32)
+    bt = perm.reshape(B, maxp).contiguous().cuda()
+    kc = (torch.randn(B * maxp, Hkv, page, D, generator=g) * 0.7).to(tdt).cuda()
+    vc = torch.randn(B * maxp, Hkv, page, D, generator=g).to(tdt).cuda()
+    kc0, vc0 = kc.clone(), vc.clone()
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, generator=g).cuda()
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))).cuda()
+    pos = torch.tensor(lens, dtype=torch.int32).cuda()
+    ang = torch.arange(maxp * page, dtype=torch.float32)[:, None] * inv.cpu()[None, :]
+    tab = torch.cat([ang.cos(), ang.sin()], dim=1).contiguous().cuda()          # as LlmEngine builds it
+    for packed in (False, True):
+        kc.copy_(kc0)
+        vc.copy_(vc0)
+        out = torch.zeros(ops.packed_rows(B), Hq * D, device="cuda", dtype=tdt)
+        ops.decode_attn(qkv, inv, pos, kc, vc, bt, out, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=dt, out_packed=packed,
+                        per_head=per_head, rope_tab=tab)
+        got = ops.unpack_act(out, B, Hq * D, dt).float().cpu() if packed else out[:B].float().cpu()
+        for b in range(B):
+            n = lens[b]
+            rows = [(int(bt[b, j // page]), j % page) for j in range(n)]
+            kk = torch.stack([kc0[pg, :, r] for pg, r in rows], 1).float().cpu() if n else torch.zeros(Hkv, 0, D)
+            vv = torch.stack([vc0[pg, :, r] for pg, r in rows], 1).float().cpu() if n else torch.zeros(Hkv, 0, D)
+            x = qkv[b].cpu()
+            cos, sin = OL.rope_cos_sin(torch.tensor([n]), D, 1e6)
+            q = x[:Hq * D].view(Hq, 1, D)
+            kn = x[Hq * D:(Hq + Hkv) * D].view(Hkv, 1, D)
+            vn = x[(Hq + Hkv) * D:].view(Hkv, 1, D)
+            q = q * cos + OL.rotate_half(q) * sin
+            kn = kn * cos + OL.rotate_half(kn) * sin
+            kn, vn = kn.to(tdt).float(), vn.to(tdt).float()              # the cache holds them in the storage type
+            kk, vv = torch.cat([kk, kn], 1), torch.cat([vv, vn], 1)
+            kr, vr = kk.repeat_interleave(Hq // Hkv, 0), vv.repeat_interleave(Hq // Hkv, 0)
+            s = (q @ kr.transpose(-2, -1)) * D ** -0.5
+            ref = (torch.softmax(s, -1) @ vr).reshape(Hq * D)
+            assert rel_err(got[b], ref) < (1e-2 if dt else 2e-5), (packed, b, n)
+            pg, r = int(bt[b, n // page]), n % page
+            assert rel_err(kc[pg, :, r].float().cpu(), kn[:, 0]) < (1e-2 if dt else 1e-6)       # the append landed
+            assert torch.equal(vc[pg, :, r].float().cpu(), vn[:, 0])
+
+
 def test_sampler_matches_oracle(env):
     """Device sampler (log_softmax + RAS + EOS re-draw + bookkeeping) vs oracle.llm.sampling_ids_e on the same
     Philox noise: ids must be IDENTICAL."""

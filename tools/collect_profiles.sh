@@ -22,6 +22,8 @@ pmc() {         # name, counters, filter words, command...
 kstats bench python3 bench.py --steps 5 --warmup 2 --no-extras &&
 kstats longform python3 bench.py --workload longform --steps 2 --warmup 1 --no-cpu-baseline --no-extras &&
 kstats cfm8x896 python3 tools/prof_cfm.py 8 896 &&
+kstats cfm3x992 python3 tools/prof_cfm.py 3 992 &&
+kstats cfm1x992 python3 tools/prof_cfm.py 1 992 &&
 kstats dac python3 tools/prof_dac.py &&
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16" "FETCH_SIZE" "WRITE_SIZE"; do

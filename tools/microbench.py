@@ -150,7 +150,7 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "skinny":
             skinny_case(B, 4864, 896, 2, pk)
 
 
-def decode_attn_case(B, ctx, layers=6):
+def decode_attn_case(B, ctx, layers=6, per_head=False):
     """mmx_decode_attn (RoPE + KV append + GQA attention of one new token) at context length ctx, rotating over layers."""
     Hq, Hkv, D, page = 14, 2, 64, 16
     max_pages = 2048 // page
@@ -169,15 +169,16 @@ def decode_attn_case(B, ctx, layers=6):
         it[0] += 1
         l = it[0] % layers
         ops.decode_attn(qkv, inv_freq, pos, kc[l], vc[l], bt, out, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=1, rope_tab=tab,
-                        out_packed=B >= 4)
+                        out_packed=B >= 4, per_head=per_head)
     us = graph_time(fn, reps=48)
-    print(f"decode_attn B={B:3d} ctx={ctx:5d}: {us:7.2f} us", flush=True)
+    print(f"decode_attn {'per head  ' if per_head else 'GQA shared'} B={B:3d} ctx={ctx:5d}: {us:7.2f} us", flush=True)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "decode_attn":
     for B in (1, 16, 32):
         for ctx in (64, 300, 600, 1500):
-            decode_attn_case(B, ctx)
+            for ph in (True, False):
+                decode_attn_case(B, ctx, per_head=ph)
 
 
 def sampler_case(B, scale):
