@@ -96,20 +96,13 @@ def _event_time_graph(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def measure_flow_kernel(eng, n=8, T=896):
-    """Roofline of the kernel that dominates GPU time of the step (rocprofv3 kernel stats under profiles/): the
-    row-tile fused kernel of the estimator's transformer blocks (est_tail_kernel: attention-output projection +
-    residual -> LayerNorm -> FF1 + GELU -> FF2 + residual -> LayerNorm -> Q/K/V projection of the next block), at a
-    typical flow-group shape (n utterances x T frames, CFG pair -> M = 2nT rows).  Algorithmic FLOPs per launch =
-    2 * M * (512*256 + 256*1024 + 1024*256 + 256*1536) (SURVEY.md §8d: the linear part of a transformer block);
-    duration measured live with HIP events over a hipGraph of launches rotating over the mid blocks' weights (56
-    different 2 MB weight sets, as in the pipeline), on the launch stream; against the dense bf16 MFMA peak."""
+def _time_est_tail(fl, n, T):
+    """Average duration (us) of one est_tail launch at group shape (n utterances x T frames, CFG pair -> M = 2nT rows):
+    a hipGraph of 112 launches rotating over the 56 mid blocks' weights (2 MB each, as in the pipeline), timed with HIP
+    events on the launch stream.  Returns (us, rows per workgroup)."""
     from mmx import ops
-    fl = eng.flow
     dt = fl.dtype
-    assert dt == 1
     B, C = 2 * n, fl.C
-    M = B * T
     blocks = [w for st in fl.mid for w in st["blocks"]]
     Tp = ops.round_up(T, 8)
     ao = torch.randn(B, T, 512, device=fl.dev).to(fl.tdt)
@@ -123,16 +116,51 @@ def measure_flow_kernel(eng, n=8, T=896):
                            ldvt=Tp, vt_bs=512 * Tp)
         ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt)
 
-    us = _event_time_graph(one, 2 * len(blocks))
-    flops = 2.0 * M * (512 * C + C * 1024 + 1024 * C + C * 1536)
+    return _event_time_graph(one, 2 * len(blocks)), bm
+
+
+def measure_flow_kernel(eng, shapes):
+    """Roofline of the kernel family with the largest share of the step's GPU time (rocprofv3 kernel stats of this
+    command under profiles/): est_tail_kernel, the row-tile fused kernel of the estimator's transformer blocks
+    (attention-output projection + residual -> LayerNorm -> FF1 + GELU -> FF2 + residual -> LayerNorm -> Q/K/V
+    projection of the next block).  It is launched 560 times per flow group, at M = 2 n T rows for a group of n
+    utterances padded to T frames, so `achieved` is taken over the step's OWN launches: every distinct (n, T) of the
+    step's flow groups is timed live (HIP events around a hipGraph of 112 launches on the launch stream) and weighted by
+    how often the step launches it.  Algorithmic FLOPs per launch = 2 * (valid rows) * (512*256 + 256*1024 + 1024*256 +
+    256*1536) (the linear part of a transformer block; padded rows are not counted); `us_per_launch`
+    is the launch-weighted mean, comparable with the kernel's AverageNs in the committed rocprofv3 summary (there the
+    kernels run beside the decode loop).  `isolated_large` is the same kernel on a chip-filling launch (M = 14 336)."""
+    fl = eng.flow
+    assert fl.dtype == 1
+    per_row = 2.0 * (512 * fl.C + fl.C * 1024 + 1024 * fl.C + fl.C * 1536)
+    count = {}
+    for n, T, valid in shapes:
+        c = count.setdefault((n, T), [0, 0])
+        c[0] += 1
+        c[1] += valid
+    tot_us = tot_fl = tot_n = 0.0
+    tiles = set()
+    for (n, T), (cnt, valid) in sorted(count.items()):
+        us, bm = _time_est_tail(fl, n, T)
+        tiles.add(bm)
+        tot_us += cnt * us
+        tot_fl += per_row * 2 * valid
+        tot_n += cnt
+    us, flops = tot_us / tot_n, tot_fl / tot_n
     tfs = flops / (us * 1e-6) / 1e12
-    traffic = None
+    us_l, bm_l = _time_est_tail(fl, 8, 896)
+    tfs_l = per_row * 14336 / (us_l * 1e-6) / 1e12
+    traffic = traffic_l = None
     pj = os.path.join(ROOT, "profiles", "r02_pmc_flow.json")
     if os.path.exists(pj):
-        traffic = json.load(open(pj)).get(f"est_tail_bm{bm}_hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": f"est_tail_kernel<bf16, {bm}> (fused transformer-block tail, M={M} rows = {n} utterances x {T} frames x CFG pair)",
+        pm = json.load(open(pj))
+        traffic, traffic_l = pm.get("est_tail_bench_hbm_bytes_per_launch"), pm.get("est_tail_8x896_hbm_bytes_per_launch")
+    return {"bound": "mfma", "kernel": f"est_tail_kernel<bf16, {'|'.join(str(t) for t in sorted(tiles))} rows per workgroup> (fused transformer-block tail) over the "
+            f"{int(tot_n)} flow groups of this step ({len(count)} shapes, M = 2nT from {min(2 * n * T for n, T in count)} to {max(2 * n * T for n, T in count)} rows)",
             "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
-            "traffic": traffic, "flops_per_launch": flops, "us_per_launch": round(us, 3)}
+            "traffic": traffic, "flops_per_launch": round(flops), "us_per_launch": round(us, 3),
+            "isolated_large": {"kernel": f"est_tail_kernel<bf16, {bm_l}>, M = 14336 (8 utterances x 896 frames x CFG pair)", "achieved": round(tfs_l, 1),
+                               "frac": round(tfs_l / MFMA_BF16_PEAK_TFS, 4), "us_per_launch": round(us_l, 3), "traffic": traffic_l}}
 
 
 def cpu_baseline():
@@ -244,6 +272,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world > 1:                                          # N ranks share one host: no rank may take every core for torch's CPU pools
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     # MMX_BENCH_REHEARSE=1: multi-rank rehearsal on a ONE-GPU box - every rank uses cuda:0, collectives run on gloo
     # over host copies.  Exercises the launch contract, sharding, barriers and the gather; never use it for numbers.
     rehearse = bool(os.environ.get("MMX_BENCH_REHEARSE")) and world > 1
@@ -321,6 +351,10 @@ def main():
         step()
     for _ in range(a.warmup):
         step()
+    shape_log = []
+    flows = getattr(eng, "_flows", None) or ([eng.flow] if hasattr(eng, "flow") else [])
+    for fl in flows:                                       # the (n, T) of every flow group of the timed steps, for `roofline`
+        fl.shape_log = shape_log
     fence()
     t0 = time.perf_counter()
     samples = 0
@@ -328,6 +362,8 @@ def main():
         samples += step()
     fence()
     el = time.perf_counter() - t0
+    for fl in flows:
+        fl.shape_log = None
     if world > 1:
         t = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -357,7 +393,7 @@ def main():
                           "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
         if world == 1:
             out["roofline_lm"] = measure_lm_kernel(eng)
-            out["roofline"] = measure_flow_kernel(eng) if (dt == 1 and a.workload == "batch") else out["roofline_lm"]
+            out["roofline"] = measure_flow_kernel(eng, shape_log) if (dt == 1 and a.workload == "batch" and shape_log) else out["roofline_lm"]
             if a.workload == "batch" and not a.no_extras:
                 # extra keys, measured after the timed region: (1) BASELINE config 3 (one 10 s utterance) for the
                 # per-utterance RTF target (>= 10x real time); (2) the same config-4 share on the fp32 build, the build

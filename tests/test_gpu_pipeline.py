@@ -153,3 +153,45 @@ def test_config4_rank_share_full_size(case):
         err = (wf[b].cpu() - wav).abs().max().item()
         print(f"config-4 share, utterance {b} ({lens[b]} steps, {len(toks)} ids): fp32 waveform max abs err {err:.3e}")
         assert wf[b].shape == wav.shape and err <= WAV_TOL_F32, (b, err)
+
+
+def test_config5_long_form_streaming_full_size(case):
+    """BASELINE config 5 at full size: ONE 60 s utterance (1500 decode steps, 24-layer LM, captured decode graph), streamed
+    in 25-token hops with the estimator state cache (bf16).
+    (a) the concatenated chunks equal one offline DAC decode of the concatenated latents (exact DAC context per hop);
+    (b) the cached schedule equals the reference's schedule, which re-solves the whole prefix at every hop
+        (cli/model.py:341-352), to bf16 rounding;
+    (c) the fp8 MFMA attention variant: same token ids, waveform within a stated SNR of the bf16 stream."""
+    from mmx.pipeline import TtsEngine
+    N = 1500
+    text = torch.randint(0, 151936, (1, 290), generator=torch.Generator().manual_seed(6)).cuda()
+    emb = case["emb"].cuda()
+
+    def run(attn, cache):
+        eng = TtsEngine(case["llm_sd"], case["flow_sd"], case["dac_sd"], dtype=1, max_batch=1, max_ctx=2048, attn=attn)
+        lats = []
+        chunks = [c.reshape(-1) for c in eng.tts_stream(text, emb, seed=1, exact_steps=N, latents_out=lats, cache=cache)]
+        n_out = int(eng.llm.state[2, 0])
+        toks = eng.llm.out_tokens[0, :n_out].tolist()
+        wav, lat = torch.cat(chunks), torch.cat(lats, 0)
+        off = eng.dac.decode_time_major(lat.to(eng.dac.tdt).reshape(1, -1, 80).contiguous(), 1, lat.shape[0])[0, 0]
+        CR, nh = eng.dac.ctx_right, (n_out - 3) // 25
+        del eng
+        torch.cuda.empty_cache()
+        return wav, lat, off, toks, CR, nh
+
+    wav, lat, off, toks, CR, nh = run("bf16", True)
+    assert N - 20 <= len(toks) <= N and wav.shape[0] == len(toks) * 960 and lat.shape == (2 * len(toks), 80)
+    edge = (nh * 50 - CR) * 480
+    d = (wav - off).abs()
+    err = max(d[:edge - CR * 480].max().item(), d[edge:].max().item())
+    print(f"config 5 (60 s, {len(toks)} ids, {nh + 1} chunks): stream vs offline decode of the same latents {err:.3e}")
+    assert err < 2e-2 and torch.isfinite(wav).all()
+    wav_r, lat_r, _, toks_r, _, _ = run("bf16", False)
+    dl, dw = (lat - lat_r).abs().max().item(), (wav - wav_r).abs().max().item()
+    print(f"config 5: cached state vs prefix recompute: latents {dl:.3e}, waveform {dw:.3e}")
+    assert toks_r == toks and dw < 2e-2 and dl < 1.0
+    wav_8, _, _, toks_8, _, _ = run("fp8", True)
+    snr = _snr_db(wav, wav_8)
+    print(f"config 5: fp8 attention vs bf16 attention: waveform SNR {snr:.1f} dB, max abs diff {(wav - wav_8).abs().max().item():.3e}")
+    assert toks_8 == toks and torch.isfinite(wav_8).all() and snr > 10.0, snr

@@ -47,6 +47,22 @@ def main():
     ms = (time.perf_counter() - t0) / a.steps * 1e3
     print(f"decode loop alone, {a.per_gpu} utterances (max {max(lens)} steps), {a.dtype}: {ms:.1f} ms per step "
           f"({ms / max(lens):.3f} ms per decode step)", flush=True)
+    # host cost of issuing one decode step (one hipGraph replay) vs the GPU time of the step: how far the host thread
+    # of a rank is from being the bottleneck (8 ranks share one host)
+    z = torch.zeros(1, 0, dtype=torch.long, device="cuda")
+    xs = [eng.llm.build_lm_input(t, z, z) for t in texts]
+    n = 200
+    eng.llm.start(xs, [n + 8] * len(xs), [n + 8] * len(xs), seed=0)
+    eng.llm.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.llm.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"host issue time {(t1 - t0) / n * 1e6:.1f} us per decode step; GPU {(t2 - t0) / n * 1e6:.1f} us per decode step "
+          f"(batch {len(xs)})", flush=True)
 
 
 if __name__ == "__main__":
