@@ -119,7 +119,7 @@ def _time_est_tail(fl, n, T):
     return _event_time_graph(one, 2 * len(blocks)), bm
 
 
-def measure_flow_kernel(eng, shapes):
+def measure_flow_kernel(eng, shapes, steps=1):
     """Roofline of the kernel family with the largest share of the step's GPU time (rocprofv3 kernel stats of this
     command under profiles/): est_tail_kernel, the row-tile fused kernel of the estimator's transformer blocks
     (attention-output projection + residual -> LayerNorm -> FF1 + GELU -> FF2 + residual -> LayerNorm -> Q/K/V
@@ -156,7 +156,7 @@ def measure_flow_kernel(eng, shapes):
         pm = json.load(open(pj))
         traffic, traffic_l = pm.get("est_tail_bench_hbm_bytes_per_launch"), pm.get("est_tail_8x896_hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": f"est_tail_kernel<bf16, {'|'.join(str(t) for t in sorted(tiles))} rows per workgroup> (fused transformer-block tail) over the "
-            f"{int(tot_n)} flow groups of this step ({len(count)} shapes, M = 2nT from {min(2 * n * T for n, T in count)} to {max(2 * n * T for n, T in count)} rows)",
+            f"{int(tot_n) // max(1, steps)} flow groups of a step ({len(count)} shapes, M = 2nT from {min(2 * n * T for n, T in count)} to {max(2 * n * T for n, T in count)} rows)",
             "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
             "traffic": traffic, "flops_per_launch": round(flops), "us_per_launch": round(us, 3),
             "isolated_large": {"kernel": f"est_tail_kernel<bf16, {bm_l}>, M = 14336 (8 utterances x 896 frames x CFG pair)", "achieved": round(tfs_l, 1),
@@ -393,7 +393,7 @@ def main():
                           "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
         if world == 1:
             out["roofline_lm"] = measure_lm_kernel(eng)
-            out["roofline"] = measure_flow_kernel(eng, shape_log) if (dt == 1 and a.workload == "batch" and shape_log) else out["roofline_lm"]
+            out["roofline"] = measure_flow_kernel(eng, shape_log, a.steps) if (dt == 1 and a.workload == "batch" and shape_log) else out["roofline_lm"]
             if a.workload == "batch" and not a.no_extras:
                 # extra keys, measured after the timed region: (1) BASELINE config 3 (one 10 s utterance) for the
                 # per-utterance RTF target (>= 10x real time); (2) the same config-4 share on the fp32 build, the build
