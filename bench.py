@@ -9,6 +9,7 @@ RCCL all-gather of the generated audio.  Inputs are resident on the device befor
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -58,9 +59,14 @@ def measure_lm_kernel(eng, iters=240):
         run(l)
     g = torch.cuda.CUDAGraph()                  # same launch mechanism as the decode step (hipGraph replay)
     torch.cuda.synchronize()
-    with torch.cuda.graph(g):
-        for i in range(iters):
-            run(i % llm.n_layers)
+    gc.collect()                                # no cyclic collection inside a capture (mmx/flow.py: Graphed)
+    gc.disable()
+    try:
+        with torch.cuda.graph(g):
+            for i in range(iters):
+                run(i % llm.n_layers)
+    finally:
+        gc.enable()
     g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())
@@ -84,9 +90,14 @@ def _event_time_graph(fn, iters):
     fn()
     g = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
-    with torch.cuda.graph(g):
-        for i in range(iters):
-            fn(i)
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g):
+            for i in range(iters):
+                fn(i)
+    finally:
+        gc.enable()
     g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream())

@@ -321,15 +321,18 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                     }
                     mx = fmaxf(mx, x);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            mx *= sc2;
-            // lazy rescale (cdna_hip_programming.md T13): keep the old running max while it is at most 2^6 below the
-            // new one for EVERY query of the wave; p then reaches at most 64 (fine in bf16 / fp32 sums) and the O
-            // accumulators (AGPRs: a rescale costs a read + multiply + write per value) are left alone.
+            mx *= sc2;                                 // this LANE's maximum: keys 4g + r of the tile's four 16-key fragments
+            // lazy rescale (cdna_hip_programming.md T13): keep the old running max while every score of the wave is at
+            // most 2^6 above it; p then reaches at most 64 (fine in bf16 / fp32 sums) and the O accumulators (AGPRs: a
+            // rescale costs a read + multiply + write per value) are left alone.  The test needs no cross-lane maximum
+            // (each lane checks its own keys against the query's running max, one wave vote), so a steady-state tile has
+            // no shuffle at all (ds_bpermute round trips sat on the critical path of a one-wave-per-SIMD loop); the four
+            // lanes of a query agree on the maximum only when it moves.  m_run stays uniform over those four lanes.
             float m_use = m_run[mf];
             const bool grow = (mx - m_run[mf]) > 6.0f || m_run[mf] == -INFINITY;
             if (__any(grow)) {
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run[mf], mx);
                 const float m_safe = m_new == -INFINITY ? 0.f : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(m_run[mf] - m_safe);   // m_run = -inf -> 0
@@ -367,10 +370,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                     *reinterpret_cast<uint2*>(Pw + (mf * 16 + l16) * LD + nf * 16 + 4 * g) = pk;
                 }
             }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            l_run[mf] += rs;
-        };
+            l_run[mf] += rs;                           // per-lane partial sum (its own keys); the four lanes of a query are
+        };                                             // added up once, after the last tile
         if (need_mask) {
             softmax_tile(std::true_type{}, std::integral_constant<int, 0>{});
             if constexpr (MF > 1) softmax_tile(std::true_type{}, std::integral_constant<int, MF - 1>{});
@@ -414,6 +415,11 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
             }
         }
         __builtin_amdgcn_wave_barrier();               // the patch is rewritten in the next tile
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {                  // (all lanes: the shuffles come before the row guard)
+        l_run[mf] += __shfl_xor(l_run[mf], 16, 64);
+        l_run[mf] += __shfl_xor(l_run[mf], 32, 64);
     }
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
@@ -542,18 +548,24 @@ __global__ __launch_bounds__(256) void attn_flash_splitk_kernel(
                 }
                 mx = fmaxf(mx, x);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         mx *= sc2;
-        const float m_new = fmaxf(m_run, mx);
-        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
-        l_run *= alpha;
+        // as in attn_flash_kernel: the running max moves (with one cross-lane maximum) only when some score of the wave
+        // is more than 2^6 above it; a steady-state tile has no shuffle
+        float m_safe = m_run;
+        const bool grow = (mx - m_run) > 6.0f || m_run == -INFINITY;
+        if (__any(grow)) {
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            m_safe = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+            l_run *= alpha;
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
+            for (int df = 0; df < 4; ++df)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[df][r] *= alpha;
-        m_run = m_new;
+                for (int r = 0; r < 4; ++r) o[df][r] *= alpha;
+            m_run = m_new;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
@@ -567,9 +579,7 @@ __global__ __launch_bounds__(256) void attn_flash_splitk_kernel(
             pk.y = pack_bf16x2(p2, p3);
             *reinterpret_cast<uint2*>(Pw + l16 * LD + nf * 16 + 4 * g) = pk;
         }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run += rs;
+        l_run += rs;                                   // per-lane partial sum; added up over the query's four lanes below
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const short8_t ap0 = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 8 * g);
@@ -591,6 +601,8 @@ __global__ __launch_bounds__(256) void attn_flash_splitk_kernel(
     for (int df = 0; df < 4; ++df)
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[(wave * 16 + l16) * 65 + df * 16 + 4 * g + r] = o[df][r];
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
     if (g == 0) { pm[wave * 16 + l16] = m_run; pl[wave * 16 + l16] = l_run; }
     __syncthreads();
     {

@@ -10,6 +10,7 @@ projection is computed directly transposed (V^T = W_v X^T, same kernel with oper
 MFMA flash-attention kernel reads K row-major and V^T row-major without any transpose pass.
 A whole 10-step Euler solve (about 5 000 launches) is recorded once per shape into a hipGraph.
 """
+import gc
 import math
 from collections import OrderedDict
 from typing import Dict, Optional
@@ -59,8 +60,15 @@ def _prime_capture_state(dev):
     with torch.inference_mode(False):
         t = torch.zeros(1, device=f"cuda:{key}")
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            t.add_(1.0)
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()                                   # see Graphed.__call__
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                t.add_(1.0)
+        finally:
+            if gc_was_on:
+                gc.enable()
     _capture_primed[key] = (g, t)
 
 
@@ -83,8 +91,19 @@ class Graphed:
                 torch.cuda.current_stream().synchronize()
                 _prime_capture_state(torch.cuda.current_device())
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self.fn()
+                # Python's cyclic collector must not run inside the capture: if it finds an unreachable engine there, the
+                # destructors of that engine's recorded graphs run on this (capturing) thread, HIP refuses them, the
+                # error is thrown from a destructor and the process aborts.  Collect now, switch the collector off for
+                # the capture (torch.cuda.graph no longer collects by itself in this torch version).
+                gc_was_on = gc.isenabled()
+                gc.collect()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self.fn()
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 self.graph = g
         self.graph.replay()
 
