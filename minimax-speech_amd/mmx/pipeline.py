@@ -215,15 +215,19 @@ class TtsEngine:
                   f"cfm {c:.1f} ms, dac {d:.1f} ms", flush=True)
 
     @torch.no_grad()
-    def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=(2, 2, 4, 8), max_pad_ratio=2.0,
-                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=40, tail_active=0) -> List[torch.Tensor]:
+    def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=8, max_pad_ratio=2.0,
+                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=60, tail_active=0) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
         conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
         issued by a second host thread on a second HIP stream, so the latency-bound decode loop and the MFMA-bound
         flow overlap on the chip (the reference overlaps the same two stages with its llm_job thread,
         cli/model.py:332-335).  overlap=False runs the stages back to back.  No prompts (synthetic load).
-        hold_steps > 0: a finished utterance waits at most that many decode steps for companions of similar length;
+        group_size / hold_steps: a finished utterance waits at most hold_steps decode steps for up to group_size companions
+        of similar length.  Large groups pay twice: a launch of the fused flow kernels costs about the same from 500 to
+        8 000 rows (it is bound by every workgroup streaming the block's weights), so fewer, fuller groups are less GPU
+        work, and less flow work beside the decode loop makes the decode loop itself faster (measured, 32 utterances:
+        ramp 2,2,4,8 / hold 40: 718 ms per step, decode loop 617 ms; groups of 8 / hold 60: 703 ms, decode loop 577 ms);
         then its (partial) group is issued, so the flow work of the long utterances is not left for after the last
         token (the rule counts decode steps, not wall time: the schedule, and with it the set of captured plans, is
         the same from run to run).
@@ -302,7 +306,7 @@ class TtsEngine:
         issued = [0]
         arrived, steps_done = {}, [1]
         free_at = [0.0] * flow_workers
-        STEP_MS, GROUP_MS, FRAME_MS = 1.45, 45.0, 0.037
+        STEP_MS, GROUP_MS, FRAME_MS = 1.2, 28.0, 0.025          # fitted to MMX_TIMING=2 traces of the round-2 kernels
 
         cur = [self.llm, list(range(NS))]                           # active engine, slot -> utterance index
         queue = list(range(NS, B))                                  # utterances waiting for a slot
