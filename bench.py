@@ -285,7 +285,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if world > 1:                                          # N ranks share one host: no rank may take every core for torch's CPU pools
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or world
+        torch.set_num_threads(max(1, ncpu // world))
     # MMX_BENCH_REHEARSE=1: multi-rank rehearsal on a ONE-GPU box - every rank uses cuda:0, collectives run on gloo
     # over host copies.  Exercises the launch contract, sharding, barriers and the gather; never use it for numbers.
     rehearse = bool(os.environ.get("MMX_BENCH_REHEARSE")) and world > 1
