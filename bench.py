@@ -130,6 +130,44 @@ def _time_est_tail(fl, n, T):
     return _event_time_graph(one, 2 * len(blocks)), bm
 
 
+def measure_attn_kernel(eng, shapes, steps=1):
+    """The estimator's flash attention (attn_flash_kernel, as large a share of the step's GPU time as est_tail_kernel) over
+    the step's own flow-group shapes, measured like est_tail: a hipGraph of 56 launches per shape, HIP events on the launch
+    stream, launch-weighted.  Algorithmic FLOPs per launch = 4 * 64 * 8 heads * 2 (CFG pair) * sum_i T_i^2 over the group's
+    utterances (Q K^T and P V of the valid frames; padded rows and masked keys are not counted)."""
+    from mmx import ops
+    fl = eng.flow
+    count = {}
+    tot_us = tot_fl = tot_n = 0.0
+    for n, T, _, sq in shapes:
+        count.setdefault((n, T), [0, 0])[0] += 1
+        tot_fl += 4.0 * 64 * 8 * 2 * sq
+    for (n, T), (cnt, _) in sorted(count.items()):
+        B, Tp = 2 * n, ops.round_up(T, 8)
+        qk = torch.randn(B, T, 1024, device=fl.dev).to(fl.tdt)
+        vt = torch.randn(B, 512, Tp, device=fl.dev).to(fl.tdt)
+        ao = torch.empty(B, T, 512, device=fl.dev, dtype=fl.tdt)
+        km = torch.ones(B, T, device=fl.dev)
+        km[:, T - min(T // 8, 24):] = 0                 # a ragged group: the key mask path the pipeline runs
+        km[0] = 1
+
+        def one(i=0):
+            ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
+                                k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, keymask=km)
+
+        tot_us += cnt * _event_time_graph(one, 56)
+        tot_n += cnt
+    us, flops = tot_us / tot_n, tot_fl / tot_n
+    tfs = flops / (us * 1e-6) / 1e12
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "r02_pmc_flow.json")
+    if os.path.exists(pj):
+        traffic = json.load(open(pj)).get("attn_flash_bench_hbm_bytes_per_launch")
+    return {"bound": "mfma", "kernel": f"attn_flash_kernel (estimator attention, 8 heads x 64, bf16) over the {int(tot_n) // max(1, steps)} flow groups of a step",
+            "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
+            "traffic": traffic, "flops_per_launch": round(flops), "us_per_launch": round(us, 3)}
+
+
 def measure_flow_kernel(eng, shapes, steps=1):
     """Roofline of the kernel family with the largest share of the step's GPU time (rocprofv3 kernel stats of this
     command under profiles/): est_tail_kernel, the row-tile fused kernel of the estimator's transformer blocks
@@ -145,7 +183,7 @@ def measure_flow_kernel(eng, shapes, steps=1):
     assert fl.dtype == 1
     per_row = 2.0 * (512 * fl.C + fl.C * 1024 + 1024 * fl.C + fl.C * 1536)
     count = {}
-    for n, T, valid in shapes:
+    for n, T, valid, _ in shapes:
         c = count.setdefault((n, T), [0, 0])
         c[0] += 1
         c[1] += valid
@@ -410,6 +448,8 @@ def main():
         if world == 1:
             out["roofline_lm"] = measure_lm_kernel(eng)
             out["roofline"] = measure_flow_kernel(eng, shape_log, a.steps) if (dt == 1 and a.workload == "batch" and shape_log) else out["roofline_lm"]
+            if dt == 1 and a.workload == "batch" and shape_log:
+                out["roofline_attn"] = measure_attn_kernel(eng, shape_log, a.steps)
             if a.workload == "batch" and not a.no_extras:
                 # extra keys, measured after the timed region: (1) BASELINE config 3 (one 10 s utterance) for the
                 # per-utterance RTF target (>= 10x real time); (2) the same config-4 share on the fp32 build, the build

@@ -133,7 +133,7 @@ class FlowEngine:
         cv = lambda k: ops.pack_conv1d(f(k), dt)
         self._pe, self._plans, self._vt = OrderedDict(), OrderedDict(), {}
         self.plan_budget_bytes = 16 << 30           # recorded Euler solves kept alive (LRU); see _cfm_plan
-        self.shape_log = None                       # a list collects (n, T, valid frames) of every cfm_batch call (bench.py)
+        self.shape_log = None                       # a list collects (n, T, sum T_i, sum T_i^2) of every cfm_batch call (bench.py)
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -887,7 +887,7 @@ class FlowEngine:
         T = ops.round_up(max(Ts), pad_to)
         masked = any(t != T for t in Ts)
         if self.shape_log is not None:                     # measurement hook (bench.py): group shapes of a run
-            self.shape_log.append((n, T, sum(Ts)))
+            self.shape_log.append((n, T, sum(Ts), sum(t * t for t in Ts)))
         P = self._cfm_plan(n, T, streaming, masked)
         if masked:
             P.mu[:n].zero_()
