@@ -147,13 +147,17 @@ def measure_attn_kernel(eng, shapes, steps=1):
         qk = torch.randn(B, T, 1024, device=fl.dev).to(fl.tdt)
         vt = torch.randn(B, 512, Tp, device=fl.dev).to(fl.tdt)
         ao = torch.empty(B, T, 512, device=fl.dev, dtype=fl.tdt)
-        km = torch.ones(B, T, device=fl.dev)
-        km[:, T - min(T // 8, 24):] = 0                 # a ragged group: the key mask path the pipeline runs
-        km[0] = 1
+        # the group as the step ran it: utterance lengths spread evenly from the group's mean down and up to T (the log
+        # keeps n, T, sum T_i, sum T_i^2, not every length), passed as klen like FlowEngine does for a padded group
+        valid = sum(v for n_, T_, v, _ in shapes if (n_, T_) == (n, T)) / cnt
+        lo = max(1, int(2 * valid / n - T))
+        lens = [int(round(lo + (T - lo) * i / max(1, n - 1))) for i in range(n)]
+        lens[-1] = T
+        klen = torch.tensor(lens * 2, dtype=torch.int32, device=fl.dev)
 
         def one(i=0):
             ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
-                                k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, keymask=km)
+                                k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, klen=(klen if n > 1 else None))
 
         tot_us += cnt * _event_time_graph(one, 56)
         tot_n += cnt

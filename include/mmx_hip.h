@@ -147,6 +147,10 @@ int mmx_cfg_euler(float* x, const float* d_cond, const float* d_uncond, float cf
  *   cached K / V.
  * mmx_attn_flash_bf16: the MFMA flash-attention kernel for the same contract without rel-pos, bf16,
  *   D = 64, V given TRANSPOSED as vt[b][h*D + d][t] (ldvt elements per row, zero padded).
+ *   klen (NULL = none): int32 [B], the number of valid keys of each batch row of a zero-padded batch whose key masks are
+ *   prefixes (decoder.py:433-445 with a padding mask): keys j >= klen[b] are invisible, key tiles beyond klen[b] are not
+ *   visited, query rows >= klen[b] (padding) that fill a whole workgroup are written as zeros.  Cheaper than the same
+ *   mask given as keymask (which makes every tile a masked tile).
  */
 int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                    const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
@@ -156,13 +160,13 @@ int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int6
 int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                         int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk, int q_begin,
-                        hipStream_t stream);
+                        const int32_t* klen, hipStream_t stream);
 /* The same contract (bf16 tensors in HBM) with Q, K, V^T and P quantised to OCP fp8 e4m3 inside the kernel and both
  * products on the fp8 MFMA (BASELINE config 5).  Accuracy: the bound stated in tests/test_gpu_kernels.py (<= 7 % of the output RMS). */
 int mmx_attn_flash_fp8(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                        const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                        int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk, int q_begin,
-                       hipStream_t stream);
+                       const int32_t* klen, hipStream_t stream);
 
 /* DAC-VAE encoder head: Conv1d(1 -> C, k) + LeakyReLU (dac-vae/model.py:208 with :509-514) on a mono waveform
  * x fp32 [B][T]; w fp32 [C][k]; out_f32 [B][T][C] (optional) and out_act T [B][T][C] = snake(v, alpha) (alpha optional). */

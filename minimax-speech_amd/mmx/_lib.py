@@ -62,6 +62,7 @@ def fill_struct(st, **kw):
     return st
 
 
+ABI_VERSION = 3                                          # include/mmx_hip.h: mmx_abi_version()
 _lib = None
 
 
@@ -76,9 +77,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise MmxError(f"{LIB_PATH} not found: build it with `make -C minimax-speech_amd/csrc` "
                            "(or __graft_entry__.build()); the hot path has no CPU fallback")
-        _lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
-            getattr(_lib, s).restype = C.c_int
+            getattr(lib, s).restype = C.c_int
+        if lib.mmx_abi_version() != ABI_VERSION:         # a stale build: argument lists differ, refuse it
+            raise MmxError(f"{LIB_PATH} has ABI version {lib.mmx_abi_version()}, this package binds version {ABI_VERSION}: "
+                           "rebuild it (`make -C minimax-speech_amd/csrc`)")
+        _lib = lib
     return _lib
 
 

@@ -491,11 +491,11 @@ class FlowEngine:
             self._vt[key] = torch.zeros(B, 512, Tp, dtype=self.tdt, device=self.dev)      # pad columns stay zero
         return self._vt[key]
 
-    def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None):
+    def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None, klen=None):
         """All inputs fp32 time-major device tensors: x [x_mod,T,80] (batch b reads x[b % x_mod]), mu/cond [B,T,80],
         spks [B,80], t [B]; mask fp32 [B,T] or None.  Returns fp32 [B,T,80]."""
         if self.fused or (self.fused is None and (self.dtype == BF16 or B * ((T + 15) // 16) >= 256)):
-            return self._estimator_fused(x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod)
+            return self._estimator_fused(x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod, klen)
         dt, C = self.dtype, self.C
         chunk = self.est_chunk if streaming else 0
         te = self._new(B, self.tdim)
@@ -554,7 +554,7 @@ class FlowEngine:
             return bm, bm
         return (32 if tiles(32) >= 128 else 16), 16            # fp32: tail, resnet (LDS: fp32 tiles are twice as large)
 
-    def _estimator_fused(self, x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod):
+    def _estimator_fused(self, x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod, klen=None):
         dt, C = self.dtype, self.C
         chunk = self.est_chunk if streaming else 0
         bm_t, bm_r = self._tile_rows(B, T)
@@ -588,8 +588,8 @@ class FlowEngine:
         def attention():
             if bf:
                 ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
-                                    k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, keymask=mask, chunk=chunk,
-                                    fp8=self.attn_fp8)
+                                    k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125,
+                                    keymask=(None if klen is not None else mask), chunk=chunk, fp8=self.attn_fp8, klen=klen)
             else:
                 ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
                                q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, keymask=mask,
@@ -862,6 +862,9 @@ class FlowEngine:
         P.spks = torch.zeros(2 * n, 80, device=self.dev)
         P.cond = torch.zeros(2 * n, T, 80, device=self.dev)
         P.mask = torch.ones(2 * n, T, device=self.dev) if masked else None
+        # the masks of a padded group are prefixes: the flash kernel takes the lengths (no masked tiles inside an utterance,
+        # no key tiles beyond it) instead of the mask
+        P.klen = torch.full((2 * n,), T, dtype=torch.int32, device=self.dev) if masked else None
         P.d = self._new(2 * n, T, 80, f32=True)
         tt, dd = self.t_schedule()
         P.t_all = torch.tensor([[v] * (2 * n) for v in tt], dtype=torch.float32, device=self.dev)
@@ -870,7 +873,7 @@ class FlowEngine:
         def run():
             P.x.copy_(P.z.unsqueeze(0).expand(n, T, 80))
             for s in range(self.n_timesteps):
-                self.estimator(P.x, T * 80, P.mu, P.spks, P.cond, P.t_all[s], 2 * n, T, P.mask, streaming, out=P.d, x_mod=n)
+                self.estimator(P.x, T * 80, P.mu, P.spks, P.cond, P.t_all[s], 2 * n, T, P.mask, streaming, out=P.d, x_mod=n, klen=P.klen)
                 ops.cfg_euler(P.x, P.d[:n], P.d[n:], self.cfg, dd[s], n * T * 80)
 
         P.run = Graphed(run, self.use_graphs)
@@ -900,6 +903,8 @@ class FlowEngine:
             if masked:
                 P.mask[i, :Ts[i]] = 1.0
                 P.mask[n + i, :Ts[i]] = 1.0
+        if masked:
+            P.klen.copy_(torch.tensor(list(Ts) * 2, dtype=torch.int32), non_blocking=False)
         P.run()
         return [P.x[i, :Ts[i]] for i in range(n)]
 

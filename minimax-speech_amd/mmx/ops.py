@@ -203,15 +203,18 @@ def attn_dense(q, k, v, out, *, B, H, Tq, Tk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_
 
 
 def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, keymask=None,
-                    chunk=0, q_begin=0, km_bs=None, fp8=False):
+                    chunk=0, q_begin=0, km_bs=None, fp8=False, klen=None):
+    """klen: int32 [B] valid keys per batch row (prefix masks of a padded batch) - see include/mmx_hip.h."""
+    if klen is not None:
+        assert klen.dtype == torch.int32 and klen.numel() >= B
     if fp8:
         check(load().mmx_attn_flash_fp8(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(vt), i64(ldvt),
                                         i64(vt_bs), _p(out), i64(ldo), i64(o_bs), B, H, T, C.c_float(scale),
-                                        _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, stream()), "mmx_attn_flash_fp8")
+                                        _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen), stream()), "mmx_attn_flash_fp8")
         return
     check(load().mmx_attn_flash_bf16(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(vt), i64(ldvt),
                                      i64(vt_bs), _p(out), i64(ldo), i64(o_bs), B, H, T, C.c_float(scale),
-                                     _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, stream()), "mmx_attn_flash_bf16")
+                                     _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen), stream()), "mmx_attn_flash_bf16")
 
 
 # ----------------------------------------------------------------------------- LM decode

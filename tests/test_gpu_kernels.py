@@ -214,6 +214,42 @@ def test_attn_flash_bf16(env, T, chunk, q_begin, fp8):
     assert float(out[:, :q_begin].abs().max() if q_begin else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("T,chunk", [(200, 0), (500, 0), (500, 50), (1000, 0), (130, 0)])
+def test_attn_flash_klen(env, T, chunk):
+    """klen (valid keys per batch row of a padded batch) gives the result of the same prefix mask passed as keymask, on
+    every valid query row; padding rows come out finite (zeros where a whole workgroup is padding)."""
+    from oracle import flow as OF
+    L, ops = env
+    g = torch.Generator().manual_seed(T)
+    B, H, D = 3, 8, 64
+    q, k, v = (torch.randn(B, T, H * D, generator=g).cuda().bfloat16() for _ in range(3))
+    Tp = ops.round_up(T, 8)
+    vt = torch.zeros(B, H * D, Tp, device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :T] = v.transpose(1, 2)
+    lens = [T, T - 9, T // 2 + 5]
+    km = torch.zeros(B, T)
+    for b in range(B):
+        km[b, :lens[b]] = 1
+    klen = torch.tensor(lens, dtype=torch.int32).cuda()
+    outs = []
+    for kw in (dict(keymask=km.cuda()), dict(klen=klen)):
+        out = torch.full((B, T, H * D), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.attn_flash_bf16(q, k, vt, out, B=B, H=H, T=T, ldq=H * D, ldk=H * D, ldvt=Tp, ldo=H * D, q_bs=T * H * D,
+                            k_bs=T * H * D, vt_bs=H * D * Tp, o_bs=T * H * D, scale=D ** -0.5, chunk=chunk, **kw)
+        outs.append(out.float().cpu())
+    qh, kh, vh = (t.float().cpu().view(B, T, H, D).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-2, -1)) * D ** -0.5
+    vis = km.bool()[:, None, :].expand(B, T, T).clone()
+    if chunk:
+        vis = vis & OF.subsequent_chunk_mask(T, chunk)[None]
+    ref = (torch.softmax(s.masked_fill(~vis[:, None], float("-inf")), -1) @ vh).transpose(1, 2).reshape(B, T, H * D)
+    for b in range(B):
+        n = lens[b]
+        assert rel_err(outs[1][b, :n], ref[b, :n]) < 2e-2, b
+        assert rel_err(outs[1][b, :n], outs[0][b, :n]) < 1e-2, b        # same tiles, same order: bf16 rounding of P only
+        assert torch.isfinite(outs[1][b]).all()
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("B,K,N,epi,rs", [(1, 896, 1152, 0, True), (3, 896, 896, 2, False), (17, 4864, 896, 2, False),
                                           (1, 896, 4864, 1, True), (33, 896, 4864, 1, True), (2, 896, 6564, 0, True)])
