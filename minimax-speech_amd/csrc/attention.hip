@@ -245,6 +245,13 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
         if (e < kend) kend = e;
     }
     const int ntile = (kend + KT - 1) / KT;
+    // keys below vis_all are visible to EVERY query of the workgroup (its first query's chunk end): those tiles run the
+    // unmasked code; only the tiles that reach into the block's own chunks compare
+    int vis_all = Tk;
+    if (chunk > 0) {
+        const int e = ((q_begin + qt * (4 * QW)) / chunk + 1) * chunk;
+        if (e < vis_all) vis_all = e;
+    }
     bf16_t* Pw = Ps[wave];
 
     uint4 kreg[2], vreg[2];
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
                 }
             }
         }
-        const bool need_mask = km || chunk > 0 || (j0 + KT > Tk);       // uniform per tile
+        const bool need_mask = km || (j0 + KT > vis_all);               // uniform per tile
         bool kvis[4][4];                               // key-side visibility of this lane's 16 keys, once per tile
         if (need_mask) {
 #pragma unroll
@@ -505,6 +512,11 @@ __global__ __launch_bounds__(256) void attn_flash_splitk_kernel(
         if (e < kend) kend = e;
     }
     const int ntile = (kend + KT - 1) / KT;
+    int vis_all = Tn;                                  // keys below it are visible to all 16 queries: unmasked tiles
+    if (chunk > 0) {
+        const int e = (qb / chunk + 1) * chunk;
+        if (e < vis_all) vis_all = e;
+    }
 
     uint4 kreg[8], vreg[8];
     auto load_tiles = [&](int j0) {
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(256) void attn_flash_splitk_kernel(
                 s[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, aq[ks], s[nf], 0, 0, 0);
             }
         }
-        const bool need_mask = km || chunk > 0 || (j0 + KT > Tn);
+        const bool need_mask = km || (j0 + KT > vis_all);
         float mx = -INFINITY;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
