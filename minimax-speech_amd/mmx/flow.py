@@ -545,12 +545,17 @@ class FlowEngine:
         return out
 
     # ------------------------------------------------------------------ estimator on the row-tile fused kernels
+    # measured time of ONE workgroup of the fused kernels by tile height (us, bf16): every workgroup streams the block's
+    # whole weight set from L2 at the CU's ~72 GB/s, so a launch takes (workgroups per CU, rounded up) x this
+    _WG_US = {16: 28.0, 32: 37.0, 64: 53.0}
+
     def _tile_rows(self, B, T):
-        """Rows per workgroup of the fused kernels: the largest tile that still gives most of the 256 CUs a workgroup."""
+        """Rows per workgroup of the fused kernels: the tile height with the shortest launch on 256 CUs."""
         tiles = lambda bm: B * ((T + bm - 1) // bm)
         if self.dtype == BF16:
-            bm = 64 if tiles(64) >= 160 else (32 if tiles(32) >= 128 else 16)
-            bm = min(bm, getattr(self, "max_tile_rows", 64))
+            cap = getattr(self, "max_tile_rows", 64)
+            cost = lambda bm: ((tiles(bm) + 255) // 256) * self._WG_US[bm]
+            bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (cost(b), -b))
             return bm, bm
         return (32 if tiles(32) >= 128 else 16), 16            # fp32: tail, resnet (LDS: fp32 tiles are twice as large)
 
