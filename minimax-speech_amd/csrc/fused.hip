@@ -659,8 +659,9 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
             else if (nw == 8) TAIL(bf16_t, 64, 2, 8);
             else return MMX_EARG;
         } else if (bm == 32) {
-            if (nw == 8) { if (pf == 2) TAIL(bf16_t, 32, 2, 8); else TAIL(bf16_t, 32, 4, 8); }
-            else if (nw == 0 || nw == 4) { if (pf == 2) TAIL(bf16_t, 32, 2, 4); else TAIL(bf16_t, 32, 4, 4); }
+            // default: 8 waves, ring depth 2 (measured 32.5 us per workgroup against 37.2 us with 4 waves / depth 4)
+            if (nw == 8 || nw == 0) { if (pf == 4) TAIL(bf16_t, 32, 4, 8); else TAIL(bf16_t, 32, 2, 8); }
+            else if (nw == 4) { if (pf == 2) TAIL(bf16_t, 32, 2, 4); else TAIL(bf16_t, 32, 4, 4); }
             else return MMX_EARG;
         } else if (bm == 16) {
             if (nw == 8) TAIL(bf16_t, 16, 4, 8);
@@ -699,7 +700,9 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     const int kb = dtype == MMX_BF16 ? 32 : 16;
     // 8 waves (two per SIMD) measured faster for the 64-row ResNet tile (50.6 vs 59.7 us at 14 336 rows); they need 17 KB
     // more LDS for the per-wave patches, which the 512-channel input tile (up block) does not leave
-    const bool w8 = dtype == MMX_BF16 && (nw == 8 || (nw == 0 && bm == 64 && resnet_lds<bf16_t, 64, 8>(p.cin) <= 160 * 1024));
+    // (and for the smaller tiles: 31.7 vs 36.2 us at 32 rows, 26.9 vs 29.0 us at 16 rows)
+    const size_t lds8 = bm == 64 ? resnet_lds<bf16_t, 64, 8>(p.cin) : (bm == 32 ? resnet_lds<bf16_t, 32, 8>(p.cin) : resnet_lds<bf16_t, 16, 8>(p.cin));
+    const bool w8 = dtype == MMX_BF16 && (nw == 8 || (nw == 0 && lds8 <= 160 * 1024));
     const int want = pf_req > 0 ? pf_req : (w8 ? (bm == 64 ? 2 : 4) : (bm == 16 ? 8 : 4));
     MMX_CHECK_ARG(want == 2 || want == 4 || want == 8);
     int pf = want;

@@ -547,7 +547,7 @@ class FlowEngine:
     # ------------------------------------------------------------------ estimator on the row-tile fused kernels
     # measured time of ONE workgroup of the fused kernels by tile height (us, bf16): every workgroup streams the block's
     # whole weight set from L2 at the CU's ~72 GB/s, so a launch takes (workgroups per CU, rounded up) x this
-    _WG_US = {16: 28.0, 32: 37.0, 64: 53.0}
+    _WG_US = {16: 28.8, 32: 32.4, 64: 53.9}
 
     def _tile_rows(self, B, T):
         """Rows per workgroup of the fused kernels: the tile height with the shortest launch on 256 CUs."""
