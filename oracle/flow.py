@@ -206,11 +206,14 @@ def basic_transformer_block(sd, p, x, bias, heads=8, dh=64):
 
 
 def estimator_forward(sd, p, x, mask, mu, t, spks, cond, streaming=False, static_chunk_size=50,
-                      n_blocks=4, n_mid=12, heads=8, dh=64, return_stages=False):
+                      n_blocks=4, n_mid=None, heads=8, dh=64, return_stages=False):
     """CausalConditionalDecoder.forward with channels=[256] (config.yaml:105-116).
     Reference layout in/out: x, mu, cond [B,80,T]; mask [B,1,T]; t [B]; spks [B,80] -> [B,80,T]."""
     stages = {}
     B, _, T = x.shape
+    if n_mid is None:                                  # config.yaml:111 num_mid_blocks = 12; reduced-depth tests carry fewer
+        pre = p + ".mid_blocks."
+        n_mid = 1 + max(int(k[len(pre):].split(".", 1)[0]) for k in sd if k.startswith(pre))
     temb = sinusoidal_pos_emb(t, sd[p + ".time_mlp.linear_1.weight"].shape[1]).to(t.dtype)
     temb = F.linear(F.silu(F.linear(temb, sd[p + ".time_mlp.linear_1.weight"], sd[p + ".time_mlp.linear_1.bias"])),
                     sd[p + ".time_mlp.linear_2.weight"], sd[p + ".time_mlp.linear_2.bias"])
