@@ -198,3 +198,15 @@ def test_config5_long_form_streaming_full_size(case):
     snr = _snr_db(wav, wav_8)
     print(f"config 5: fp8 attention vs bf16 attention: waveform SNR {snr:.1f} dB, max abs diff {(wav - wav_8).abs().max().item():.3e}")
     assert toks_8 == toks and torch.isfinite(wav_8).all() and snr > 10.0, snr
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke(): reduced-depth LM / estimator through the whole path vs the CPU oracle (fp32 ids identical,
+    waveform <= 1e-3), then the bf16 build."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    importlib.import_module("__graft_entry__").smoke()
