@@ -302,6 +302,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flow-bm-min", type=int, default=0, help="tuning: smallest tile height of the fused flow kernels")
     ap.add_argument("--flow-bm", type=int, default=0, help="cap the fused flow kernels' tile height (tuning: 32 leaves registers for co-resident decode waves)")
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"], help="fp8: estimator attention on the fp8 MFMA (config 5)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-utterance and fp32-build extra measurements")
@@ -314,6 +315,7 @@ def main():
     ap.add_argument("--hold-steps", type=int, default=60, help="decode steps a finished utterance waits for a fuller flow group")
     ap.add_argument("--queue-batches", type=int, default=1, help="utterances per step = this many batches of --per-gpu, through the same decode slots (continuous batching: a freed slot admits the next utterance)")
     ap.add_argument("--gqa-min-batch", type=int, default=None, help="decode batches of at least this size use the GQA-shared attention kernel")
+    ap.add_argument("--no-polite", action="store_true", help="flow groups beside the decode loop use the fastest tiling instead of the 64-row one")
     ap.add_argument("--tail-active", type=int, default=0, help="with at most this many sequences still decoding, finished utterances go to an idle flow worker at once")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
@@ -356,6 +358,8 @@ def main():
     eng = make_engine(dt, dev, PER_GPU, 2048 if a.workload == "longform" else 640)
     if a.flow_bm:
         eng.flow.max_tile_rows = a.flow_bm
+    if a.flow_bm_min:
+        eng.flow.min_tile_rows = a.flow_bm_min
     emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1)).to(dev)
     if a.workload == "longform":
         # BASELINE config 5: one 60 s utterance per GPU, streaming (25-token hops, chunk-causal flow with the estimator /
@@ -390,7 +394,7 @@ def main():
                     first_chunk_ms.append((time.perf_counter() - t_in) * 1e3)
                 n += w.shape[-1]
             return n
-        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps, poll_every=a.poll_every, tail_active=a.tail_active)
+        wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps, poll_every=a.poll_every, tail_active=a.tail_active, polite=not a.no_polite)
         if world > 1:                                              # the path's one exchange step (RCCL all-gather)
             gather_audio([w.cpu() for w in wavs] if rehearse else wavs, mine, len(lens_all), max_samples)
         return sum(w.shape[-1] for w in wavs)

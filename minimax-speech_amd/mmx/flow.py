@@ -134,6 +134,11 @@ class FlowEngine:
         self._pe, self._plans, self._vt = OrderedDict(), OrderedDict(), {}
         self.plan_budget_bytes = 16 << 30           # recorded Euler solves kept alive (LRU); see _cfm_plan
         self.shape_log = None                       # a list collects (n, T, sum T_i, sum T_i^2) of every cfm_batch call (bench.py)
+        # polite = True: the fused kernels use 64-row tiles whatever the launch-time model says.  Fewer, longer workgroups:
+        # slower for the launch itself below ~8 000 rows, but they occupy fewer CUs, and a latency-bound kernel chain running
+        # beside them on another stream (the LM decode loop of TtsEngine.tts_batch) keeps more of the chip
+        # (measured, 32-utterance step: decode loop 548 -> 523 ms, step 643 -> 622 ms).  Part of the plan key.
+        self.polite = False
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -556,6 +561,7 @@ class FlowEngine:
             cap = getattr(self, "max_tile_rows", 64)
             cost = lambda bm: ((tiles(bm) + 255) // 256) * self._WG_US[bm]
             bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (cost(b), -b))
+            bm = max(bm, getattr(self, "min_tile_rows", 16), 64 if self.polite else 16)
             return bm, bm
         return (32 if tiles(32) >= 128 else 16), 16            # fp32: tail, resnet (LDS: fp32 tiles are twice as large)
 
@@ -848,7 +854,7 @@ class FlowEngine:
 
     def _cfm_plan(self, n, T, streaming, masked):
         """Plan for n utterances padded to T frames: static buffers + the graph of the whole Euler solve."""
-        key = ("cfm", n, T, bool(streaming), bool(masked))
+        key = ("cfm", n, T, bool(streaming), bool(masked), bool(self.polite))
         if key in self._plans:
             self._plans.move_to_end(key)
             return self._plans[key]

@@ -216,7 +216,7 @@ class TtsEngine:
 
     @torch.no_grad()
     def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=8, max_pad_ratio=2.0,
-                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=60, tail_active=0) -> List[torch.Tensor]:
+                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=60, tail_active=0, polite=True) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
         conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
@@ -231,6 +231,8 @@ class TtsEngine:
         then its (partial) group is issued, so the flow work of the long utterances is not left for after the last
         token (the rule counts decode steps, not wall time: the schedule, and with it the set of captured plans, is
         the same from run to run).
+        polite: flow groups issued while the decode loop runs use FlowEngine.polite tiling (64-row tiles: fewer workgroups,
+        more of the chip left to the decode loop's launches); the groups of the final harvest use the fastest tiling.
         tail_active > 0: once at most that many sequences are still decoding, a finished utterance no longer waits for
         companions when a flow worker is (predicted) idle - the decode loop is the critical path, and whatever the last
         utterances still have to do after their last token is what the step ends on."""
@@ -283,7 +285,7 @@ class TtsEngine:
                         item = qs[wi].get()
                         if item is None:
                             return
-                        grp, ev = item
+                        grp, ev, flow.polite = item
                         side.wait_event(ev)                      # the group's token ids were written on the LM stream
                         t_in = _time.perf_counter()
                         self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow)
@@ -366,7 +368,9 @@ class TtsEngine:
                 # with it every worker's set of captured plans - repeats from run to run
                 wi = assign.pop(0) if assign else min(range(flow_workers), key=lambda w: (max(free_at[w], now), w))
                 free_at[wi] = max(free_at[wi], now) + GROUP_MS + FRAME_MS * sum(frames[b] for b in grp)
-                qs[wi].put((grp, ev))
+                # groups issued while the decode loop is running use the flow kernels' polite tiling (FlowEngine.polite);
+                # the last arrivals, issued when it has ended, the fastest one
+                qs[wi].put((grp, ev, polite and not final and B == NS))    # (with a queue the flow stage is the bottleneck)
                 issued[0] += 1
                 for b in grp:
                     pending.remove(b)
@@ -399,6 +403,8 @@ class TtsEngine:
             raise err[0]
         for sd in self._sides:
             sd.synchronize()
+        for fl in self._flows:
+            fl.polite = False
         if timing:
             print(f"[tts_batch] LM loop done at {(t_lm - self._t0) * 1e3:.0f} ms, flow/DAC tail until {(time.perf_counter() - self._t0) * 1e3:.0f} ms, "
                   f"decode steps {done}", flush=True)
