@@ -107,7 +107,7 @@ def _event_time_graph(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def _time_est_tail(fl, n, T):
+def _time_est_tail(fl, n, T, polite=False):
     """Average duration (us) of one est_tail launch at group shape (n utterances x T frames, CFG pair -> M = 2nT rows):
     a hipGraph of 112 launches rotating over the 56 mid blocks' weights (2 MB each, as in the pipeline), timed with HIP
     events on the launch stream.  Returns (us, rows per workgroup)."""
@@ -119,7 +119,9 @@ def _time_est_tail(fl, n, T):
     ao = torch.randn(B, T, 512, device=fl.dev).to(fl.tdt)
     x = torch.randn(B, T, C, device=fl.dev)
     qk, vt = fl._new(B, T, 1024), torch.zeros(B, 512, Tp, dtype=fl.tdt, device=fl.dev)
+    was, fl.polite = fl.polite, polite                  # the tiling the step used for this group (FlowEngine.polite)
     bm, _ = fl._tile_rows(B, T)
+    fl.polite = was
 
     def one(i=0):
         w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
@@ -139,7 +141,7 @@ def measure_attn_kernel(eng, shapes, steps=1):
     fl = eng.flow
     count = {}
     tot_us = tot_fl = tot_n = 0.0
-    for n, T, _, sq in shapes:
+    for n, T, _, sq, _pol in shapes:
         count.setdefault((n, T), [0, 0])[0] += 1
         tot_fl += 4.0 * 64 * 8 * 2 * sq
     for (n, T), (cnt, _) in sorted(count.items()):
@@ -149,7 +151,7 @@ def measure_attn_kernel(eng, shapes, steps=1):
         ao = torch.empty(B, T, 512, device=fl.dev, dtype=fl.tdt)
         # the group as the step ran it: utterance lengths spread evenly from the group's mean down and up to T (the log
         # keeps n, T, sum T_i, sum T_i^2, not every length), passed as klen like FlowEngine does for a padded group
-        valid = sum(v for n_, T_, v, _ in shapes if (n_, T_) == (n, T)) / cnt
+        valid = sum(v for n_, T_, v, _, _p in shapes if (n_, T_) == (n, T)) / cnt
         lo = max(1, int(2 * valid / n - T))
         lens = [int(round(lo + (T - lo) * i / max(1, n - 1))) for i in range(n)]
         lens[-1] = T
@@ -187,14 +189,14 @@ def measure_flow_kernel(eng, shapes, steps=1):
     assert fl.dtype == 1
     per_row = 2.0 * (512 * fl.C + fl.C * 1024 + 1024 * fl.C + fl.C * 1536)
     count = {}
-    for n, T, valid, _ in shapes:
-        c = count.setdefault((n, T), [0, 0])
+    for n, T, valid, _, pol in shapes:
+        c = count.setdefault((n, T, pol), [0, 0])
         c[0] += 1
         c[1] += valid
     tot_us = tot_fl = tot_n = 0.0
     tiles = set()
-    for (n, T), (cnt, valid) in sorted(count.items()):
-        us, bm = _time_est_tail(fl, n, T)
+    for (n, T, pol), (cnt, valid) in sorted(count.items()):
+        us, bm = _time_est_tail(fl, n, T, pol)
         tiles.add(bm)
         tot_us += cnt * us
         tot_fl += per_row * 2 * valid
@@ -209,7 +211,8 @@ def measure_flow_kernel(eng, shapes, steps=1):
         pm = json.load(open(pj))
         traffic, traffic_l = pm.get("est_tail_bench_hbm_bytes_per_launch"), pm.get("est_tail_8x896_hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": f"est_tail_kernel<bf16, {'|'.join(str(t) for t in sorted(tiles))} rows per workgroup> (fused transformer-block tail) over the "
-            f"{int(tot_n) // max(1, steps)} flow groups of a step ({len(count)} shapes, M = 2nT from {min(2 * n * T for n, T in count)} to {max(2 * n * T for n, T in count)} rows)",
+            f"{int(tot_n) // max(1, steps)} flow groups of a step ({len(count)} shapes, M = 2nT from {min(2 * n * T for n, T, _ in count)} to {max(2 * n * T for n, T, _ in count)} rows; "
+            f"{sum(c[0] for k, c in count.items() if k[2]) // max(1, steps)} of them beside the decode loop, on 64-row tiles)",
             "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
             "traffic": traffic, "flops_per_launch": round(flops), "us_per_launch": round(us, 3),
             "isolated_large": {"kernel": f"est_tail_kernel<bf16, {bm_l}>, M = 14336 (8 utterances x 896 frames x CFG pair)", "achieved": round(tfs_l, 1),

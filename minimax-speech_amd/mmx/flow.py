@@ -133,7 +133,7 @@ class FlowEngine:
         cv = lambda k: ops.pack_conv1d(f(k), dt)
         self._pe, self._plans, self._vt = OrderedDict(), OrderedDict(), {}
         self.plan_budget_bytes = 16 << 30           # recorded Euler solves kept alive (LRU); see _cfm_plan
-        self.shape_log = None                       # a list collects (n, T, sum T_i, sum T_i^2) of every cfm_batch call (bench.py)
+        self.shape_log = None                       # a list collects (n, T, sum T_i, sum T_i^2, polite) of every cfm_batch call (bench.py)
         # polite = True: the fused kernels use 64-row tiles whatever the launch-time model says.  Fewer, longer workgroups:
         # slower for the launch itself below ~8 000 rows, but they occupy fewer CUs, and a latency-bound kernel chain running
         # beside them on another stream (the LM decode loop of TtsEngine.tts_batch) keeps more of the chip
@@ -901,7 +901,7 @@ class FlowEngine:
         T = ops.round_up(max(Ts), pad_to)
         masked = any(t != T for t in Ts)
         if self.shape_log is not None:                     # measurement hook (bench.py): group shapes of a run
-            self.shape_log.append((n, T, sum(Ts), sum(t * t for t in Ts)))
+            self.shape_log.append((n, T, sum(Ts), sum(t * t for t in Ts), bool(self.polite)))
         P = self._cfm_plan(n, T, streaming, masked)
         if masked:
             P.mu[:n].zero_()
