@@ -18,6 +18,11 @@
  *    reference's exception/assert convention (flow.py:453, llm.py:273);
  *  - `dtype`: MMX_F32 (parity build: fp32 storage, exact fp32 MFMA) or MMX_BF16 (bf16 storage of weights
  *    and GEMM-input activations, fp32 accumulation and fp32 residual streams).  "T" below means that type.
+ *    MMX_X2 / MMX_X3 (the split build): weights are stored and streamed as bf16 exactly as in MMX_BF16, every
+ *    activation is stored as fp32 ("T" = float for activations), and each product against an activation runs on the
+ *    bf16 MFMA with the activation split into 2 (hi + lo: 16 significant bits) or 3 (24 bits) bf16 terms accumulated
+ *    in fp32.  With bf16-representable weights the result is fp32-grade (X3) at the bf16 build's weight bytes.
+ *    Entry points without a matrix product treat MMX_X2 / MMX_X3 as MMX_F32.
  *  - activations are TIME-MAJOR: a [B,C,T] tensor of the reference is stored as rows of C channels.
  */
 #ifndef MMX_HIP_H
@@ -33,6 +38,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 #define MMX_F32 0
 #define MMX_BF16 1
+#define MMX_X2 2
+#define MMX_X3 3
 
 /* activation codes */
 #define MMX_ACT_NONE 0

@@ -8,6 +8,9 @@
 #define MMX_CHECK_ARG(c) do { if (!(c)) return MMX_EARG; } while (0)
 #define MMX_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return -(int)e_ - 1000; } while (0)
 
+// entry points without a matrix product: the split builds (MMX_X2 / MMX_X3 = 2 / 3) store activations as fp32
+#define MMX_ACT_DTYPE(d) ((d) >= 2 ? 0 : (d))
+
 typedef unsigned short bf16_t;   // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) float float4_t;

@@ -37,20 +37,30 @@ template <> struct Frag<float> {
     static constexpr int LDS_ROW = 40;        // 32 data + 8 pad elements: 160 B pitch
 };
 
-template <typename T, int BM, int BN, int WM, int WN>
+// NS > 1 is the split build (MMX_X2 / MMX_X3, include/mmx_hip.h): T (weights, LDS tiles, MFMA operands) is bf16, the A
+// operand and out_act are fp32 in HBM (TA = float).  An A chunk of 4 floats is split into NS bf16 planes on its way
+// into LDS (hi = bf16(x), then the rounded remainders), and every A x W fragment pair costs NS MFMAs into the same
+// accumulator: exact bf16 x bf16 products, fp32 accumulation, i.e. 16 (NS = 2) or 24 (NS = 3) significant bits of the
+// activation against exactly represented bf16 weights.
+template <typename T, typename TA, int NS, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     constexpr int BK = 32;
+    constexpr bool XS = NS > 1;
+    static_assert(!XS || (sizeof(T) == 2 && sizeof(TA) == 4), "split build: bf16 weights, fp32 activations");
+    static_assert(XS || sizeof(T) == sizeof(TA), "one storage type otherwise");
     constexpr int CH = Frag<T>::CH;
-    constexpr int CPR = BK / CH;                       // chunks per row per k-tile
+    constexpr int CPR = BK / CH;                       // W chunks per row per k-tile
+    constexpr int CHA = 16 / sizeof(TA);               // A elements per 16-byte chunk
+    constexpr int CPRA = BK / CHA;
     constexpr int LR = Frag<T>::LDS_ROW;
     constexpr int MF = BM / WM / 16, NF = BN / WN / 16;
-    constexpr int A_CHUNKS = (BM * CPR + 255) / 256, W_CHUNKS = (BN * CPR + 255) / 256;
-    constexpr bool A_FULL = (BM * CPR) % 256 == 0, W_FULL = (BN * CPR) % 256 == 0;
-    constexpr bool PRECISE = sizeof(T) == 4;
+    constexpr int A_CHUNKS = (BM * CPRA + 255) / 256, W_CHUNKS = (BN * CPR + 255) / 256;
+    constexpr bool A_FULL = (BM * CPRA) % 256 == 0, W_FULL = (BN * CPR) % 256 == 0;
+    constexpr bool PRECISE = sizeof(TA) == 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* As = reinterpret_cast<T*>(smem);                // [2][BM][LR]
-    T* Ws = As + 2 * BM * LR;                          // [2][BN][LR]
+    T* As = reinterpret_cast<T*>(smem);                // [NS][2][BM][LR]
+    T* Ws = As + NS * 2 * BM * LR;                     // [2][BN][LR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     const int b = blockIdx.z;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    const T* A = reinterpret_cast<const T*>(p.A) + (long)b * p.a_bstride;
+    const TA* A = reinterpret_cast<const TA*>(p.A) + (long)b * p.a_bstride;
     const T* W = reinterpret_cast<const T*>(p.W) + (long)b * p.w_bstride;
 
     // Per-thread chunk state.  Address generation is strength-reduced to a pointer bump per k-tile (the
@@ -71,23 +81,23 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     // compiler lose count of the loads in flight, and it then drains them all (s_waitcnt vmcnt(0)) before every LDS
     // store, which had collapsed the STAGES-deep prefetch to one k-tile (rocprofv3 PMC: waves parked 48 % of the time).
     constexpr unsigned OOB = 0x80000000u;
-    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0, 0x7fffffff, 0x00020000);
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<TA*>(A), 0, 0x7fffffff, 0x00020000);
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W), 0, 0x7fffffff, 0x00020000);
     unsigned a_off[A_CHUNKS];
     int a_c[A_CHUNKS], a_tap[A_CHUNKS];
     long a_srow[A_CHUNKS];
     bool a_mok[A_CHUNKS];
-    const unsigned tap_jump = (unsigned)(((long)p.dil * p.lda - p.cin) * (long)sizeof(T));
+    const unsigned tap_jump = (unsigned)(((long)p.dil * p.lda - p.cin) * (long)sizeof(TA));
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
         const int id = tid + i * 256;
-        const int r = id / CPR, k = (id % CPR) * CH;
+        const int r = id / CPRA, k = (id % CPRA) * CHA;
         const int m = m0 + r;
         a_tap[i] = k / p.cin;
         a_c[i] = k % p.cin;
         a_srow[i] = (long)m * p.row_stride + (long)a_tap[i] * p.dil + p.row_off;
-        a_off[i] = (unsigned)((a_srow[i] * p.lda + a_c[i]) * (long)sizeof(T));     // mod 2^32; used only when in range
-        a_mok[i] = (m < p.M) && (A_FULL || id < BM * CPR);
+        a_off[i] = (unsigned)((a_srow[i] * p.lda + a_c[i]) * (long)sizeof(TA));    // mod 2^32; used only when in range
+        a_mok[i] = (m < p.M) && (A_FULL || id < BM * CPRA);
     }
     unsigned w_off[W_CHUNKS];
 #pragma unroll
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     }
     // register-staged prefetch ring: STAGES k-tiles of global loads in flight per workgroup (these GEMMs are
     // short-K and latency bound: M ~ 500-1000 rows, K = 256..1024), 2 LDS buffers, one barrier per k-tile
-    constexpr int STAGES = sizeof(T) == 2 ? 4 : 2;
+    constexpr int STAGES = (sizeof(T) == 2 && !XS) ? 4 : 2;
     uint4 a_reg[STAGES][A_CHUNKS], w_reg[STAGES][W_CHUNKS];
     const int K = p.ntaps * p.cin;
     const int nk = (K + BK - 1) / BK;                  // W is zero padded to nk*BK columns (ldw >= nk*BK)
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
             const bool ok = a_mok[i] && (a_tap[i] < p.ntaps) && (a_srow[i] >= p.row_lo) && (a_srow[i] < p.row_hi);
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, ok ? a_off[i] : OOB, 0, 0);
             a_reg[slot][i] = make_uint4(v[0], v[1], v[2], v[3]);
-            a_off[i] += BK * (unsigned)sizeof(T);
+            a_off[i] += BK * (unsigned)sizeof(TA);
             a_c[i] += BK;
             while (a_c[i] >= p.cin) {
                 a_c[i] -= p.cin;
@@ -134,8 +144,25 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             int id = tid + i * 256;
-            if (A_FULL || id < BM * CPR)
-                *reinterpret_cast<uint4*>(As + (stage * BM + id / CPR) * LR + (id % CPR) * CH) = a_reg[slot][i];
+            if (A_FULL || id < BM * CPRA) {
+                if constexpr (XS) {
+                    const uint4 v = a_reg[slot][i];
+                    float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(x[0], x[1]);
+                        pk.y = pack_bf16x2(x[2], x[3]);
+                        *reinterpret_cast<uint2*>(As + ((s2 * 2 + stage) * BM + id / CPRA) * LR + (id % CPRA) * CHA) = pk;
+                        if (s2 + 1 < NS) {                // remainders (exact in fp32: the parts do not overlap)
+                            x[0] -= __uint_as_float(pk.x << 16); x[1] -= __uint_as_float(pk.x & 0xffff0000u);
+                            x[2] -= __uint_as_float(pk.y << 16); x[3] -= __uint_as_float(pk.y & 0xffff0000u);
+                        }
+                    }
+                } else {
+                    *reinterpret_cast<uint4*>(As + (stage * BM + id / CPRA) * LR + (id % CPRA) * CHA) = a_reg[slot][i];
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
@@ -155,16 +182,20 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         const T* as = As + (st * BM + wm * (BM / WM) + l16) * LR;
         const T* ws = Ws + (st * BN + wn * (BN / WN) + l16) * LR;
         if constexpr (sizeof(T) == 2) {
-            short8_t af[MF], bfr[NF];
-#pragma unroll
-            for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const short8_t*>(as + i * 16 * LR + 8 * g);
+            short8_t bfr[NF];
 #pragma unroll
             for (int j = 0; j < NF; ++j) bfr[j] = *reinterpret_cast<const short8_t*>(ws + j * 16 * LR + 8 * g);
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
+            for (int s2 = 0; s2 < NS; ++s2) {          // the planes of the split A tile (one plane otherwise)
+                short8_t af[MF];
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const short8_t*>(as + s2 * 2 * BM * LR + i * 16 * LR + 8 * g);
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {              // two 16-deep chunks; step s multiplies k = 16c + 4g' + s
@@ -223,10 +254,10 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     constexpr int LDC = WNC + 4;                       // padded fp32 row: conflict-free ds_write_b32
     float* Cs = reinterpret_cast<float*>(smem) + wave * 16 * LDC;
     float* outf = p.out_f32 ? p.out_f32 + (long)b * p.of_bstride : nullptr;
-    T* outa = p.out_act ? reinterpret_cast<T*>(p.out_act) + (long)b * p.oa_bstride : nullptr;
+    TA* outa = p.out_act ? reinterpret_cast<TA*>(p.out_act) + (long)b * p.oa_bstride : nullptr;
     const float* res = p.residual ? p.residual + (long)b * p.r_bstride : nullptr;
     const float* rmask = p.rowmask ? p.rowmask + (long)b * p.rm_bstride : nullptr;
-    constexpr int VA = 16 / sizeof(T);                 // act elements per 16 bytes
+    constexpr int VA = 16 / sizeof(TA);                // act elements per 16 bytes
     const bool vec_f = outf && (p.ldo_f % 4 == 0) && (p.out_off % 4 == 0) && (p.of_bstride % 4 == 0) && ((uintptr_t)p.out_f32 % 16 == 0);
     const bool vec_a = outa && (p.ldo_a % VA == 0) && (p.out_off % VA == 0) && (p.oa_bstride % VA == 0) && ((uintptr_t)p.out_act % 16 == 0) && (CW % VA == 0);
     const bool vec_r = res && (p.ldr % 4 == 0) && (p.r_bstride % 4 == 0) && ((uintptr_t)p.residual % 16 == 0);
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         if (outa) {
             const long lin = (long)m * p.ldo_a + nb + p.out_off;
             if (vec_a && full && lin >= 0 && lin + CW <= p.out_len) {
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (sizeof(TA) == 2) {
 #pragma unroll
                     for (int c = 0; c < CW; c += 8) {
                         uint4 pk;
@@ -322,7 +353,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
             } else {
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
-                    if (nb + c < p.N && lin + c >= 0 && lin + c < p.out_len) outa[lin + c] = Cvt<T>::from_f(w2[c]);
+                    if (nb + c < p.N && lin + c >= 0 && lin + c < p.out_len) outa[lin + c] = Cvt<TA>::from_f(w2[c]);
             }
         }
     }
@@ -340,57 +371,66 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, typename TA, int NS, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch);
-    size_t lds = (size_t)2 * (BM + BN) * Frag<T>::LDS_ROW * sizeof(T);
+    size_t lds = (size_t)2 * (NS * BM + BN) * Frag<T>::LDS_ROW * sizeof(T);
     const size_t lds_epi = (size_t)4 * 16 * (BN / WN + 4) * sizeof(float);    // per-wave epilogue patches
     if (lds_epi > lds) lds = lds_epi;
-    hipLaunchKernelGGL((gemm_win_kernel<T, BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
+    if (lds > 64 * 1024) {
+        // more than 64 KB of dynamic LDS is an opt-in per function AND per device: set it on every such launch (a host-side
+        // attribute write, no stream operation) rather than remembering which devices have seen it
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_win_kernel<T, TA, NS, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -1000 - (int)e;
+    }
+    hipLaunchKernelGGL((gemm_win_kernel<T, TA, NS, BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
 
-template <typename T>
+template <typename T, typename TA, int NS>
 static int launch_T(const GemmParams& p, hipStream_t s, int force_tile) {
     // shape validation the kernel relies on (16-byte chunk loads)
     constexpr int CH = Frag<T>::CH;
+    constexpr int CHA = 16 / sizeof(TA);
     MMX_CHECK_ARG(p.A && p.W && p.M > 0 && p.N > 0 && p.batch > 0 && p.ntaps >= 1);
-    MMX_CHECK_ARG(p.cin % CH == 0 && p.lda % CH == 0 && p.ldw % CH == 0);
-    MMX_CHECK_ARG(p.a_bstride % CH == 0 && p.w_bstride % CH == 0);
+    MMX_CHECK_ARG(p.cin % CH == 0 && p.lda % CHA == 0 && p.ldw % CH == 0);
+    MMX_CHECK_ARG(p.a_bstride % CHA == 0 && p.w_bstride % CH == 0);
     MMX_CHECK_ARG(p.ldw >= ((p.ntaps * p.cin + 31) / 32) * 32);
     MMX_CHECK_ARG(p.bias_mod > 0 && p.alpha_mod > 0 && p.row_stride >= 1);
     MMX_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0);
     MMX_CHECK_ARG(p.out_f32 || p.out_act);
     // operands are addressed with 32-bit byte offsets inside a 2 GiB buffer window per batch item
     const long a_rows = std::min<long>(p.row_hi, (long)(p.M - 1) * p.row_stride + (long)(p.ntaps - 1) * p.dil + p.row_off + 1);
-    MMX_CHECK_ARG((double)a_rows * (double)p.lda * sizeof(T) < 2147483000.0 &&
+    MMX_CHECK_ARG((double)a_rows * (double)p.lda * sizeof(TA) < 2147483000.0 &&
                   (double)p.N * (double)p.ldw * sizeof(T) < 2147483000.0);
     MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use
     // largest tile that still gives every CU a workgroup (256 CUs); short-K GEMMs want many MFMAs per barrier
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch; };
     switch (force_tile) {                              // mmx_gemm_win_tile: the tuning entry (tools/microbench.py)
         case 0: break;
-        case MMX_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2>(p, s);
-        case MMX_TILE_128x64: return launch_cfg<T, 128, 64, 4, 1>(p, s);
-        case MMX_TILE_64x64: return launch_cfg<T, 64, 64, 2, 2>(p, s);
-        case MMX_TILE_32x64: return launch_cfg<T, 32, 64, 1, 4>(p, s);
+        case MMX_TILE_128x128: return launch_cfg<T, TA, NS, 128, 128, 2, 2>(p, s);
+        case MMX_TILE_128x64: return launch_cfg<T, TA, NS, 128, 64, 4, 1>(p, s);
+        case MMX_TILE_64x64: return launch_cfg<T, TA, NS, 64, 64, 2, 2>(p, s);
+        case MMX_TILE_32x64: return launch_cfg<T, TA, NS, 32, 64, 1, 4>(p, s);
         default: return MMX_EARG;
     }
     // measured on MI355X (tools/microbench.py tiles, profiles/r01_gemm_tiles.txt): these GEMMs are short-K and
     // latency bound, so more (smaller) workgroups win until the problem is large: 64x64 beats 128x128 up to
     // ~1000 128-tiles (234 vs 239 TFLOP/s at M=8192,N=1024,K=256; 256 vs 153 at N=256,K=1024) and by 2x at M=1024.
     const long b128 = blocks(128, 128);
-    if (p.N > 64 && (b128 >= 1024 || (p.ntaps * p.cin >= 1024 && b128 >= 512))) return launch_cfg<T, 128, 128, 2, 2>(p, s);
-    if (p.N <= 64 && blocks(128, 64) >= 512) return launch_cfg<T, 128, 64, 4, 1>(p, s);
-    if (blocks(64, 64) >= 64 || p.M > 32) return launch_cfg<T, 64, 64, 2, 2>(p, s);
-    return launch_cfg<T, 32, 64, 1, 4>(p, s);
+    if (p.N > 64 && (b128 >= 1024 || (p.ntaps * p.cin >= 1024 && b128 >= 512))) return launch_cfg<T, TA, NS, 128, 128, 2, 2>(p, s);
+    if (p.N <= 64 && blocks(128, 64) >= 512) return launch_cfg<T, TA, NS, 128, 64, 4, 1>(p, s);
+    if (blocks(64, 64) >= 64 || p.M > 32) return launch_cfg<T, TA, NS, 64, 64, 2, 2>(p, s);
+    return launch_cfg<T, TA, NS, 32, 64, 1, 4>(p, s);
 }
 
 extern "C" int mmx_gemm_win_tile(const GemmParams* p, int dtype, int tile, hipStream_t stream) {
     MMX_CHECK_ARG(p != nullptr);
-    if (dtype == MMX_BF16) return launch_T<bf16_t>(*p, stream, tile);
-    if (dtype == MMX_F32) return launch_T<float>(*p, stream, tile);
+    if (dtype == MMX_BF16) return launch_T<bf16_t, bf16_t, 1>(*p, stream, tile);
+    if (dtype == MMX_F32) return launch_T<float, float, 1>(*p, stream, tile);
+    if (dtype == MMX_X2) return launch_T<bf16_t, float, 2>(*p, stream, tile);
+    if (dtype == MMX_X3) return launch_T<bf16_t, float, 3>(*p, stream, tile);
     return MMX_EARG;
 }
 extern "C" int mmx_gemm_win(const GemmParams* p, int dtype, hipStream_t stream) {

@@ -5,6 +5,12 @@ architecture (BASELINE.json).  Every tensor is a pure function of (state-dict ke
 generator: the same weights can be regenerated anywhere without shipping 600 M parameters.  Scales are chosen
 so activations stay O(1) through the deep stacks (56 transformer blocks, 37 convs); plain random init gives a
 ~1e-3 waveform and degenerate (uniform) token distributions.
+
+Every matrix-shaped parameter (Linear / Conv / embedding weights) is **bf16-representable**: the checkpoint this path
+serves ships in bf16 (Qwen2.5-0.5B does), so weights are inputs that both sides hold exactly — the CPU oracle computes
+in fp32 on these values, the GPU streams them as bf16 with no rounding.  Weight-normed convs (DAC-VAE) are in the
+state torch's weight_norm leaves a freshly initialised module in: weight_g = ||weight_v|| per output channel, so the
+effective weight g * v / ||v|| is weight_v itself.  Vectors (biases, norm gains, snake alphas) stay fp32.
 """
 import math
 import zlib
@@ -21,7 +27,27 @@ def _randn(shape, g, std=1.0, mean=0.0):
     return torch.randn(tuple(shape), generator=g) * std + mean
 
 
+def _bf16_exact(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# per-output-channel gain the weight-normed conv ends up with (effective weight = weight_v, see the module docstring)
+def _wn_gain(n: str, shape) -> float:
+    if n.endswith("block.3.0.weight_v"):               # ResidualUnit k1 conv: damp the residual branch
+        return 0.3
+    if shape[0] == 1:                                  # final conv (C -> 1) ahead of tanh
+        return 0.25
+    return 1.0
+
+
 def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
+    t = _synth_tensor(name, shape, seed)
+    if len(shape) >= 2 and not name.endswith(".alpha") and not name.endswith(".weight_g"):
+        t = _bf16_exact(t)
+    return t
+
+
+def _synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
     g = _gen(seed, name)
     shape = tuple(shape)
     n = name
@@ -29,15 +55,12 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
     if n.endswith(".alpha"):
         return _randn(shape, g, 0.1, 1.0)
     if n.endswith(".weight_v"):
-        return _randn(shape, g)
+        fan = 1
+        for s_ in shape[1:]:
+            fan *= s_
+        return _randn(shape, g, _wn_gain(n, shape) / math.sqrt(fan))
     if n.endswith(".weight_g"):
-        if n.endswith("block.3.0.weight_g"):           # ResidualUnit k1 conv: damp the residual branch
-            return torch.full(shape, 0.3)
-        if ".block.1.weight_g" in n and n.count("block") == 1:   # ConvTranspose1d, g is per INPUT channel
-            return torch.full(shape, 1.0)
-        if shape[0] == 1:                              # final conv (C -> 1) ahead of tanh
-            return torch.full(shape, 0.25)
-        return torch.full(shape, 1.0)
+        raise KeyError("weight_g is derived from weight_v: use synth_state_dict")
     # ---- norms
     if "norm" in n or n.endswith("block.2.weight") or n.endswith("block.2.bias") or ".out.1." in n \
             or "layernorm" in n:
@@ -76,4 +99,10 @@ def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
 
 
 def synth_state_dict(manifest: Dict[str, Tuple[int, ...]], seed: int = 0) -> Dict[str, torch.Tensor]:
-    return {k: synth_tensor(k, tuple(v), seed) for k, v in manifest.items()}
+    sd = {k: synth_tensor(k, tuple(v), seed) for k, v in manifest.items() if not k.endswith(".weight_g")}
+    for k, shp in manifest.items():
+        if k.endswith(".weight_g"):
+            # torch.nn.utils.weight_norm at init: g = ||v|| over every dim but 0 (the same call the module's forward makes)
+            v = sd[k[:-1] + "v"]
+            sd[k] = torch.norm_except_dim(v, 2, 0).reshape(tuple(shp)).clone()
+    return {k: sd[k] for k in manifest}
