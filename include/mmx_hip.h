@@ -203,6 +203,9 @@ int mmx_conv_cout1_tanh(const void* act, int64_t a_bs, int T, int C, int k, cons
  *   x[m*16 + l16][kb*KB + g*E + j]; E = 8 bf16 / 4 fp32, KB = 4E; ceil(B/16)*16 rows allocated, ldx ignored);
  *   MMX_OUT_PACKED — out_act is written in that order for a consumer whose K is this N (N % 32 == 0, ldo_a ignored).
  *   Pays at batch > 8, where every workgroup re-reads the whole activation matrix from L2.
+ *   dtype MMX_X2 / MMX_X3 (split build): x fp32 row-major (flags 0), Wp the bf16 pack made WITHOUT kscale, kgamma [K] fp32
+ *   (or NULL) = the RMSNorm gain applied to x before the split, results to out_f32 only (epi 1 writes silu(g)*u there).
+ *   kgamma must be NULL for the other dtypes.
  */
 #define MMX_X_PACKED 1
 #define MMX_OUT_PACKED 2
@@ -210,7 +213,7 @@ int mmx_pack_skinny(const void* w, int64_t ldw, int N, int K, const float* kscal
                     void* wp, int dtype, hipStream_t stream);
 int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N, const void* wp,
                     const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
-                    void* out_act, int64_t ldo_a, int dtype, int flags, hipStream_t stream);
+                    void* out_act, int64_t ldo_a, int dtype, int flags, const float* kgamma, hipStream_t stream);
 
 /* RoPE (HF rotate_half; inv_freq[D/2] fp32 = 1/theta^(2i/D) as HF computes it) on q/k of
  * qkv[b][t][: (Hq+2Hkv)*D] at position pos[b] + t, K/V appended to the paged cache, q written as T.  Cache layout:

@@ -113,6 +113,7 @@ extern "C" int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const vo
                               int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs,
                               int chunk, const void* pos, int64_t ldp, const float* pos_u, const float* pos_v,
                               int head_stride, int q_begin, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(q && k && v && out && B > 0 && H > 0 && D == 64 && Tq > 0 && Tk > 0 && chunk >= 0);
     MMX_CHECK_ARG(q_begin >= 0 && q_begin < Tq);
     const int hs = head_stride > 0 ? head_stride : D;

@@ -55,6 +55,7 @@ extern "C" int mmx_rownorm(const float* x, int64_t ldx, int64_t x_bstride, int r
                            const float* rowmask, int64_t rm_bstride, const float* addvec, int64_t av_bstride,
                            float* out_f32, int64_t ldo_f, int64_t of_bstride,
                            void* out_act, int64_t ldo_a, int64_t oa_bstride, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(x && gamma && rows > 0 && C > 0 && C <= 1024 && batch > 0 && (out_f32 || out_act));
     dim3 grid((rows + 3) / 4, batch);
     MMX_CHECK_ARG(act == ACT_NONE || act == ACT_MISH);
@@ -87,6 +88,7 @@ __global__ void gather_rows_kernel(const int64_t* __restrict__ ids, int n, const
 }
 extern "C" int mmx_gather_rows(const int64_t* ids, int n, const float* table, int C, float scale, const float* rowmask,
                                float* out_f32, int64_t ldo_f, void* out_act, int64_t ldo_a, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(ids && table && n > 0 && C > 0 && (out_f32 || out_act));
     if (dtype == MMX_BF16)
         hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(n), dim3(256), 0, stream, ids, n, table, C, scale, rowmask, out_f32, ldo_f, (bf16_t*)out_act, ldo_a);
@@ -128,6 +130,8 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const TI* __restrict__ in, 
 extern "C" int mmx_copy2d(const void* in, int in_dtype, int64_t ibs, int64_t irs, int64_t ics, int rep,
                           void* out, int out_dtype, int64_t obs, int64_t ors, int64_t ocs,
                           int rows, int cols, int batch, hipStream_t stream) {
+    in_dtype = MMX_ACT_DTYPE(in_dtype);
+    out_dtype = MMX_ACT_DTYPE(out_dtype);
     MMX_CHECK_ARG(in && out && rows > 0 && cols > 0 && batch > 0 && rep >= 1);
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
 #define CP(TI, TO) hipLaunchKernelGGL((copy2d_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)in, ibs, irs, ics, rep, (TO*)out, obs, ors, ocs, rows, cols)
@@ -160,6 +164,7 @@ __global__ void est_pack_kernel(const float* __restrict__ x, long x_bs, int x_mo
 }
 extern "C" int mmx_est_pack(const float* x, int64_t x_bs, int x_mod, const float* mu, const float* spks, const float* cond, int B, int T_, int C,
                             void* h, int64_t ldh, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(x && h && B > 0 && T_ > 0 && C > 0 && ldh >= 4 * C && x_mod > 0);
     dim3 grid(T_, B);
     if (dtype == MMX_BF16) hipLaunchKernelGGL(est_pack_kernel<bf16_t>, grid, dim3(128), 0, stream, x, x_bs, x_mod, mu, spks, cond, T_, C, (bf16_t*)h, ldh);
@@ -181,6 +186,7 @@ __global__ void sinusoidal_kernel(const float* __restrict__ t, int dim, float sc
     }
 }
 extern "C" int mmx_sinusoidal_emb(const float* t, int B, int dim, float scale, void* out, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(t && out && B > 0 && dim >= 4 && dim % 2 == 0);
     if (dtype == MMX_BF16) hipLaunchKernelGGL(sinusoidal_kernel<bf16_t>, dim3(B), dim3(128), 0, stream, t, dim, scale, (bf16_t*)out);
     else if (dtype == MMX_F32) hipLaunchKernelGGL(sinusoidal_kernel<float>, dim3(B), dim3(128), 0, stream, t, dim, scale, (float*)out);
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const T* __restrict__ a
 }
 extern "C" int mmx_conv_cout1_tanh(const void* act, int64_t a_bs, int T_, int C, int k, const float* w, const float* bias,
                                    float slope, int use_tanh, float* out, int64_t o_bs, int batch, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(act && w && out && T_ > 0 && C > 0 && k > 0 && (k & 1) && batch > 0);
     dim3 grid((T_ + 255) / 256, batch);
     size_t esz = dtype == MMX_BF16 ? 2 : 4;
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* __restrict_
 }
 extern "C" int mmx_conv_cin1(const float* x, int64_t x_bs, int T_, int C, int k, const float* w, const float* bias, float slope,
                              const float* alpha, float* out_f32, void* out_act, int batch, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(x && w && (out_f32 || out_act) && T_ > 0 && C > 0 && C % 8 == 0 && k > 0 && (k & 1) && batch > 0);
     dim3 grid((T_ + 255) / 256, batch);
     size_t lds = (size_t)(256 + k - 1 + C * k) * 4;
@@ -334,6 +342,7 @@ __global__ void swiglu_kernel(const float* __restrict__ gu, long ldgu, int I, T*
     out[r * ldo + c] = Cvt<T>::from_f(s * u);
 }
 extern "C" int mmx_swiglu(const float* gu, int64_t ldgu, int rows, int I, void* out, int64_t ldo, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(gu && out && rows > 0 && I > 0);
     dim3 grid((I + 255) / 256, rows);
     if (dtype == MMX_BF16) hipLaunchKernelGGL(swiglu_kernel<bf16_t>, grid, dim3(256), 0, stream, gu, ldgu, I, (bf16_t*)out, ldo);
@@ -383,6 +392,7 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict_
 }
 extern "C" int mmx_groupnorm(const float* x, int B, int T_, int C, int groups, const float* gamma, const float* beta,
                              float eps, int act, const float* rowmask, void* out, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(x && gamma && beta && out && B > 0 && T_ > 0 && C > 0 && groups > 0 && C % groups == 0);
     MMX_CHECK_ARG(act == ACT_NONE || act == ACT_MISH);
     dim3 grid(groups, B);
@@ -407,6 +417,7 @@ __global__ void act_rows_kernel(const float* __restrict__ x, long n, int C, int 
 }
 extern "C" int mmx_act_rows(const float* x, int64_t rows, int C, int act, const float* rowmask, float* out_f32, void* out_act,
                             int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(x && rows > 0 && C > 0 && (out_f32 || out_act) && act >= ACT_NONE && act <= ACT_TANH);
     const long n = rows * C;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -417,4 +428,4 @@ extern "C" int mmx_act_rows(const float* x, int64_t rows, int C, int act, const 
     return MMX_OK;
 }
 
-extern "C" int mmx_abi_version(void) { return 3; }
+extern "C" int mmx_abi_version(void) { return 4; }

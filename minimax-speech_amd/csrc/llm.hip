@@ -42,6 +42,7 @@ extern "C" int mmx_pack_skinny(const void* w, int64_t ldw, int N, int K, const f
                                void* wp, int dtype, hipStream_t stream) {
     MMX_CHECK_ARG(w && wp && N > 0 && K > 0 && K % 32 == 0);
     MMX_CHECK_ARG(interleave_half == 0 || (N == 2 * interleave_half && interleave_half % 16 == 0));
+    if (dtype == MMX_X2 || dtype == MMX_X3) { MMX_CHECK_ARG(!kscale); dtype = MMX_BF16; }   // split build: exact bf16 weights
     if (dtype == MMX_BF16) hipLaunchKernelGGL(pack_skinny_kernel<bf16_t>, dim3(2048), dim3(256), 0, stream, (const bf16_t*)w, ldw, N, K, kscale, interleave_half, (bf16_t*)wp);
     else if (dtype == MMX_F32) hipLaunchKernelGGL(pack_skinny_kernel<float>, dim3(2048), dim3(256), 0, stream, (const float*)w, ldw, N, K, kscale, interleave_half, (float*)wp);
     else return MMX_EARG;
@@ -69,12 +70,16 @@ __device__ __forceinline__ long act_packed_index(int row, int col, int K) {
 // bandwidth comes from bytes in flight: every wave issues ALL the weight loads of its k slice (<= KS k-blocks,
 // 1 KiB per wave-instruction) back to back into registers before the first MFMA, and the k split is chosen so
 // that a slice fits (skinny_launch_mt below).
-template <typename T, typename TX, int MT, int EPI, int KS, bool XPK, bool OPK>
+// NS > 1 (MMX_X2 / MMX_X3): bf16 weights, fp32 activations split into NS bf16 terms per product (see csrc/gemm.hip);
+// the RMSNorm gain is then NOT folded into the weights (they must stay the checkpoint's bf16 values): kgamma [K]
+// multiplies the activations before the split.
+template <typename T, typename TX, int MT, int EPI, int KS, bool XPK, bool OPK, int NS = 1>
 __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__ x, long ldx, int B, int K, int N,
                                    const T* __restrict__ wp, const float* __restrict__ bias, int rs, float eps,
                                    float* __restrict__ outf, long ldo_f, T* __restrict__ outa, long ldo_a,
-                                   int ksplit, int ntiles) {
+                                   int ksplit, int ntiles, const float* __restrict__ kgamma) {
     constexpr bool BF = sizeof(T) == 2;
+    static_assert(NS == 1 || (BF && sizeof(TX) == 4 && !XPK && !OPK), "split build: bf16 weights, fp32 row-major activations");
     constexpr int E = BF ? 8 : 4;
     constexpr int KB = E * 4;
     constexpr int NB = EPI == 1 ? 2 : 1;               // B fragments per wave
@@ -177,7 +182,29 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
 #pragma unroll
                         for (int e = 0; e < E; ++e) ssq[m] += xv[e] * xv[e];
                     }
-                    if constexpr (BF) {
+                    if constexpr (NS > 1) {
+                        if (kgamma) {
+                            const float4 g0 = *reinterpret_cast<const float4*>(kgamma + (kc + i) * KB + g * E);
+                            const float4 g1 = *reinterpret_cast<const float4*>(kgamma + (kc + i) * KB + g * E + 4);
+                            xv[0] *= g0.x; xv[1] *= g0.y; xv[2] *= g0.z; xv[3] *= g0.w;
+                            xv[4] *= g1.x; xv[5] *= g1.y; xv[6] *= g1.z; xv[7] *= g1.w;
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < NS; ++s2) {
+                            short8_t af;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const bf16_t hb = f2bf(xv[e]);
+                                af[e] = (short)hb;
+                                xv[e] -= bf2f(hb);
+                            }
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                short8_t bfr = *reinterpret_cast<const short8_t*>(&wf[i][n]);
+                                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[n][m], 0, 0, 0);
+                            }
+                        }
+                    } else if constexpr (BF) {
                         short8_t af;
                         if constexpr (sizeof(TX) == 2) {
                             af = *reinterpret_cast<const short8_t*>(&raw[0]);
@@ -267,7 +294,8 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
                 if (n < N) {
                     float gte = acc[0][m][r] * sc, up = acc[1][m][r] * sc;
                     float sl = gte / (1.f + expf(-gte));
-                    outa[OPK ? act_packed_index<T>(row, n, N) : (long)row * ldo_a + n] = Cvt<T>::from_f(sl * up);
+                    if constexpr (NS > 1) outf[(long)row * ldo_f + n] = sl * up;       // split build: activations are fp32
+                    else outa[OPK ? act_packed_index<T>(row, n, N) : (long)row * ldo_a + n] = Cvt<T>::from_f(sl * up);
                 }
             } else {
                 const int n = tile * 16 + l16;
@@ -275,16 +303,18 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
                     float v = acc[0][m][r] * sc + pre_bias;
                     if constexpr (EPI == 2) v += pre_res[m][r];
                     if (outf) outf[(long)row * ldo_f + n] = v;
-                    if (outa) outa[OPK ? act_packed_index<T>(row, n, N) : (long)row * ldo_a + n] = Cvt<T>::from_f(v);
+                    if constexpr (NS == 1)
+                        if (outa) outa[OPK ? act_packed_index<T>(row, n, N) : (long)row * ldo_a + n] = Cvt<T>::from_f(v);
                 }
             }
         }
     }
 }
 
-template <typename T, typename TX, int EPI, bool XPK, bool OPK>
+template <typename T, typename TX, int EPI, bool XPK, bool OPK, int NS = 1>
 static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, int rs,
-                            float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s) {
+                            float eps, float* outf, int64_t ldo_f, void* outa, int64_t ldo_a, hipStream_t s,
+                            const float* kgamma = nullptr) {
     constexpr int KB = sizeof(T) == 2 ? 32 : 16;
     const int ntiles = (N + 15) / 16;                  // for EPI==1, N is the activation width I
     const int nkb = K / KB;
@@ -302,8 +332,8 @@ static int skinny_launch_mt(const void* x, int64_t ldx, int B, int K, int N, con
     dim3 grid((ntiles + tpb - 1) / tpb), block(waves * 64);
     constexpr int NB = EPI == 1 ? 2 : 1;
     size_t lds = ksplit > 1 ? (size_t)waves * (NB * mt * 4 + mt) * 64 * 4 : 0;
-#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, (MT == 1 ? 10 : (MT == 2 ? 7 : 4)), XPK, OPK>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
-        bias, rs, eps, outf, ldo_f, (T*)outa, ldo_a, ksplit, ntiles)
+#define SK(MT) hipLaunchKernelGGL((skinny_gemm_kernel<T, TX, MT, EPI, (MT == 1 ? 10 : (MT == 2 ? 7 : 4)), XPK, OPK, NS>), grid, block, lds, s, (const TX*)x, ldx, B, K, N, (const T*)wp, \
+        bias, rs, eps, outf, ldo_f, (T*)outa, ldo_a, ksplit, ntiles, kgamma)
     switch (mt) {
         case 1: SK(1); break;
         case 2: SK(2); break;
@@ -338,10 +368,26 @@ static int skinny_launch_layout(int flags, int epi, const void* x, int64_t ldx, 
     if (flags == 0) return skinny_launch_epi<T, TX, false, false>(epi, x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, outa, ldo_a, s);
     return MMX_EARG;
 }
+template <int NS>
+static int skinny_launch_split(int epi, const void* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, int rs,
+                               float eps, float* outf, int64_t ldo_f, hipStream_t s, const float* kgamma) {
+    if (epi == 0) return skinny_launch_mt<bf16_t, float, 0, false, false, NS>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, nullptr, 0, s, kgamma);
+    if (epi == 1) return skinny_launch_mt<bf16_t, float, 1, false, false, NS>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, nullptr, 0, s, kgamma);
+    if (epi == 2) return skinny_launch_mt<bf16_t, float, 2, false, false, NS>(x, ldx, B, K, N, wp, bias, rs, eps, outf, ldo_f, nullptr, 0, s, kgamma);
+    return MMX_EARG;
+}
 extern "C" int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N, const void* wp,
                                const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
-                               void* out_act, int64_t ldo_a, int dtype, int flags, hipStream_t stream) {
+                               void* out_act, int64_t ldo_a, int dtype, int flags, const float* kgamma, hipStream_t stream) {
     MMX_CHECK_ARG(x && wp && B > 0 && B <= 64 && K > 0 && K % 32 == 0 && N > 0);
+    if (dtype == MMX_X2 || dtype == MMX_X3) {
+        // split build: fp32 row-major activations in, fp32 out (epi 1 writes SwiGLU(gate, up) to out_f32)
+        MMX_CHECK_ARG(x_dtype == MMX_F32 && flags == 0 && out_f32 && !out_act && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0);
+        MMX_CHECK_ARG(!kgamma || ((uintptr_t)kgamma % 16) == 0);
+        return dtype == MMX_X2 ? skinny_launch_split<2>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, stream, kgamma)
+                               : skinny_launch_split<3>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, stream, kgamma);
+    }
+    MMX_CHECK_ARG(!kgamma);                            // the other builds fold the RMSNorm gain into the packed weights
     MMX_CHECK_ARG((flags == 0 || flags == MMX_X_PACKED || flags == (MMX_X_PACKED | MMX_OUT_PACKED)) && (flags == 0 || x_dtype == dtype) &&
                   (!(flags & MMX_OUT_PACKED) || N % 32 == 0));
     MMX_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0);
@@ -395,6 +441,7 @@ extern "C" int mmx_rope_kv_store(const float* qkv, int64_t ldqkv, int64_t qkv_bs
                                  const float* inv_freq, const int32_t* pos, void* q_out, int64_t ldq, int64_t q_bs,
                                  void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
                                  int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(qkv && inv_freq && pos && q_out && kc && vc && block_table && B > 0 && rows > 0 && D == 64 && page > 0);
     dim3 grid(rows, B);
     if (dtype == MMX_BF16) hipLaunchKernelGGL(rope_kv_kernel<bf16_t>, grid, dim3(256), 0, stream, qkv, ldqkv, qkv_bs, Hq, Hkv, inv_freq, pos, (bf16_t*)q_out, ldq, q_bs, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, page);
@@ -462,6 +509,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
 extern "C" int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, int Hq, int Hkv, int D, float scale,
                               const int32_t* pos, const void* kc, const void* vc, const int32_t* block_table, int max_pages,
                               int page, void* out, int64_t ldo, int64_t o_bs, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(q && pos && kc && vc && block_table && out && B > 0 && rows > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
     const size_t max_ctx = (size_t)max_pages * page;
     size_t lds = (64 + 8 + 4 * 64 + max_ctx) * 4;
@@ -873,6 +921,7 @@ __global__ __launch_bounds__(256) void decode_attn_gqa_kernel(
 extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                                const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages,
                                int page, float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
     MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 3);
     const bool gqa_shared = !(out_packed & 2);         // bit 1: force the per-head kernel (A/B measurements, tests)

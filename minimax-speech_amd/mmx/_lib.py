@@ -5,9 +5,19 @@ import os
 import torch
 
 F32, BF16 = 0, 1
+# the split builds (include/mmx_hip.h MMX_X2 / MMX_X3): weights stored and streamed as bf16, activations stored as fp32
+# and split into 2 / 3 bf16 terms inside every MFMA product.  X2 is what the flow and the DAC run (16 significant bits
+# per activation), X3 the LM (24 bits: its sampler turns a 1e-3 log-prob error into another token id).
+X2, X3 = 2, 3
 ACT = {"none": 0, "lrelu": 1, "gelu": 2, "silu": 3, "mish": 4, "tanh": 5}
-TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
-ESIZE = {F32: 4, BF16: 2}
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.float32, X3: torch.float32}       # activation storage
+WEIGHT_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.bfloat16, X3: torch.bfloat16}   # weight storage
+ESIZE = {F32: 4, BF16: 2, X2: 4, X3: 4}
+DTYPE_NAMES = {"f32": F32, "bf16": BF16, "x": X2, "x2": X2, "x3": X3}
+
+
+def is_split(dtype):
+    return dtype in (X2, X3)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")
@@ -62,7 +72,7 @@ def fill_struct(st, **kw):
     return st
 
 
-ABI_VERSION = 3                                          # include/mmx_hip.h: mmx_abi_version()
+ABI_VERSION = 4                                          # include/mmx_hip.h: mmx_abi_version()
 _lib = None
 
 

@@ -18,7 +18,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT
+from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, is_split
 
 
 def espnet_rel_pe(T: int, d: int) -> torch.Tensor:
@@ -80,6 +80,16 @@ class Graphed:
     def __init__(self, fn, enabled=True):
         self.fn, self.enabled, self.graph, self.calls = fn, enabled, None, 0
 
+    def release(self):
+        """Destroys the recorded graph (and its private pool) NOW, on the calling thread, and drops the closure: the
+        owner calls this on eviction / teardown so that no hipGraph is ever left for Python's cyclic collector (which may
+        run on a thread that is capturing: see __call__)."""
+        g, self.graph, self.fn = self.graph, None, None
+        if g is not None:
+            with CAPTURE_LOCK:                             # never while another thread is inside a capture
+                g.reset()
+            del g
+
     def __call__(self):
         if not self.enabled:
             return self.fn()
@@ -123,6 +133,9 @@ class FlowEngine:
         # workgroup (64 workgroups for one 10 s utterance) leaves 3/4 of the matrix cores idle, while the per-op launches
         # split N over all CUs (measured, one 10 s utterance, fp32: 175 ms fused, 104 ms per-op)
         self.fused = fused
+        self.split = is_split(dtype)
+        if self.split and fused is None:
+            self.fused = False                      # the row-tile fused kernels have no split variant yet
         # attn="fp8": the estimator's full-length attention launches run the fp8 MFMA variant (bf16 build only; BASELINE
         # config 5).  The split-key launches of streaming hops stay bf16.
         assert attn in ("bf16", "fp8")
@@ -157,15 +170,14 @@ class FlowEngine:
         import copy
         c = copy.copy(self)
         c._plans, c._pe, c._vt, c.plan_bytes = OrderedDict(), OrderedDict(), {}, 0
-        c._stream_pool = {}
+        c._stream_pool = OrderedDict()
         return c
 
     def set_noise(self, noise: torch.Tensor):
         """Replaces rand_noise (the drop-in CausalConditionalCFM owns its own tensor, flow_matching.py:321)."""
         if noise is not self.rand_noise and not torch.equal(noise.cpu(), self.rand_noise):
             self.rand_noise = noise.detach().cpu().float()
-            self._plans.clear()
-            self.plan_bytes = 0
+            self.close()                                   # recorded plans baked the old noise in
 
     def _init_encoder(self, sd, f, lin, cv):
         dt = self.dtype
@@ -220,7 +232,7 @@ class FlowEngine:
                      w2=lin(p + ".ff.net.2.weight"), b2=f(p + ".ff.net.2.bias"))
             wq, wk, wv = f(a + ".to_q.weight"), f(a + ".to_k.weight"), f(a + ".to_v.weight")
             if self.fused is not False:
-                pk = lambda w: ops.pack_skinny(w.to(self.tdt).contiguous(), dtype=dt)
+                pk = lambda w: ops.pack_skinny(w.to(WEIGHT_DT[dt]).contiguous(), dtype=dt)
                 d.update(wo_p=pk(f(a + ".to_out.0.weight")), w1_p=pk(f(p + ".ff.net.0.proj.weight")),
                          w2_p=pk(f(p + ".ff.net.2.weight")), wqkv_p=pk(torch.cat([wq, wk, wv], 0)))
             if dt == BF16:
@@ -665,6 +677,13 @@ class FlowEngine:
             self.spks2 = torch.zeros(2, 80, device=eng.dev)
             self.ids = torch.zeros(self.Tcap // 2 + eng.L + 8, dtype=torch.int64, device=eng.dev)
             self.graphs, self._win = {}, {}
+            self.busy = False
+
+        def release(self):
+            """drops the recorded hop graphs and the buffers (an evicted state)"""
+            for g in self.graphs.values():
+                g.release()
+            self.graphs, self._win, self.steps, self.enc = {}, {}, [None] * self.eng.n_timesteps, None
 
         def window(self, n):
             """static per-hop windows: ODE state of the n new frames, CFG pair of mu / cond rows (row 1 stays zero)"""
@@ -689,17 +708,52 @@ class FlowEngine:
                                      vt=([z(2, 512, Tc) for _ in range(nblk)] if e.dtype == BF16 else [None] * nblk))
             return self.steps[s]
 
+    # streaming state pool: capacities are bucketed coarsely (multiples of 512 frames, at most stream_cap_frames: beyond
+    # the cap a hop falls back to the uncached whole-prefix solve, inference_time_major), idle states are kept for reuse
+    # (their recorded hop graphs are the expensive part) under a byte budget, least recently used first out
+    stream_cap_frames = 4096                        # 82 s of audio; 0.36 MB per frame in bf16 (all 10 Euler steps)
+    stream_budget_bytes = 24 << 30
+
+    def _stream_state_bytes(self, cap):
+        per_frame = 0.36e6 * (1 if self.dtype == BF16 else 2)
+        return int(cap * per_frame)
+
     def stream_open(self, max_frames: int) -> "FlowEngine.StreamState":
-        """State for one streaming utterance of up to max_frames frames.  States are pooled per capacity: buffers and the
-        recorded per-hop graphs are reused by the next utterance (one utterance at a time per state)."""
-        cap = ops.round_up(max_frames, 64)
-        if not hasattr(self, "_stream_pool"):
-            self._stream_pool = {}
-        st = self._stream_pool.get(cap)
-        if st is None:
-            st = self._stream_pool[cap] = FlowEngine.StreamState(self, cap)
+        """State for one streaming utterance of up to max_frames frames (capped at stream_cap_frames).  States are pooled
+        per capacity bucket: buffers and the recorded per-hop graphs are reused by the next utterance of that bucket.  A state
+        is busy from stream_open to stream_close (a second concurrent utterance of the same bucket gets its own state);
+        idle states beyond stream_budget_bytes are dropped, least recently used first."""
+        cap = min(ops.round_up(max(max_frames, 1), 512), ops.round_up(self.stream_cap_frames, 64))
+        if not hasattr(self, "_stream_pool") or not isinstance(self._stream_pool, OrderedDict):
+            self._stream_pool = OrderedDict()          # id -> state, in LRU order
+        for key, st in self._stream_pool.items():
+            if st.Tcap == cap and not st.busy:
+                self._stream_pool.move_to_end(key)
+                break
+        else:
+            self._stream_evict(self._stream_state_bytes(cap))
+            st = FlowEngine.StreamState(self, cap)
+            self._stream_pool[id(st)] = st
+        st.busy = True
         st.reset()
         return st
+
+    def stream_close(self, st):
+        """The utterance is over: the state returns to the pool (or is dropped when the pool is over budget)."""
+        st.busy = False
+        self._stream_evict(0)
+
+    def _stream_evict(self, incoming):
+        pool = getattr(self, "_stream_pool", None)
+        if not pool:
+            return
+        total = sum(self._stream_state_bytes(s_.Tcap) for s_ in pool.values()) + incoming
+        for key in list(pool):
+            if total <= self.stream_budget_bytes:
+                break
+            if not pool[key].busy:
+                total -= self._stream_state_bytes(pool[key].Tcap)
+                pool.pop(key).release()
 
     def _estimator_stream(self, st, s, x_new, mu_new, spks2, cond_new, tb, T):
         """One estimator call of Euler step s on frames tb .. T-1 of a streaming utterance (CFG pair, B = 2), reading the
@@ -865,8 +919,7 @@ class FlowEngine:
         P.nbytes = 2 * n * T * (16 << 10)
         while self._plans and self.plan_bytes + P.nbytes > self.plan_budget_bytes:
             _, old = self._plans.popitem(last=False)
-            self.plan_bytes -= old.nbytes
-            del old
+            self._release_plan(old)
         self.plan_bytes += P.nbytes
         P.x = self._new(n, T, 80, f32=True)             # ODE state, shared by the two halves of the CFG batch
         P.mu = torch.zeros(2 * n, T, 80, device=self.dev)   # rows n.. stay zero: the unconditional branch
@@ -890,6 +943,23 @@ class FlowEngine:
         P.run = Graphed(run, self.use_graphs)
         self._plans[key] = P
         return P
+
+    def _release_plan(self, P):
+        """A plan is a reference cycle (P.run's closure holds P), so dropping the last name would leave its hipGraph and
+        its private pool to the cyclic collector: release them here, now, on this thread, and break the cycle."""
+        self.plan_bytes -= P.nbytes
+        P.run.release()
+        P.__dict__.clear()
+
+    def close(self):
+        """Deterministic teardown: every recorded graph (Euler-solve plans, streaming hop graphs) is destroyed on the
+        calling thread.  The engine can still be used afterwards (plans are recorded again on demand)."""
+        while self._plans:
+            _, old = self._plans.popitem(last=False)
+            self._release_plan(old)
+        pool = getattr(self, "_stream_pool", None) or {}
+        for key in list(pool):
+            pool.pop(key).release()
 
     def cfm_batch(self, mus, spks, conds, streaming=False, pad_to=1):
         """n utterances in one solve: mus/conds lists of fp32 [T_i,80], spks list of [80].  Shorter utterances are

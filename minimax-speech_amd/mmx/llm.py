@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT
+from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, is_split
 from .flow import Graphed
 
 ST_POS, ST_STEP, ST_NOUT, ST_FIN, ST_MINLEN, ST_MAXLEN, ST_SEQ, ST_ERR = range(8)
@@ -56,6 +56,7 @@ class LlmEngine:
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
                  prefix="llm.model.model", share_from=None, kv_pages=None):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.split = is_split(dtype)                      # bf16 weights, fp32 activations split inside the MFMA products
         self.Hq, self.Hkv, self.D, self.eps = heads, kv_heads, head_dim, eps
         self.page, self.use_graphs = page, use_graphs
         self.eos = speech_token_size
@@ -74,7 +75,8 @@ class LlmEngine:
             self._alloc_state()
             return
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
-        c = lambda t: t.to(self.tdt).contiguous()
+        c = lambda t: t.to(WEIGHT_DT[dtype]).contiguous()
+        ks = (lambda g: None) if self.split else (lambda g: g)   # split build: the gain stays out of the (exact bf16) weights
         self.n_layers = len({k.split(".")[4] for k in sd if k.startswith(prefix + ".layers.")})
         self.H = sd[prefix + ".norm.weight"].shape[0]
         self.I = sd[prefix + ".layers.0.mlp.gate_proj.weight"].shape[0]
@@ -93,15 +95,16 @@ class LlmEngine:
                     wgu=ops.pack_linear(c(wgu), dt), wdown=ops.pack_linear(c(f(p + ".mlp.down_proj.weight")), dt),
                     g1=f(p + ".input_layernorm.weight"), g2=f(p + ".post_attention_layernorm.weight")))
             self.layers.append(dict(
-                wqkv=ops.pack_skinny(c(wqkv), dtype=dt, kscale=f(p + ".input_layernorm.weight")), bqkv=bqkv,
+                wqkv=ops.pack_skinny(c(wqkv), dtype=dt, kscale=ks(f(p + ".input_layernorm.weight"))), bqkv=bqkv,
                 wo=ops.pack_skinny(c(f(a + ".o_proj.weight")), dtype=dt),
-                wgu=ops.pack_skinny(c(wgu), dtype=dt, kscale=f(p + ".post_attention_layernorm.weight"), interleave_half=self.I),
-                wdown=ops.pack_skinny(c(f(p + ".mlp.down_proj.weight")), dtype=dt)))
+                wgu=ops.pack_skinny(c(wgu), dtype=dt, kscale=ks(f(p + ".post_attention_layernorm.weight")), interleave_half=self.I),
+                wdown=ops.pack_skinny(c(f(p + ".mlp.down_proj.weight")), dtype=dt),
+                g1=f(p + ".input_layernorm.weight"), g2=f(p + ".post_attention_layernorm.weight")))
             del wqkv, wgu
         self.norm_w = f(prefix + ".norm.weight")
         self.embed_tokens = f(prefix + ".embed_tokens.weight")
         if "llm_decoder.weight" in sd:
-            self.wdec = ops.pack_skinny(c(f("llm_decoder.weight")), dtype=dt, kscale=self.norm_w)
+            self.wdec = ops.pack_skinny(c(f("llm_decoder.weight")), dtype=dt, kscale=ks(self.norm_w))
             self.bdec = f("llm_decoder.bias")
             self.speech_emb = f("speech_embedding.weight")
             self.llm_emb = f("llm_embedding.weight")
@@ -138,7 +141,7 @@ class LlmEngine:
         self.h = torch.zeros(B, self.H, device=self.dev)            # residual stream of the step
         # its compute-dtype copy; at batch > 8 the decode step keeps it (and every other GEMM input) in the packed
         # MFMA-fragment order of include/mmx_hip.h (whole 16-row tiles)
-        self.packed = B >= 4
+        self.packed = B >= 4 and not self.split
         self.h_act = torch.zeros(ops.packed_rows(B), self.H, dtype=self.tdt, device=self.dev)
         self.logits = torch.zeros(B, self.V, device=self.dev)
         self.logp = torch.zeros(B, self.V, device=self.dev)
@@ -158,6 +161,8 @@ class LlmEngine:
         dt, H, I = self.dtype, self.H, self.I
         n = B * rows
         assert n <= 64 and not (packed and rows != 1)
+        if self.split:
+            return self._layers_split(h, B, rows, pos, block_table)
         nr = ops.packed_rows(n) if packed else n
         qkv = torch.empty(n, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
         q = torch.empty(n, self.Hq * self.D, dtype=self.tdt, device=self.dev)
@@ -184,10 +189,38 @@ class LlmEngine:
             ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha,
                             x_packed=pk, out_packed=pk)
 
+    def _layers_split(self, h, B, rows, pos, block_table):
+        """The split build of _layers: every GEMM input is the fp32 tensor itself (row-major), the RMSNorm gains ride as
+        kgamma, all intermediates are fp32."""
+        dt, H, I = self.dtype, self.H, self.I
+        n = B * rows
+        qkv = torch.empty(n, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
+        q = torch.empty(n, self.Hq * self.D, device=self.dev)
+        att = torch.empty(n, self.Hq * self.D, device=self.dev)
+        act = torch.empty(n, I, device=self.dev)
+        for l, w in enumerate(self.layers):
+            ops.skinny_gemm(h, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True, eps=self.eps, epi=0,
+                            out_f32=qkv, kgamma=w["g1"])
+            if rows == 1:
+                ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
+                                Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, per_head=True)
+            else:
+                ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=rows,
+                                  Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
+                ops.paged_attn(q, pos, self.kc[l], self.vc[l], block_table, att, B=B, rows=rows, Hq=self.Hq,
+                               Hkv=self.Hkv, page=self.page, dtype=dt)
+            ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h)
+            ops.skinny_gemm(h, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_f32=act, kgamma=w["g2"])
+            ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h)
+
     def _tail(self, B, packed=False):
         """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences."""
-        ops.skinny_gemm(self.h_act, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
-                        eps=self.eps, epi=0, out_f32=self.logits, x_packed=packed)
+        if self.split:
+            ops.skinny_gemm(self.h, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
+                            eps=self.eps, epi=0, out_f32=self.logits, kgamma=self.norm_w)
+        else:
+            ops.skinny_gemm(self.h_act, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
+                            eps=self.eps, epi=0, out_f32=self.logits, x_packed=packed)
         ops.sample_step(self.logits, self.state, self.out_tokens, self.speech_emb, self.x_in, V=self.V, B=B,
                         eos_id=self.eos, seed=self.seed, top_k=self.top_k, top_p=self.top_p, win_size=self.win_size,
                         tau_r=self.tau_r, sampled=self.sampled, forced=self.forced,
@@ -256,16 +289,19 @@ class LlmEngine:
                 self._set_pages(s_, pos[s_] + 1 + ahead)
 
     @torch.no_grad()
-    def admit(self, slot: int, x: torch.Tensor, min_len: int, max_len: int, seq_id: int, ahead: int = 32):
+    def admit(self, slot: int, x: torch.Tensor, min_len: int, max_len: int, seq_id: int, ahead: Optional[int] = None):
         """Continuous batching: puts a new request into an idle slot while the other slots keep decoding.  All prompt
         rows but the last are prefetched into freshly allocated pages; the last row becomes the slot's next input, so the
         next ordinary decode step of the batch computes its logits and draws its first token (same Philox key (seed,
-        seq id, step 0) as a fixed-batch start) — no separate sampling pass, nothing of the other sequences is touched."""
+        seq id, step 0) as a fixed-batch start) — no separate sampling pass, nothing of the other sequences is touched.
+        ahead: cache rows reserved past the prompt.  None reserves the whole max_len (what start() does); a caller that
+        passes less MUST call ensure_capacity() between decode steps (run_queue does) — rows past the reservation map to
+        the shared scratch page."""
         L = x.shape[0]
         if L + max_len > self.max_pages * self.page:
             raise RuntimeError("sequence exceeds the KV cache")
         self.release(slot)
-        self._set_pages(slot, L + ahead)
+        self._set_pages(slot, L + (max_len if ahead is None else min(ahead, max_len)))
         x = x.to(self.dev, torch.float32).contiguous()
         for c0 in range(0, L - 1, 64):
             self._prefill_chunk(x[c0:min(L - 1, c0 + 64)], c0, slot)
@@ -314,6 +350,7 @@ class LlmEngine:
         if self._decode is None:
             self._decode = Graphed(self._decode_step, self.use_graphs)
         elif self._graph_key != (self.forced is None, want_logp, self.seed):
+            self._decode.release()
             self._decode = Graphed(self._decode_step, self.use_graphs)      # baked arguments changed: re-record
         self._graph_key = (self.forced is None, want_logp, self.seed)
 
@@ -384,6 +421,16 @@ class LlmEngine:
     def step(self):
         self._decode()
 
+    def close(self):
+        """Deterministic teardown of the recorded graphs (decode step, prompt chunks) on the calling thread."""
+        if self._decode is not None:
+            self._decode.release()
+            self._decode = None
+        if hasattr(self, "_pf"):
+            for g in self._pf["graphs"].values():
+                g.release()
+            del self._pf
+
     @torch.no_grad()
     def forward_rows(self, x: torch.Tensor, pos0: int) -> torch.Tensor:
         """Qwen2Encoder.forward_one_step (llm.py:359-371): appends the rows x [n, H] to sequence 0's KV cache at position
@@ -423,7 +470,12 @@ class LlmEngine:
         self.top_p, self.top_k, self.win_size, self.tau_r = big.top_p, big.top_k, big.win_size, big.tau_r
         self.forced = None
         key = (True, False, self.seed)
+        self._fresh_decode_graph(key)
+
+    def _fresh_decode_graph(self, key):
         if self._decode is None or getattr(self, "_graph_key", None) != key:
+            if self._decode is not None:
+                self._decode.release()
             self._decode = Graphed(self._decode_step, self.use_graphs)
         self._graph_key = key
 
@@ -448,10 +500,7 @@ class LlmEngine:
         between two decode steps.  Returns the accepted tokens per request (seq id = request index, so the result equals
         running every request alone under the same seed)."""
         self.seed, self.want_logp, self.forced = int(seed), False, None
-        key = (True, False, self.seed)
-        if self._decode is None or getattr(self, "_graph_key", None) != key:
-            self._decode = Graphed(self._decode_step, self.use_graphs)
-        self._graph_key = key
+        self._fresh_decode_graph((True, False, self.seed))
         st = torch.zeros(8, self.B, dtype=torch.int32)
         st[ST_FIN] = 1
         self.state.copy_(st)
@@ -492,10 +541,7 @@ class LlmEngine:
         self.seed, self.want_logp, self.forced = int(seed), bool(want_logp), None
         self._st = dict(rows=0, calls=0, hist=0, seq=int(seq_id), last=None)
         self.sampled.fill_(-1)
-        key = (True, self.want_logp, self.seed)
-        if self._decode is None or getattr(self, "_graph_key", None) != key:
-            self._decode = Graphed(self._decode_step, self.use_graphs)
-        self._graph_key = key
+        self._fresh_decode_graph((True, self.want_logp, self.seed))
 
     def embed_text(self, tok: torch.Tensor) -> torch.Tensor:
         """llm.model.model.embed_tokens rows, fp32 [n, H]."""

@@ -20,7 +20,7 @@ def round_up(x, m):
 def pack_linear(w: torch.Tensor, dtype) -> torch.Tensor:
     """[N, K] -> [N, Kpad] (K contiguous, zero padded to a multiple of 32) in the compute dtype."""
     N, K = w.shape
-    out = torch.zeros(N, round_up(K, 32), dtype=L.TORCH_DT[dtype], device=w.device)
+    out = torch.zeros(N, round_up(K, 32), dtype=L.WEIGHT_DT[dtype], device=w.device)
     out[:, :K] = w
     return out
 
@@ -219,11 +219,12 @@ def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, 
 
 # ----------------------------------------------------------------------------- LM decode
 def pack_skinny(w, *, dtype, kscale=None, interleave_half=0):
-    """w: [N, K] tensor in the compute dtype -> MFMA-fragment-ordered copy (see csrc/llm.hip)."""
+    """w: [N, K] tensor in the weight dtype -> MFMA-fragment-ordered copy (see csrc/llm.hip)."""
     N, K = w.shape
-    KB = 32 if dtype == BF16 else 16
+    assert w.dtype == L.WEIGHT_DT[dtype]
+    KB = 32 if L.WEIGHT_DT[dtype] == torch.bfloat16 else 16
     tiles = (N + 15) // 16
-    wp = torch.empty(tiles * (K // KB) * 64 * (KB // 4), dtype=L.TORCH_DT[dtype], device=w.device)
+    wp = torch.empty(tiles * (K // KB) * 64 * (KB // 4), dtype=L.WEIGHT_DT[dtype], device=w.device)
     check(load().mmx_pack_skinny(_p(w), i64(w.stride(0)), N, K, _p(kscale), interleave_half, _p(wp), dtype, stream()),
           "mmx_pack_skinny")
     return wp
@@ -255,12 +256,13 @@ def unpack_act(xp, B, K, dtype):
 
 
 def skinny_gemm(x, wp, *, B, K, N, dtype, bias=None, rs=False, eps=1e-6, epi=0, out_f32=None, out_act=None,
-                ldx=None, ldo_f=None, ldo_a=None, x_packed=False, out_packed=False):
+                ldx=None, ldo_f=None, ldo_a=None, x_packed=False, out_packed=False, kgamma=None):
+    """kgamma (split builds only): the RMSNorm gain [K], applied to x in the kernel instead of being folded into wp."""
     xdt = L.dt_of(x)
     flags = (X_PACKED if x_packed else 0) | (OUT_PACKED if out_packed else 0)
     check(load().mmx_skinny_gemm(_p(x), xdt, i64(ldx if ldx is not None else K), B, K, N, _p(wp), _p(bias), int(rs),
                                  C.c_float(eps), epi, _p(out_f32), i64(ldo_f if ldo_f is not None else N),
-                                 _p(out_act), i64(ldo_a if ldo_a is not None else N), dtype, flags, stream()),
+                                 _p(out_act), i64(ldo_a if ldo_a is not None else N), dtype, flags, _p(kgamma), stream()),
           "mmx_skinny_gemm")
 
 

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT
+from ._lib import BF16, F32, TORCH_DT, X2, X3, is_split
 from .dac import DacDecoderEngine
 from .flow import FlowEngine
 from .llm import LlmEngine
@@ -28,14 +28,27 @@ class TtsEngine:
         if self.dev.type == "cuda" and self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())
         device = self.dev
-        self.llm = LlmEngine(llm_sd, dtype=dtype, device=device, max_batch=max_batch, max_ctx=max_ctx, use_graphs=use_graphs)
+        # the split build: the flow and the DAC keep 16 significant bits of every activation (X2: waveform error ~1e-4),
+        # the LM 24 (X3): its sampler turns a log-prob error into a different token id, and the AR loop feeds that back
+        ldt = X3 if is_split(dtype) else dtype
+        self.llm = LlmEngine(llm_sd, dtype=ldt, device=device, max_batch=max_batch, max_ctx=max_ctx, use_graphs=use_graphs)
         # the decode step costs ~40 % more at 17..32 rows than at <= 16 (two MFMA row tiles): once at most 16
         # sequences are still running the batch continues in a 16-slot engine over the same weights and KV pages
-        self.llm_small = (LlmEngine(None, dtype=dtype, device=device, max_batch=16, max_ctx=max_ctx, use_graphs=use_graphs,
+        self.llm_small = (LlmEngine(None, dtype=ldt, device=device, max_batch=16, max_ctx=max_ctx, use_graphs=use_graphs,
                                     share_from=self.llm) if max_batch > 16 else None)
         self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs, attn=attn)
         self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device)
         self.hop = self.dac.hop
+
+    def close(self):
+        """Destroys every recorded hipGraph of the engines on the calling thread (deterministic teardown: nothing is left
+        for Python's cyclic collector to finalise later on whatever thread it happens to run)."""
+        self.llm.close()
+        if self.llm_small is not None:
+            self.llm_small.close()
+        for fl in getattr(self, "_flows", [self.flow]):
+            fl.close()
+        self.flow.close()
 
     @torch.no_grad()
     def generate_tokens(self, texts: List[torch.Tensor], prompt_texts=None, prompt_speech=None, seed=0,
@@ -143,28 +156,32 @@ class TtsEngine:
             emitted = hi
             return wav
 
-        while True:
-            with torch.cuda.stream(lm):
-                st = self.llm.state[:, 0].tolist()         # D2H copy on the LM stream: waits for the steps issued so far
-            n_out, finished = st[ST_NOUT], bool(st[ST_FIN]) or done >= mx
-            while n_out - offset >= token_hop + L:
-                w = render(offset + token_hop + L, finalize=False)
-                offset += token_hop
-                if w is not None:
-                    yield w
-            if finished:
-                w = render(n_out, finalize=True)
-                if w is not None:
-                    yield w
-                break
-            # keep the decode a few ACCEPTED tokens ahead of the renderer.  The look-ahead is counted in tokens, not in
-            # steps (ids above the EOS id advance the step counter without producing a token, llm.py:755-756), and at
-            # least one step is issued per round, so the loop always makes progress.
-            k = min(mx - done, max(1, offset + token_hop + L + 8 - n_out))
-            with torch.cuda.stream(lm):
-                for _ in range(k):
-                    self.llm.step()
-            done += k
+        try:
+            while True:
+                with torch.cuda.stream(lm):
+                    st = self.llm.state[:, 0].tolist()         # D2H copy on the LM stream: waits for the steps issued so far
+                n_out, finished = st[ST_NOUT], bool(st[ST_FIN]) or done >= mx
+                while n_out - offset >= token_hop + L:
+                    w = render(offset + token_hop + L, finalize=False)
+                    offset += token_hop
+                    if w is not None:
+                        yield w
+                if finished:
+                    w = render(n_out, finalize=True)
+                    if w is not None:
+                        yield w
+                    break
+                # keep the decode a few ACCEPTED tokens ahead of the renderer.  The look-ahead is counted in tokens, not in
+                # steps (ids above the EOS id advance the step counter without producing a token, llm.py:755-756), and at
+                # least one step is issued per round, so the loop always makes progress.
+                k = min(mx - done, max(1, offset + token_hop + L + 8 - n_out))
+                with torch.cuda.stream(lm):
+                    for _ in range(k):
+                        self.llm.step()
+                done += k
+        finally:
+            if sstate is not None:
+                self.flow.stream_close(sstate)           # the state (and its hop graphs) goes back to the pool
         caller.wait_stream(lm)
 
     # ------------------------------------------------------------------ batch of independent utterances
@@ -236,9 +253,9 @@ class TtsEngine:
         tail_active > 0: once at most that many sequences are still decoding, a finished utterance no longer waits for
         companions when a flow worker is (predicted) idle - the decode loop is the critical path, and whatever the last
         utterances still have to do after their last token is what the step ends on."""
-        import queue
+        import queue as queue_mod
         import threading
-        from .llm import ST_FIN, ST_NOUT
+        from .llm import ST_FIN, ST_NOUT, ST_POS
         B = len(texts)
         NS = self.llm.B                                   # decode slots; more utterances than slots queue up and are admitted
         assert B >= NS and (overlap or B == NS)           # into slots as they free (continuous batching, LlmEngine.admit)
@@ -272,7 +289,7 @@ class TtsEngine:
             self._sides = [torch.cuda.Stream(device=self.dev, priority=0) for _ in range(flow_workers)]
             self._flows = [self.flow] + [self.flow.clone_shared() for _ in range(flow_workers - 1)]
             self._hi = torch.cuda.Stream(device=self.dev, priority=-1)
-        qs, err = [queue.Queue() for _ in range(flow_workers)], []
+        qs, err = [queue_mod.Queue() for _ in range(flow_workers)], []
         caller = torch.cuda.current_stream()
         self._hi.wait_stream(caller)
 
@@ -311,7 +328,7 @@ class TtsEngine:
         STEP_MS, GROUP_MS, FRAME_MS = 1.2, 28.0, 0.025          # fitted to MMX_TIMING=2 traces of the round-2 kernels
 
         cur = [self.llm, list(range(NS))]                           # active engine, slot -> utterance index
-        queue = list(range(NS, B))                                  # utterances waiting for a slot
+        waiting = list(range(NS, B))                                # utterances waiting for a slot
 
         def harvest(final):
             eng, slots = cur
@@ -325,15 +342,21 @@ class TtsEngine:
                 toks[b] = eng.out_tokens[s_, :n[s_]].to(torch.int64)
                 pending.append(b)
                 arrived[b] = steps_done[0]
-            while queue and not final:                              # a freed slot takes the next queued utterance
+            while waiting and not final:                            # a freed slot takes the next queued utterance
                 free = [s_ for s_ in range(len(slots)) if fin[s_] and slots[s_] in seen and slots[s_] >= 0]
                 if not free:
                     break
-                s_, b = free[0], queue.pop(0)
-                eng.admit(s_, xs[b], mins[b], maxs[b], seq_id=b)
+                s_, b = free[0], waiting.pop(0)
+                eng.admit(s_, xs[b], mins[b], maxs[b], seq_id=b)    # reserves KV pages for the whole max_len
                 slots[s_] = b
                 fin[s_] = 0
-            if (not final and not queue and self.llm_small is not None and eng is self.llm and B - len(seen) <= self.llm_small.B
+            if not final and eng is self.llm:
+                # every running sequence must own the pages the steps up to the next poll will write (a no-op when admit /
+                # start reserved the whole max_len; raises when the allocator is exhausted instead of decoding into the
+                # shared scratch page)
+                eng.ensure_capacity(poll_every + 1, pos=eng.state[ST_POS].tolist(),
+                                    active=[s_ for s_ in range(len(slots)) if not fin[s_]])
+            if (not final and not waiting and self.llm_small is not None and eng is self.llm and B - len(seen) <= self.llm_small.B
                     and B - len(seen) > 0):
                 act = [s_ for s_ in range(len(slots)) if slots[s_] not in seen]
                 self.llm_small.compact_from(self.llm, act)
@@ -377,7 +400,10 @@ class TtsEngine:
 
         with torch.cuda.stream(main):
             self.llm.start(xs[:NS], mins[:NS], maxs[:NS], seed=seed)   # (captures serialise themselves: mmx/flow.py, Graphed)
-            done, max_steps = 1, (max(maxs) if B == NS else sum(maxs))      # with a queue the loop ends when all are seen
+            # without a queue max(maxs) steps end every sequence; with one, admissions happen only at polls, so the loop
+            # runs until every utterance has been seen (the bound only stops a runaway: each admitted utterance can wait
+            # up to poll_every steps for its slot on top of its own max_len)
+            done, max_steps = 1, (max(maxs) if B == NS else sum(maxs) + (B + 1) * poll_every)
             while done < max_steps:
                 k = min(poll_every, max_steps - done)
                 for _ in range(k):
@@ -387,6 +413,8 @@ class TtsEngine:
                 harvest(False)
                 if len(seen) == B:
                     break
+            if waiting:
+                raise RuntimeError(f"tts_batch: {len(waiting)} queued utterances were never admitted")
             harvest(True)
         timing = os.environ.get("MMX_TIMING")
         # The call returns finished audio, so it drains its streams on the host as well: the decode stream here, the

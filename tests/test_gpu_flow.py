@@ -179,3 +179,43 @@ def test_estimator_max_profile_length_bf16_vs_fp32(engines):
     b = engines[1].estimator_channels_first(x, mask, mu, t, spks, cond, True)
     assert a.shape == (2, 80, T) and torch.isfinite(a).all() and torch.isfinite(b).all()
     assert (a - b).abs().max().item() < 0.15 and (a - b).abs().mean().item() < 0.01
+
+
+def test_capture_survives_unreachable_engine_and_eager_collector():
+    """Regression for the process abort of round 2 (a recorded plan is a reference cycle; an engine dropped without
+    close() leaves its hipGraphs to Python's cyclic collector, which used to run INSIDE another engine's capture and
+    destroy them on the capturing thread).  An unreachable engine is left uncollected, the collector is made as eager as
+    it gets, and a new plan is captured: it must complete.  Also: eviction and close() destroy graphs deterministically."""
+    import gc
+    from mmx import shapes, synth
+    from mmx.flow import FlowEngine
+    sd = synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 3)
+    mk = lambda: FlowEngine(sd, dtype=1, parts=("estimator",))
+    mu, cond, spk = torch.randn(64, 80).cuda(), torch.zeros(64, 80).cuda(), torch.randn(80).cuda()
+    gc.collect()
+    gc.disable()
+    try:
+        e = mk()
+        e.cfm(mu, spk, cond)
+        e.cfm(mu, spk, cond)                                 # second call records the plan's graph
+        del e                                                # unreachable, NOT collected: its plan is a cycle
+    finally:
+        gc.enable()
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        e2 = mk()
+        e2.cfm(mu, spk, cond)
+        x = e2.cfm(mu, spk, cond).clone()                    # captures with the collector at its most eager
+    finally:
+        gc.set_threshold(*old)
+    assert torch.isfinite(x).all()
+    # eviction releases the evicted plan's graph on the spot and the accounting follows
+    e2.plan_budget_bytes = 1
+    p_old = next(iter(e2._plans.values()))
+    run_old = p_old.run
+    assert run_old.graph is not None
+    e2.cfm(mu[:32], spk, cond[:32])
+    assert run_old.graph is None and run_old.fn is None and len(e2._plans) == 1
+    e2.close()
+    assert e2.plan_bytes == 0 and not e2._plans

@@ -23,14 +23,17 @@ def rel_err(a, b):
 
 
 DT = [0, 1]   # F32, BF16
-TOL = {0: 2e-5, 1: 2e-2}
+# 2 / 3 = the split builds (bf16 weights, fp32 activations as 2 / 3 bf16 terms per MFMA product): the reference below
+# multiplies the fp32 activations with the bf16-rounded weights, so what is left is 2^-17 (X2) / fp32-level (X3) rounding
+DTX = [0, 1, 2, 3]
+TOL = {0: 2e-5, 1: 2e-2, 2: 4e-5, 3: 2e-5}
 
 
 def cast(x, dt):
     return x.to(torch.bfloat16 if dt == 1 else torch.float32)
 
 
-@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("dt", DTX)
 @pytest.mark.parametrize("M,N,K", [(1, 16, 32), (37, 80, 96), (500, 256, 320), (130, 1536, 256), (1000, 48, 336), (64, 64, 4864)])
 def test_gemm_plain(env, dt, M, N, K):
     L, ops = env
@@ -44,10 +47,10 @@ def test_gemm_plain(env, dt, M, N, K):
     ops.linear(xa, wp, K, dtype=dt, bias=b, act="gelu", out_f32=out, out_act=outa)
     ref = F.gelu(F.linear(xa.float(), wp[:, :K].float(), b))
     assert rel_err(out, ref) < TOL[dt]
-    assert rel_err(outa, ref) < (1e-2 if dt else TOL[dt])
+    assert rel_err(outa, ref) < (1e-2 if dt == 1 else TOL[dt])
 
 
-@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("dt", DTX)
 def test_gemm_epilogue_residual_mask_snake(env, dt):
     L, ops = env
     g = torch.Generator().manual_seed(3)
@@ -66,10 +69,10 @@ def test_gemm_epilogue_residual_mask_snake(env, dt):
     v = (F.leaky_relu(F.linear(xa.float(), wp[:, :K].float(), b), 0.1) + res) * mask[:, None]
     assert rel_err(out, v) < TOL[dt]
     sn = v + (alpha + 1e-9).reciprocal() * torch.sin(alpha * v) ** 2
-    assert rel_err(outa, sn) < (1e-2 if dt else 1e-4)
+    assert rel_err(outa, sn) < (1e-2 if dt == 1 else 1e-4)
 
 
-@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("dt", DTX)
 @pytest.mark.parametrize("Cin,Cout,k,dil,T", [(80, 1536, 7, 1, 50), (48, 48, 7, 9, 700), (96, 96, 7, 3, 333), (192, 192, 1, 1, 100),
                                               (320, 256, 3, 1, 64)])
 def test_conv1d(env, dt, Cin, Cout, k, dil, T):
@@ -93,7 +96,7 @@ def test_conv1d(env, dt, Cin, Cout, k, dil, T):
     assert rel_err(out, ref.transpose(1, 2)) < TOL[dt]
 
 
-@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("dt", DTX)
 @pytest.mark.parametrize("Cin,Cout,s,T", [(1536, 768, 5, 8), (96, 48, 2, 40), (192, 96, 3, 33), (384, 192, 4, 17)])
 def test_convtranspose1d(env, dt, Cin, Cout, s, T):
     L, ops = env
@@ -103,7 +106,7 @@ def test_convtranspose1d(env, dt, Cin, Cout, s, T):
     w = torch.randn(Cin, Cout, 2 * s, generator=g).cuda() / math.sqrt(Cin * 2)
     b = torch.randn(Cout, generator=g).cuda()
     xt = cast(x.transpose(1, 2).contiguous(), dt)
-    wq = cast(w, dt).float()
+    wq = w.to(L.WEIGHT_DT[dt]).float()
     wp = ops.pack_convtranspose1d(w, s, dt)
     out = torch.full((B, T * s, Cout), float("nan"), device="cuda")
     ops.convtranspose1d(xt, wp, T=T, Cin=Cin, Cout=Cout, stride=s, dtype=dt, batch=B, bias=b, out_f32=out)

@@ -240,12 +240,21 @@ def test_tts_batch_with_more_utterances_than_slots():
     g = torch.Generator().manual_seed(2)
     texts = [torch.randint(0, 4096, (1, 8), generator=g).cuda() for _ in range(7)]
     emb = [torch.randn(1, 192, generator=g).cuda() for _ in range(7)]
-    lens = [12, 30, 9, 21, 16, 27, 10]
-    e7 = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=7, max_ctx=128)
+    # the ADMITTED utterances (index >= 3) run for 100+ steps: far past the 32 rows an admission used to reserve, so a
+    # sequence that decodes into the shared scratch page shows up as different ids
+    lens = [12, 30, 9, 121, 16, 140, 104]
+    e7 = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=7, max_ctx=256)
     ref = [w.clone() for w in e7.tts_batch(texts, emb, seed=3, exact_steps=lens, group_size=2)]
-    e3 = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=3, max_ctx=128)
+    want = [t.tolist() for t in e7.last_tokens]
+    e3 = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=3, max_ctx=256)
     for rep in range(2):
         got = e3.tts_batch(texts, emb, seed=3, exact_steps=lens, group_size=2, poll_every=4)
         torch.cuda.synchronize()
+        assert [t.tolist() for t in e3.last_tokens] == want, rep
         for a, b in zip(got, ref):
             assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4, (rep, a.shape, b.shape)
+    # a single decode slot: admissions happen only at polls, the loop must still see every utterance
+    e1 = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=1, max_ctx=256)
+    got = e1.tts_batch(texts[:3], emb[:3], seed=3, exact_steps=lens[:3], group_size=2, poll_every=4)
+    torch.cuda.synchronize()
+    assert [t.tolist() for t in e1.last_tokens] == want[:3]
