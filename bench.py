@@ -308,7 +308,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "x"],
+                    help="x = the split build: bf16 weight stream, fp32 activations split into bf16 terms inside the MFMA products")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flow-bm-min", type=int, default=0, help="tuning: smallest tile height of the fused flow kernels")
     ap.add_argument("--flow-bm", type=int, default=0, help="cap the fused flow kernels' tile height (tuning: 32 leaves registers for co-resident decode waves)")
@@ -361,7 +362,7 @@ def main():
     cdev = "cpu" if rehearse else "cuda"
     from mmx.pipeline import TOKEN_RATE, SAMPLE_RATE
     from mmx.dist import gather_audio, shard_utterances
-    dt = 1 if a.dtype == "bf16" else 0
+    dt = {"bf16": 1, "f32": 0, "x": 2}[a.dtype]
     PER_GPU = 1 if a.workload in ("single", "longform") else a.per_gpu
     eng = make_engine(dt, dev, PER_GPU, 2048 if a.workload == "longform" else 640)
     if a.flow_bm:
@@ -461,7 +462,7 @@ def main():
                "rtf": round(el / audio_s * world, 5),
                "config": {"workload": wl, "utterances_per_gpu": PER_GPU, "audio_s_per_step": round(audio_s / a.steps, 2),
                           "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
-        if world == 1:
+        if world == 1 and dt != 2:
             out["roofline_lm"] = measure_lm_kernel(eng)
             out["roofline"] = measure_flow_kernel(eng, shape_log, a.steps) if (dt == 1 and a.workload == "batch" and shape_log) else out["roofline_lm"]
             if dt == 1 and a.workload == "batch" and shape_log:
@@ -494,14 +495,15 @@ def main():
                                            "x_realtime": round(1e4 / ms1, 1)}
                 del e1
                 if dt == 1:
-                    ef = TtsEngine(*w3, dtype=0, device=f"cuda:{local}", max_batch=PER_GPU, max_ctx=640)
+                    ef = TtsEngine(*w3, dtype=2, device=f"cuda:{local}", max_batch=PER_GPU, max_ctx=640)
                     fn = lambda: ef.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens)
-                    msf = _time_steps(fn, build=2, warmup=0, steps=2)
+                    msf = _time_steps(fn, build=2, warmup=1, steps=3)
                     a_s = sum(lens) / TOKEN_RATE
-                    out["parity_build"] = {"dtype": "f32", "value": round(a_s / (msf / 1e3), 2), "unit": "audio_s/s",
-                                           "ms_per_step": round(msf, 1), "steps": 2,
-                                           "note": "same workload on the fp32 build (exact-fp32 MFMA): the build held to ids "
-                                                   "identical / waveform <= 1e-3 by tests/test_gpu_pipeline.py"}
+                    out["parity_build"] = {"dtype": "x (bf16 weights, fp32 activations split into bf16 terms on the MFMA)",
+                                           "value": round(a_s / (msf / 1e3), 2), "unit": "audio_s/s",
+                                           "ms_per_step": round(msf, 1), "steps": 3,
+                                           "note": "same workload on the split build: the build held to ids identical / waveform "
+                                                   "<= 1e-3 by tests/test_gpu_split.py"}
                     del ef
                 del w3
             if not a.no_cpu_baseline:

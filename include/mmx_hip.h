@@ -168,6 +168,13 @@ int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                         int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk, int q_begin,
                         const int32_t* klen, hipStream_t stream);
+/* The same contract on the split build (MMX_X2): q / k / v / out fp32, V ROW-major (v[b][t][h*D + d], ldv elements per
+ * row — the QKV projection's own output, no transposed copy), both operands of Q K^T and P V split into bf16 hi + lo
+ * (3 MFMAs per product).  Replaces the same reference lines as mmx_attn_flash_bf16. */
+int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const float* k, int64_t ldk, int64_t k_bs,
+                     const float* v, int64_t ldv, int64_t v_bs, float* out, int64_t ldo, int64_t o_bs,
+                     int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk,
+                     int q_begin, const int32_t* klen, hipStream_t stream);
 /* The same contract (bf16 tensors in HBM) with Q, K, V^T and P quantised to OCP fp8 e4m3 inside the kernel and both
  * products on the fp8 MFMA (BASELINE config 5).  Accuracy: the bound stated in tests/test_gpu_kernels.py (<= 7 % of the output RMS). */
 int mmx_attn_flash_fp8(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,

@@ -669,9 +669,7 @@ extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, con
     if ((long)npairs * ((Tq + 63) / 64) < 96 && T_ >= 512 && !klen) {            // few queries, many keys: split the keys over waves
         const int nq16 = (Tq + 15) / 16;
         const size_t lds = 4 * (2 * 64 * 80 + 16 * 72) * sizeof(bf16_t);   // >= the merge buffers (4*16*65 + 128 floats)
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_splitk_kernel),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr_ != hipSuccess) return -(int)attr_ - 1000;
+        MMX_LDS_OPT_IN(attn_flash_splitk_kernel, lds);
         hipLaunchKernelGGL(attn_flash_splitk_kernel, dim3(8 * ((npairs + 7) / 8) * nq16), dim3(256), lds, stream, (const bf16_t*)q, ldq,
                            q_bs, (const bf16_t*)k, ldk, k_bs, (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask,
                            km_bs, chunk, nq16, H, npairs, q_begin);

@@ -1,0 +1,330 @@
+// Flash attention of the split build (MMX_X2): q / k / v and the output are fp32 in HBM, the products run on the bf16 MFMA
+// with BOTH operands of each product split into bf16 hi + lo (both are activations here, unlike the GEMMs, where the
+// weights are exact bf16): S = Qh Kh + Ql Kh + Qh Kl and O = Ph Vh + Pl Vh + Ph Vl — three MFMAs per product, the
+// lo x lo term (2^-18 relative) is dropped.  Same contract as mmx_attn_flash_bf16 except that V comes ROW-major
+// (v[b][t][h*D + d], the QKV projection's own output): the workgroup transposes its V tile on the way into LDS.
+//
+// Structure (as attn_flash_kernel, csrc/attention.hip): block = 4 waves x 16*MF queries, key tiles of 64, everything
+// computed transposed (S^T = K Q^T, O^T = V^T P^T) so a lane owns one query; K and V^T tiles double buffered in LDS with
+// register-staged prefetch two tiles ahead, one workgroup barrier per key tile; lazy-rescale online softmax.
+// LDS images are UNPADDED 128-byte rows (64 bf16) with the 16-byte chunk index XOR-ed with (row & 7): the ds_read_b128
+// fragment reads (16 rows x 2 adjacent chunks per 16-lane service group, MI355X_MICROARCH.md "LDS") then land on 16
+// distinct 16-byte bank slots, and the tile needs no pad columns (hi + lo planes of K, V^T and P: 96 KB at MF = 2).
+#include "common.h"
+#include "../../include/mmx_hip.h"
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+// byte offset of 16-byte chunk `c` (0..7) of 128-byte row `row`
+__device__ __forceinline__ int swz(int row, int c) { return row * 128 + ((c ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ void split4(const float x[4], uint2& hi, uint2& lo) {
+    hi.x = pack_bf16x2(x[0], x[1]);
+    hi.y = pack_bf16x2(x[2], x[3]);
+    lo.x = pack_bf16x2(x[0] - __uint_as_float(hi.x << 16), x[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack_bf16x2(x[2] - __uint_as_float(hi.y << 16), x[3] - __uint_as_float(hi.y & 0xffff0000u));
+}
+
+template <int MF>
+__global__ __launch_bounds__(256) void attn_flash_x_kernel(
+    const float* __restrict__ q, long ldq, long q_bs, const float* __restrict__ k, long ldk, long k_bs,
+    const float* __restrict__ v, long ldv, long v_bs, float* __restrict__ out, long ldo, long o_bs,
+    int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
+    int q_begin, const int32_t* __restrict__ klen) {
+    constexpr int D = 64, KT = 64, QW = 16 * MF;
+    constexpr int TILE = KT * 128;                     // bytes of one [64][64] bf16 image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kh = smem;                                   // [2 bufs][TILE]   keys x channels
+    char* Kl = Kh + 2 * TILE;
+    char* Vh = Kl + 2 * TILE;                          // [2 bufs][TILE]   channels x keys (V^T)
+    char* Vl = Vh + 2 * TILE;
+    char* Ph = Vl + 2 * TILE;                          // [4 waves][QW rows x 128 B]   queries x keys
+    char* Pl = Ph + 4 * QW * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / nq) * 8 + xcd;            // XCD-aware: the query tiles of one (batch, head) share an L2
+    if (pair >= npairs) return;
+    const int qt = slot % nq;
+    const int b = pair / nheads, h = pair % nheads;
+    const int qb = q_begin + qt * (4 * QW) + wave * QW;
+    q += (long)b * q_bs + h * D;
+    k += (long)b * k_bs + h * D;
+    v += (long)b * v_bs + h * D;
+    out += (long)b * o_bs + h * D;
+    const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
+    const float sc2 = scale * 1.44269504088896341f;
+    const int Tk = klen ? (klen[b] < Tn ? klen[b] : Tn) : Tn;
+    if (klen && q_begin + qt * (4 * QW) >= Tk) {        // a workgroup of pure padding rows
+        for (int id = tid; id < 4 * QW * 16; id += 256) {
+            const int i = q_begin + qt * (4 * QW) + (id >> 4);
+            if (i < Tn) *reinterpret_cast<float4*>(out + (long)i * ldo + (id & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+
+    // Q fragments, hi + lo: lane (query l16, k-group g) holds Q[q][ks*32 + 8g .. +7]
+    short8_t aqh[MF][2], aql[MF][2];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        int row = qb + mf * 16 + l16;
+        row = row < Tn ? row : Tn - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* qp = q + (long)row * ldq + ks * 32 + 8 * g;
+            const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
+            const float x0[4] = {a.x, a.y, a.z, a.w}, x1[4] = {c.x, c.y, c.z, c.w};
+            uint2 h0, l0, h1, l1;
+            split4(x0, h0, l0);
+            split4(x1, h1, l1);
+            aqh[mf][ks] = __builtin_bit_cast(short8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            aql[mf][ks] = __builtin_bit_cast(short8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        }
+    }
+    float4_t o[MF][4];
+    float m_run[MF], l_run[MF];
+    int lim[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[mf][i] = float4_t{0.f, 0.f, 0.f, 0.f};
+        m_run[mf] = -INFINITY;
+        l_run[mf] = 0.f;
+        const int i = qb + mf * 16 + l16;
+        int e = Tk;
+        if (chunk > 0) { int c2 = (i / chunk + 1) * chunk; e = c2 < e ? c2 : e; }
+        lim[mf] = e;
+    }
+    int kend = Tk;
+    if (chunk > 0) {
+        int qlast = q_begin + qt * (4 * QW) + 4 * QW - 1;
+        if (qlast > Tn - 1) qlast = Tn - 1;
+        int e = (qlast / chunk + 1) * chunk;
+        if (e < kend) kend = e;
+    }
+    const int ntile = (kend + KT - 1) / KT;
+    int vis_all = Tk;
+    if (chunk > 0) {
+        const int e = ((q_begin + qt * (4 * QW)) / chunk + 1) * chunk;
+        if (e < vis_all) vis_all = e;
+    }
+    char* Pwh = Ph + wave * QW * 128;
+    char* Pwl = Pl + wave * QW * 128;
+
+    // tile loads: 1024 chunks of 4 floats per operand, 4 per thread.
+    //   K: chunk id -> (key r = id >> 4, channels 4*(id & 15) ..): coalesced 256-byte rows
+    //   V: chunk id -> (key 2*(id >> 5) + (id & 1), channels 4*((id >> 1) & 15) ..): ADJACENT LANES hold the two keys of a
+    //      pair for the same channels; they swap halves (one shuffle pair) so each lane owns 2 channels x 2 keys and writes
+    //      (key 2p, key 2p+1) as one dword of the transposed image
+    float4 kreg[4], vreg[4];
+    auto load_tiles = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256;
+            const int kr = j0 + (id >> 4);
+            kreg[i] = kr < Tk ? *reinterpret_cast<const float4*>(k + (long)kr * ldk + (id & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int vr = j0 + 2 * (id >> 5) + (id & 1);
+            vreg[i] = vr < Tk ? *reinterpret_cast<const float4*>(v + (long)vr * ldv + ((id >> 1) & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256;
+            {
+                const int r = id >> 4, c4 = id & 15;   // 4 channels = half a 16-byte chunk of bf16
+                const float x[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
+                uint2 hi, lo;
+                split4(x, hi, lo);
+                const int off = buf * TILE + swz(r, c4 >> 1) + (c4 & 1) * 8;
+                *reinterpret_cast<uint2*>(Kh + off) = hi;
+                *reinterpret_cast<uint2*>(Kl + off) = lo;
+            }
+            {
+                const int par = id & 1, cc = (id >> 1) & 15, kp = id >> 5;
+                // even lane keeps channels 4cc, 4cc+1 and receives them of key 2kp+1; odd lane keeps 4cc+2, 4cc+3
+                const float s0 = par ? vreg[i].x : vreg[i].z, s1 = par ? vreg[i].y : vreg[i].w;
+                const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+                const float a0 = par ? r0 : vreg[i].x, b0 = par ? vreg[i].z : r0;     // channel d0: (key 2kp, key 2kp+1)
+                const float a1 = par ? r1 : vreg[i].y, b1 = par ? vreg[i].w : r1;     // channel d0 + 1
+                const int d0 = 4 * cc + 2 * par;
+                const unsigned h0 = pack_bf16x2(a0, b0), h1 = pack_bf16x2(a1, b1);
+                const unsigned l0 = pack_bf16x2(a0 - __uint_as_float(h0 << 16), b0 - __uint_as_float(h0 & 0xffff0000u));
+                const unsigned l1 = pack_bf16x2(a1 - __uint_as_float(h1 << 16), b1 - __uint_as_float(h1 & 0xffff0000u));
+                const int o0 = buf * TILE + swz(d0, kp >> 2) + (kp & 3) * 4, o1 = buf * TILE + swz(d0 + 1, kp >> 2) + (kp & 3) * 4;
+                *reinterpret_cast<unsigned*>(Vh + o0) = h0;
+                *reinterpret_cast<unsigned*>(Vl + o0) = l0;
+                *reinterpret_cast<unsigned*>(Vh + o1) = h1;
+                *reinterpret_cast<unsigned*>(Vl + o1) = l1;
+            }
+        }
+    };
+    load_tiles(0);
+    store_tiles(0);
+    if (ntile > 1) load_tiles(KT);
+    for (int jt = 0; jt < ntile; ++jt) {
+        const int j0 = jt * KT, buf = jt & 1;
+        __syncthreads();
+        if (jt + 1 < ntile) store_tiles(buf ^ 1);
+        if (jt + 2 < ntile) load_tiles(j0 + 2 * KT);
+        // S^T = K Q^T
+        float4_t s[MF][4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) s[mf][nf] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = buf * TILE + swz(nf * 16 + l16, ks * 4 + g);
+                const short8_t bkh = *reinterpret_cast<const short8_t*>(Kh + off);
+                const short8_t bkl = *reinterpret_cast<const short8_t*>(Kl + off);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bkh, aqh[mf][ks], s[mf][nf], 0, 0, 0);
+                    s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bkh, aql[mf][ks], s[mf][nf], 0, 0, 0);
+                    s[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bkl, aqh[mf][ks], s[mf][nf], 0, 0, 0);
+                }
+            }
+        }
+        const bool need_mask = km || (j0 + KT > vis_all);
+        bool kvis[4][4];
+        if (need_mask) {
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + nf * 16 + 4 * g + r;
+                    kvis[nf][r] = j < Tk && (!km || km[j] != 0.f);
+                }
+        }
+        auto softmax_tile = [&](auto mask_c, auto mf_c) {
+            constexpr bool MASK = decltype(mask_c)::value;
+            constexpr int mf = decltype(mf_c)::value;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = s[mf][nf][r];
+                    if constexpr (MASK) {
+                        const int j = j0 + nf * 16 + 4 * g + r;
+                        x = (j < lim[mf] && kvis[nf][r]) ? x : -INFINITY;
+                        s[mf][nf][r] = x;
+                    }
+                    mx = fmaxf(mx, x);
+                }
+            mx *= sc2;
+            float m_use = m_run[mf];
+            const bool grow = (mx - m_run[mf]) > 6.0f || m_run[mf] == -INFINITY;     // lazy rescale (see attention.hip)
+            if (__any(grow)) {
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[mf], mx);
+                const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[mf] - m_safe);
+                l_run[mf] *= alpha;
+#pragma unroll
+                for (int df = 0; df < 4; ++df)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[mf][df][r] *= alpha;
+                m_run[mf] = m_new;
+                m_use = m_safe;
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                float p[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[mf][nf][r], sc2, -m_use));
+                rs += (p[0] + p[1]) + (p[2] + p[3]);
+                uint2 hi, lo;
+                split4(p, hi, lo);
+                // keys nf*16 + 4g .. +3 of query row mf*16 + l16: half a chunk
+                const int off = swz(mf * 16 + l16, nf * 2 + (g >> 1)) + (g & 1) * 8;
+                *reinterpret_cast<uint2*>(Pwh + off) = hi;
+                *reinterpret_cast<uint2*>(Pwl + off) = lo;
+            }
+            l_run[mf] += rs;
+        };
+        if (need_mask) {
+            softmax_tile(std::true_type{}, std::integral_constant<int, 0>{});
+            if constexpr (MF > 1) softmax_tile(std::true_type{}, std::integral_constant<int, MF - 1>{});
+        } else {
+            softmax_tile(std::false_type{}, std::integral_constant<int, 0>{});
+            if constexpr (MF > 1) softmax_tile(std::false_type{}, std::integral_constant<int, MF - 1>{});
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        short8_t aph[MF][2], apl[MF][2];               // lane (q = l16, g): P[q][ks*32 + 8g .. +7]
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = swz(mf * 16 + l16, ks * 4 + g);
+                aph[mf][ks] = *reinterpret_cast<const short8_t*>(Pwh + off);
+                apl[mf][ks] = *reinterpret_cast<const short8_t*>(Pwl + off);
+            }
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = buf * TILE + swz(df * 16 + l16, ks * 4 + g);
+                const short8_t bvh = *reinterpret_cast<const short8_t*>(Vh + off);
+                const short8_t bvl = *reinterpret_cast<const short8_t*>(Vl + off);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bvh, aph[mf][ks], o[mf][df], 0, 0, 0);
+                    o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bvh, apl[mf][ks], o[mf][df], 0, 0, 0);
+                    o[mf][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bvl, aph[mf][ks], o[mf][df], 0, 0, 0);
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        l_run[mf] += __shfl_xor(l_run[mf], 16, 64);
+        l_run[mf] += __shfl_xor(l_run[mf], 32, 64);
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int i = qb + mf * 16 + l16;
+        if (i >= Tn) continue;
+        const float inv = l_run[mf] > 0.f ? 1.f / l_run[mf] : 0.f;
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+            *reinterpret_cast<float4*>(out + (long)i * ldo + df * 16 + 4 * g) =
+                make_float4(o[mf][df][0] * inv, o[mf][df][1] * inv, o[mf][df][2] * inv, o[mf][df][3] * inv);
+    }
+}
+
+template <int MF>
+int launch_flash_x(dim3 grid, hipStream_t stream, const float* q, long ldq, long q_bs, const float* k, long ldk, long k_bs,
+                   const float* v, long ldv, long v_bs, float* out, long ldo, long o_bs, int T_, float scale,
+                   const float* keymask, long km_bs, int chunk, int nq, int H, int npairs, int q_begin, const int32_t* klen) {
+    const size_t lds = (size_t)8 * 64 * 128 + (size_t)2 * 4 * 16 * MF * 128;
+    MMX_LDS_OPT_IN(attn_flash_x_kernel<MF>, lds);
+    hipLaunchKernelGGL((attn_flash_x_kernel<MF>), grid, dim3(256), lds, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_,
+                       scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+}  // namespace
+
+extern "C" int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const float* k, int64_t ldk, int64_t k_bs,
+                                const float* v, int64_t ldv, int64_t v_bs, float* out, int64_t ldo, int64_t o_bs,
+                                int B, int H, int T_, float scale, const float* keymask, int64_t km_bs, int chunk,
+                                int q_begin, const int32_t* klen, hipStream_t stream) {
+    MMX_CHECK_ARG(q && k && v && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0);
+    MMX_CHECK_ARG(q_begin >= 0 && q_begin < T_ && q_begin % 16 == 0);
+    MMX_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && q_bs % 4 == 0 && k_bs % 4 == 0 && v_bs % 4 == 0 && o_bs % 4 == 0);
+    MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0);
+    const int npairs = H * B, Tq = T_ - q_begin;
+    const bool small = (long)npairs * ((Tq + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
+    const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
+    dim3 grid(8 * ((npairs + 7) / 8) * nq);
+    if (small) return launch_flash_x<1>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    return launch_flash_x<2>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+}

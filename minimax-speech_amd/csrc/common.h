@@ -11,6 +11,24 @@
 // entry points without a matrix product: the split builds (MMX_X2 / MMX_X3 = 2 / 3) store activations as fp32
 #define MMX_ACT_DTYPE(d) ((d) >= 2 ? 0 : (d))
 
+// More than 64 KB of dynamic LDS is an opt-in per function AND per device.  MMX_LDS_OPT_IN(fn, bytes) raises the limit
+// of `fn` to 160 KB the first time the CURRENT device launches it (one flag per device, per call site = per template
+// instantiation; racing first calls write the same value).  The first launch of any shape is an eager one (the engines
+// record a graph only from the second call on), so the attribute write never happens inside a stream capture.
+#define MMX_LDS_OPT_IN(fn, bytes)                                                                                   \
+    do {                                                                                                            \
+        if ((bytes) > 64 * 1024) {                                                                                  \
+            static bool done_[64] = {};                                                                             \
+            int dev_ = 0;                                                                                           \
+            if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return MMX_EARG;                       \
+            if (!done_[dev_]) {                                                                                     \
+                hipError_t e_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                if (e_ != hipSuccess) return -1000 - (int)e_;                                                       \
+                done_[dev_] = true;                                                                                 \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+
 typedef unsigned short bf16_t;   // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) float float4_t;

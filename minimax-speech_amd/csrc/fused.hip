@@ -649,8 +649,8 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
 #define TAIL(TT, BM, PF, NW)                                                                              \
     do {                                                                                                   \
         const size_t lds = tail_lds<TT, BM, NW>();                                                         \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_tail_kernel<TT, BM, PF, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
+        MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
+        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW>), lds);                                            \
         hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
     if (dtype == MMX_BF16) {
@@ -691,8 +691,7 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     do {                                                                                                   \
         const size_t lds = resnet_lds<TT, BM, NW>(p.cin);                                                  \
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&est_resnet_kernel<TT, BM, PF, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (attr_ != hipSuccess) return -(int)attr_ - 1000;                                                \
+        MMX_LDS_OPT_IN((est_resnet_kernel<TT, BM, PF, NW>), lds);                                          \
         hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF, NW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
     // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count

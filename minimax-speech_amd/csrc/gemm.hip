@@ -377,12 +377,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t s) {
     size_t lds = (size_t)2 * (NS * BM + BN) * Frag<T>::LDS_ROW * sizeof(T);
     const size_t lds_epi = (size_t)4 * 16 * (BN / WN + 4) * sizeof(float);    // per-wave epilogue patches
     if (lds_epi > lds) lds = lds_epi;
-    if (lds > 64 * 1024) {
-        // more than 64 KB of dynamic LDS is an opt-in per function AND per device: set it on every such launch (a host-side
-        // attribute write, no stream operation) rather than remembering which devices have seen it
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_win_kernel<T, TA, NS, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -1000 - (int)e;
-    }
+    MMX_LDS_OPT_IN((gemm_win_kernel<T, TA, NS, BM, BN, WM, WN>), lds);
     hipLaunchKernelGGL((gemm_win_kernel<T, TA, NS, BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
     MMX_LAUNCH_CHECK();
     return MMX_OK;

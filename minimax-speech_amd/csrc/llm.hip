@@ -935,15 +935,8 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
     if (dtype == MMX_BF16 && page == 16 && Hq == 7 * Hkv && gqa_shared) {
         const size_t lds2 = (2 * 16 * 64 + 2 * 64) * 2 + (4 * 8 * 16 * 8 + 3 * 32 + 32 * 7 * 64 + (size_t)max_pages) * 4;
         MMX_CHECK_ARG(lds2 <= 160 * 1024);
-        if (lds2 > 64 * 1024) {
-            static bool raised[2] = {false, false};                  // idempotent: racing first calls set the same value
-            if (!raised[out_packed]) {
-                const void* fn = out_packed ? (const void*)decode_attn_gqa_kernel<true, 7> : (const void*)decode_attn_gqa_kernel<false, 7>;
-                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return -1000 - (int)e;
-                raised[out_packed] = true;
-            }
-        }
+        if (out_packed) MMX_LDS_OPT_IN((decode_attn_gqa_kernel<true, 7>), lds2);
+        else MMX_LDS_OPT_IN((decode_attn_gqa_kernel<false, 7>), lds2);
 #define DG(OPK) hipLaunchKernelGGL((decode_attn_gqa_kernel<OPK, 7>), dim3(Hkv * B), dim3(256), lds2, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, scale, (bf16_t*)out, ldo, B)
         if (out_packed) DG(true); else DG(false);
     } else if (dtype == MMX_BF16) { if (out_packed) DA(bf16_t, true); else DA(bf16_t, false); }

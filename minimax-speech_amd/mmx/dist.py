@@ -18,6 +18,9 @@ def shard_utterances(lengths: Sequence[int], world: int) -> List[List[int]]:
     return shards
 
 
+_gather_bufs = {}        # (rows, max_samples, device) -> (all_buf, all_meta): allocated once per shape, reused by every call
+
+
 def gather_audio(wavs: List[torch.Tensor], owned: List[int], n_total: int, max_samples: int,
                  group=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """All ranks end up with every utterance.  Returns (buf, lengths, row_of): utterance i (global index) is
@@ -31,13 +34,24 @@ def gather_audio(wavs: List[torch.Tensor], owned: List[int], n_total: int, max_s
     dev = wavs[0].device if wavs else torch.device("cpu")
     per = (n_total + world - 1) // world
     assert len(wavs) <= per
-    all_buf = torch.zeros(world * per, max_samples, dtype=torch.float32, device=dev)
-    all_meta = torch.full((world * per, 2), -1, dtype=torch.int64, device=dev)      # (global index, n samples)
+    key = (world * per, int(max_samples), str(dev))
+    if key not in _gather_bufs:
+        _gather_bufs.clear()                                   # one live shape at a time
+        _gather_bufs[key] = (torch.zeros(world * per, max_samples, dtype=torch.float32, device=dev),
+                             torch.empty((world * per, 2), dtype=torch.int64, device=dev))
+    all_buf, all_meta = _gather_bufs[key]
     buf, meta = all_buf[rank * per:(rank + 1) * per], all_meta[rank * per:(rank + 1) * per]   # this rank's slots, in place
+    meta_h = torch.full((per, 2), -1, dtype=torch.int64)        # (global index, n samples), one host->device copy
     for slot, (w, gi) in enumerate(zip(wavs, owned)):
         n = w.numel()
         buf[slot, :n] = w.reshape(-1)
-        meta[slot, 0], meta[slot, 1] = gi, n
+        buf[slot, n:].zero_()
+        meta_h[slot, 0], meta_h[slot, 1] = gi, n
+    for slot in range(len(wavs), per):
+        buf[slot].zero_()
+    if world == 1:
+        all_meta.fill_(-1)
+    meta.copy_(meta_h)
     if world > 1:
         dist.all_gather_into_tensor(all_meta, meta.clone(), group=group)
         dist.all_gather_into_tensor(all_buf, buf, group=group)      # in-place form: the input is this rank's slice of the output

@@ -465,7 +465,7 @@ class FlowEngine:
         ops.gemm(a_in, r["wr"], T, C, dtype=dt, lda=lda, cin=cin, ntaps=1, row_lo=0, row_hi=T, batch=B, a_bstride=T * lda,
                  bias=r["br"], residual=h2, ldr=C, r_bstride=T * C, out_f32=out_x, ldo_f=C, of_bstride=T * C)
 
-    def _tblock(self, w, x, B, T, mask, chunk, act_out=None, act_ld=0):
+    def _tblock(self, w, x, B, T, mask, chunk, act_out=None, act_ld=0, klen=None):
         """BasicTransformerBlock on fp32 x [B,T,256] (in place); optional compute-dtype copy of the result
         (x*mask) into act_out with row stride act_ld."""
         dt, C = self.dtype, self.C
@@ -488,9 +488,14 @@ class FlowEngine:
             qkv = self._new(B, T, 1536)
             ops.gemm(hn, w["wqkv"], T, 1536, dtype=dt, lda=C, cin=C, batch=B, a_bstride=T * C, out_act=qkv, ldo_a=1536,
                      oa_bstride=T * 1536)
-            ops.attn_dense(qkv, qkv[:, :, 512:], qkv[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536,
-                           ldo=512, q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt,
-                           keymask=mask, chunk=chunk)
+            if self.split:
+                ops.attn_flash_x(qkv, qkv[:, :, 512:], qkv[:, :, 1024:], ao, B=B, H=8, T=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                                 q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125,
+                                 keymask=(None if klen is not None else mask), chunk=chunk, klen=klen)
+            else:
+                ops.attn_dense(qkv, qkv[:, :, 512:], qkv[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536,
+                               ldo=512, q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt,
+                               keymask=mask, chunk=chunk)
         ops.gemm(ao, w["wo"], T, C, dtype=dt, lda=512, cin=512, batch=B, a_bstride=T * 512, bias=w["bo"], residual=x,
                  ldr=C, r_bstride=T * C, out_f32=x, ldo_f=C, of_bstride=T * C)
         ops.rownorm(x, w["n3g"], w["n3b"], 1e-5, rows=T, C_=C, batch=B, out_act=hn, dtype=dt)
@@ -531,7 +536,7 @@ class FlowEngine:
         self._resnet(self.down["res"], h0, 320, B, T, tv, mask, xs)
         for j, w in enumerate(self.down["blocks"]):
             last = j == 3
-            self._tblock(w, xs, B, T, mask, chunk, act_out=(cat[:, :, C:] if last else None), act_ld=2 * C)
+            self._tblock(w, xs, B, T, mask, chunk, act_out=(cat[:, :, C:] if last else None), act_ld=2 * C, klen=klen)
         a = self._new(B, T, C)
         ops.gemm(cat[:, :, C:], self.down_w, T, C, dtype=dt, lda=2 * C, cin=C, ntaps=3, row_off=-2, row_lo=0, row_hi=T,
                  batch=B, a_bstride=T * 2 * C, bias=self.down_b, rowmask=mask, rm_bstride=T, out_act=a, ldo_a=C,
@@ -543,14 +548,14 @@ class FlowEngine:
             for j, w in enumerate(st["blocks"]):
                 last = j == 3
                 if last and lastst:
-                    self._tblock(w, xs, B, T, mask, chunk, act_out=cat, act_ld=2 * C)
+                    self._tblock(w, xs, B, T, mask, chunk, act_out=cat, act_ld=2 * C, klen=klen)
                 elif last:
-                    self._tblock(w, xs, B, T, mask, chunk, act_out=a, act_ld=C)
+                    self._tblock(w, xs, B, T, mask, chunk, act_out=a, act_ld=C, klen=klen)
                 else:
-                    self._tblock(w, xs, B, T, mask, chunk)
+                    self._tblock(w, xs, B, T, mask, chunk, klen=klen)
         self._resnet(self.up["res"], cat, 2 * C, B, T, tv, mask, xs)
         for j, w in enumerate(self.up["blocks"]):
-            self._tblock(w, xs, B, T, mask, chunk, act_out=(a if j == 3 else None), act_ld=C)
+            self._tblock(w, xs, B, T, mask, chunk, act_out=(a if j == 3 else None), act_ld=C, klen=klen)
         a2 = self._new(B, T, C)
         ops.conv1d(a, self.up_w, T=T, Cin=C, k=3, pad_left=2, dtype=dt, batch=B, bias=self.up_b, rowmask=mask, out_act=a2)
         c1 = self._new(B, T, C, f32=True)

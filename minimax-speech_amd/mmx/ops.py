@@ -217,6 +217,16 @@ def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, 
                                      _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen), stream()), "mmx_attn_flash_bf16")
 
 
+def attn_flash_x(q, k, v, out, *, B, H, T, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, keymask=None, chunk=0, q_begin=0,
+                 km_bs=None, klen=None):
+    """The split build's flash attention: fp32 q / k / v (V row-major) and fp32 out (include/mmx_hip.h)."""
+    if klen is not None:
+        assert klen.dtype == torch.int32 and klen.numel() >= B
+    check(load().mmx_attn_flash_x(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(v), i64(ldv), i64(v_bs),
+                                  _p(out), i64(ldo), i64(o_bs), B, H, T, C.c_float(scale), _p(keymask),
+                                  i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen), stream()), "mmx_attn_flash_x")
+
+
 # ----------------------------------------------------------------------------- LM decode
 def pack_skinny(w, *, dtype, kscale=None, interleave_half=0):
     """w: [N, K] tensor in the weight dtype -> MFMA-fragment-ordered copy (see csrc/llm.hip)."""

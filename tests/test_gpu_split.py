@@ -79,6 +79,40 @@ def test_gemm_split_is_fp32_grade_on_bf16_weights():
     assert errs[X3] < 2e-6 and errs[X2] < 2e-5 and errs[0] < 2e-6
 
 
+@pytest.mark.parametrize("B,T,chunk,mode", [(2, 200, 0, "none"), (16, 333, 0, "klen"), (2, 130, 50, "none"), (3, 97, 0, "mask"),
+                                            (2, 1000, 50, "none"), (4, 257, 0, "qbegin")])
+def test_attn_flash_x_vs_float64(B, T, chunk, mode):
+    """fp32 q / k / v with hi + lo bf16 splits of both operands (3 MFMAs per product) against float64 softmax attention:
+    2^-17 per operand -> 4e-5 of the output range (stated in the module docstring)."""
+    from mmx import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    H, D = 8, 64
+    qkv = (torch.randn(B, T, 3 * H * D, generator=g) * 1.5).cuda()
+    lens = [T - (i * 37) % (T // 2) for i in range(B)] if mode in ("klen", "mask") else [T] * B
+    lens[0] = T
+    mask = torch.zeros(B, T)
+    for i, n in enumerate(lens):
+        mask[i, :n] = 1
+    mask = mask.cuda()
+    q_begin = 64 if mode == "qbegin" else 0
+    out = torch.full((B, T, H * D), float("nan"), device="cuda")
+    ops.attn_flash_x(qkv, qkv[:, :, 512:], qkv[:, :, 1024:], out, B=B, H=H, T=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                     q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, chunk=chunk, q_begin=q_begin,
+                     keymask=(mask if mode == "mask" else None),
+                     klen=(torch.tensor(lens, dtype=torch.int32, device="cuda") if mode == "klen" else None))
+    x = qkv.double().reshape(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = (x[0] @ x[1].transpose(-1, -2)) * 0.125
+    vis = mask.bool()[:, None, None, :].expand(B, H, T, T).clone()
+    if chunk:
+        i = torch.arange(T, device="cuda")
+        vis &= (i[None, :] < ((i[:, None] // chunk + 1) * chunk))[None, None]
+    ref = (torch.softmax(s.masked_fill(~vis, float("-inf")), -1) @ x[2]).permute(0, 2, 1, 3).reshape(B, T, H * D)
+    for i, n in enumerate(lens):                            # padding query rows are don't-care (zeros or finite)
+        a, r = out[i, q_begin:n], ref[i, q_begin:n]
+        assert torch.isfinite(a).all()
+        assert rel_err(a, r) < 4e-5, (i, rel_err(a, r))
+
+
 def test_lm_teacher_forced_logp_split(golden_dir):
     """24-layer LM, teacher-forced log-probs against the reference golden: X3 is held to the fp32 build's bound."""
     from mmx.llm import LlmEngine
