@@ -222,6 +222,23 @@ int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N
                     const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
                     void* out_act, int64_t ldo_a, int dtype, int flags, const float* kgamma, hipStream_t stream);
 
+/* mmx_skinny2 — the decode-step projection of the split build (dtype MMX_X3), B <= 32 rows:
+ *   out[b][n] = epi( rstd[b] * sum_k (x[b][k] * kgamma[k]) * Wp[n][k] ),  x fp32 row-major [B][ldx], Wp the bf16 pack of
+ *   mmx_pack_skinny (no kscale), kgamma [K] or NULL, rs != 0: rstd[b] = rsqrt(mean_k x[b][k]^2 + eps), else 1.
+ *   epi 0: + bias -> out;  epi 1: SwiGLU of [gate tile | up tile] pairs -> out[b][n], n < N = the activation width;
+ *   epi 2: out[b][n] += acc (+ bias), in place (residual projections).
+ *   tiles_per_wg (1 | 2): 16-column output tiles a workgroup produces from ONE pass over x (a workgroup is 8 waves =
+ *   8 k slices; each wave splits its slice of x into bf16 terms once and reuses it for every tile).
+ *   ksplit (1, or > 1 with epi 2): K is also cut into `ksplit` slices across workgroups; partial tiles go through
+ *   `part` (>= ksplit * ceil(N/16) * ceil(B/16)*4 * 64 floats) and are summed in slice order by the workgroup that
+ *   takes the last ticket of its tile (`tickets`: ceil(N/16) int32, all zero before the first launch; the kernel
+ *   leaves them zero).  Launches that share part / tickets must be ordered on one stream.
+ *   Replaces the q/k/v, o, gate/up (+SiLU*up), down projections and the llm_decoder head of one decode step
+ *   (speech/cosyvoice/llm/llm.py:359-371,749; HF Qwen2 MLP / attention projections). */
+int mmx_skinny2(const float* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, const float* kgamma,
+                int rs, float eps, int epi, float* out, int64_t ldo, int tiles_per_wg, int ksplit, float* part,
+                int64_t part_floats, int32_t* tickets, int dtype, hipStream_t stream);
+
 /* RoPE (HF rotate_half; inv_freq[D/2] fp32 = 1/theta^(2i/D) as HF computes it) on q/k of
  * qkv[b][t][: (Hq+2Hkv)*D] at position pos[b] + t, K/V appended to the paged cache, q written as T.  Cache layout:
  * kc/vc [n_pages][Hkv][page][D] T, block_table [B][max_pages] int32.  rows = tokens per sequence. */

@@ -51,6 +51,7 @@ class LlmEngine:
     # decode attention: batches of at least this many sequences use the GQA-shared kernel (one workgroup per kv head serving
     # its 7 query heads), smaller ones the per-head kernel (more workgroups for the few sequences there are)
     gqa_min_batch = 1 << 30
+    use_v2 = True            # split build: decode-step projections on csrc/decode.hip (False: the round-2 kernel with NS terms)
 
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
@@ -189,11 +190,39 @@ class LlmEngine:
             ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha,
                             x_packed=pk, out_packed=pk)
 
+    # decode-step projections of the split build (csrc/decode.hip): (output tiles per workgroup, k slices across workgroups)
+    v2_cfg = dict(qkv=(1, 1), o=(1, 1), gu=(2, 1), down=(2, 8), head=(2, 1))
+
+    def _layers_split_decode(self, h, B, pos, block_table):
+        """One decode step of the split build on the mmx_skinny2 projections (B <= 32 rows): 5 launches per layer."""
+        dt, H, I, c = self.dtype, self.H, self.I, self.v2_cfg
+        NQ = (self.Hq + 2 * self.Hkv) * self.D
+        if not hasattr(self, "_v2"):
+            J = c["down"][1]
+            self._v2 = dict(qkv=torch.empty(self.B, NQ, device=self.dev), att=torch.empty(self.B, self.Hq * self.D, device=self.dev),
+                            act=torch.empty(self.B, I, device=self.dev),
+                            part=torch.empty(J * ((H + 15) // 16) * ops.packed_rows(self.B) // 4 * 64, device=self.dev),
+                            tickets=torch.zeros((H + 15) // 16, dtype=torch.int32, device=self.dev))
+        S = self._v2
+        qkv, att, act = S["qkv"][:B], S["att"][:B], S["act"][:B]
+        for l, w in enumerate(self.layers):
+            ops.skinny2(h, w["wqkv"], qkv, B=B, K=H, N=NQ, dtype=dt, bias=w["bqkv"], kgamma=w["g1"], rs=True, eps=self.eps, epi=0,
+                        tiles_per_wg=c["qkv"][0])
+            ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
+                            Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, per_head=True)
+            ops.skinny2(att, w["wo"], h, B=B, K=self.Hq * self.D, N=H, dtype=dt, epi=2, tiles_per_wg=c["o"][0])
+            ops.skinny2(h, w["wgu"], act, B=B, K=H, N=I, dtype=dt, kgamma=w["g2"], rs=True, eps=self.eps, epi=1,
+                        tiles_per_wg=c["gu"][0])
+            ops.skinny2(act, w["wdown"], h, B=B, K=I, N=H, dtype=dt, epi=2, tiles_per_wg=c["down"][0], ksplit=c["down"][1],
+                        part=S["part"], tickets=S["tickets"])
+
     def _layers_split(self, h, B, rows, pos, block_table):
         """The split build of _layers: every GEMM input is the fp32 tensor itself (row-major), the RMSNorm gains ride as
         kgamma, all intermediates are fp32."""
         dt, H, I = self.dtype, self.H, self.I
         n = B * rows
+        if rows == 1 and n <= 32 and self.use_v2:
+            return self._layers_split_decode(h, B, pos, block_table)
         qkv = torch.empty(n, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
         q = torch.empty(n, self.Hq * self.D, device=self.dev)
         att = torch.empty(n, self.Hq * self.D, device=self.dev)
@@ -215,7 +244,10 @@ class LlmEngine:
 
     def _tail(self, B, packed=False):
         """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences."""
-        if self.split:
+        if self.split and B <= 32 and self.use_v2:
+            ops.skinny2(self.h, self.wdec, self.logits, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec,
+                        kgamma=self.norm_w, rs=True, eps=self.eps, epi=0, tiles_per_wg=self.v2_cfg["head"][0])
+        elif self.split:
             ops.skinny_gemm(self.h, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
                             eps=self.eps, epi=0, out_f32=self.logits, kgamma=self.norm_w)
         else:

@@ -276,6 +276,14 @@ def skinny_gemm(x, wp, *, B, K, N, dtype, bias=None, rs=False, eps=1e-6, epi=0, 
           "mmx_skinny_gemm")
 
 
+def skinny2(x, wp, out, *, B, K, N, dtype, bias=None, kgamma=None, rs=False, eps=1e-6, epi=0, tiles_per_wg=1, ksplit=1,
+            part=None, tickets=None, ldx=None, ldo=None):
+    """The split build's decode-step projection (include/mmx_hip.h mmx_skinny2): fp32 x [B, K] -> fp32 out [B, N]."""
+    check(load().mmx_skinny2(_p(x), i64(ldx if ldx is not None else K), B, K, N, _p(wp), _p(bias), _p(kgamma), int(rs),
+                             C.c_float(eps), epi, _p(out), i64(ldo if ldo is not None else N), tiles_per_wg, ksplit, _p(part),
+                             i64(part.numel() if part is not None else 0), _p(tickets), dtype, stream()), "mmx_skinny2")
+
+
 def rope_kv_store(qkv, inv_freq, pos, q_out, kc, vc, block_table, *, B, rows, Hq, Hkv, page, dtype):
     ld = (Hq + 2 * Hkv) * 64
     check(load().mmx_rope_kv_store(_p(qkv), i64(ld), i64(rows * ld), B, rows, Hq, Hkv, 64, _p(inv_freq), _p(pos),

@@ -159,3 +159,64 @@ def test_composed_pipeline_split_ids_identical_waveform_1e3(case):
         print(f"split build composed: {len(got)} ids identical, waveform max abs err {err:.3e} "
               f"(std {case['wav'].std().item():.3f}, SNR {TP._snr_db(case['wav'], wav.cpu()):.1f} dB)")
         assert wav.shape == case["wav"].shape and err <= TP.WAV_TOL_F32, err
+
+
+@pytest.mark.parametrize("B,K,N,epi,rs,tw,J", [(1, 896, 1152, 0, True, 1, 1), (32, 896, 1152, 0, True, 1, 1), (17, 896, 896, 2, False, 1, 1),
+                                               (32, 896, 4864, 1, True, 2, 1), (9, 896, 4864, 1, True, 1, 1), (32, 4864, 896, 2, False, 2, 8),
+                                               (3, 4864, 896, 2, False, 1, 8), (32, 896, 6564, 0, True, 2, 1), (16, 896, 6564, 0, True, 1, 1)])
+def test_skinny2_vs_float64(B, K, N, epi, rs, tw, J):
+    """The decode-step projection kernel (csrc/decode.hip) against float64 on the same values, fp32 level (X3); with the
+    k split across workgroups (J = 8) it is launched 20 times back to back on the same tickets / partial buffers: every
+    launch must return the same bits (slice-order summation, tickets left at zero)."""
+    from mmx import ops
+    g = torch.Generator().manual_seed(B * 31 + N + J)
+    x = (torch.randn(B, K, generator=g) * 3).cuda()
+    w = (torch.randn((2 * N if epi == 1 else N), K, generator=g) / math.sqrt(K)).to(torch.bfloat16).cuda()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).cuda() if rs else None
+    bias = torch.randn(N, generator=g).cuda() if epi == 0 else None
+    wp = ops.pack_skinny(w.contiguous(), dtype=X3, interleave_half=(N if epi == 1 else 0))
+    xd = x.double()
+    acc = (xd * (gam.double() if rs else 1.0)) @ w.double().t()
+    if rs:
+        acc = acc * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6)
+    res = torch.randn(B, N, generator=g).cuda()
+    ref = acc + bias.double() if epi == 0 else (F.silu(acc[:, :N]) * acc[:, N:] if epi == 1 else res.double() + acc)
+    nt = (N + 15) // 16
+    part = torch.full((J * nt * ops.packed_rows(B) // 4 * 64,), float("nan"), device="cuda") if J > 1 else None
+    tickets = torch.zeros(nt, dtype=torch.int32, device="cuda") if J > 1 else None
+    outs = []
+    for rep in range(20 if J > 1 else 2):
+        out = res.clone() if epi == 2 else torch.full((B, N), float("nan"), device="cuda")
+        ops.skinny2(x, wp, out, B=B, K=K, N=N, dtype=X3, bias=bias, kgamma=gam, rs=rs, eps=1e-6, epi=epi, tiles_per_wg=tw, ksplit=J,
+                    part=part, tickets=tickets)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert rel_err(outs[0], ref) < 3e-6, rel_err(outs[0], ref)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    if J > 1:
+        assert int(tickets.abs().sum()) == 0
+
+
+def test_lm_split_decode_v2_equals_round2_kernel(golden_dir):
+    """The decode step on csrc/decode.hip produces the log-probs of the same step on the round-2 kernel (NS = 3) to fp32
+    rounding (different summation trees), at batch 1 and at batch 32 (two 16-row tiles, k split across workgroups)."""
+    from mmx import shapes, synth
+    from mmx.llm import LlmEngine
+    sd = synth.synth_state_dict(shapes.llm_manifest(layers=2), 0)
+    z = torch.zeros(1, 0, dtype=torch.long, device="cuda")
+    g = torch.Generator().manual_seed(4)
+    for B in (1, 32):
+        texts = [torch.randint(0, 151936, (1, 6 + b % 5), generator=g).cuda() for b in range(B)]
+        lp = {}
+        for v2 in (False, True):
+            eng = LlmEngine(sd, dtype=X3, max_batch=B, max_ctx=128, use_graphs=False)
+            eng.use_v2 = v2
+            xs = [eng.build_lm_input(t, z, z) for t in texts]
+            eng.start(xs, [12] * B, [12] * B, seed=3, want_logp=True)
+            for _ in range(6):
+                eng.step()
+            lp[v2] = (eng.logp.clone(), eng.tokens())
+        d = (lp[True][0] - lp[False][0]).abs().max().item()
+        print(f"decode v2 vs round-2 kernel, batch {B}: max |dlogp| {d:.3e}")
+        assert d < 2e-4 and lp[True][1] == lp[False][1]

@@ -2,7 +2,7 @@
 compaction to the 16-slot engine, harvest / poll schedule, worker threads) with the flow + DAC stage replaced by
 zero waveforms — a measurement tool, not a product switch.
 
-    python tools/decode_alone.py [--dtype bf16|f32] [--per-gpu 32] [--steps 5]
+    python tools/decode_alone.py [--dtype bf16|f32|x] [--per-gpu 32] [--steps 5] [--v1] [--cfg gu=2,1:down=2,8]
 """
 import argparse
 import os
@@ -28,8 +28,14 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--v1", action="store_true", help="split build: the round-2 projection kernel instead of csrc/decode.hip")
+    ap.add_argument("--cfg", default="", help="split build: LlmEngine.v2_cfg overrides, e.g. gu=1,1:down=2,8")
     a = ap.parse_args()
-    dt = 1 if a.dtype == "bf16" else 0
+    dt = {"bf16": 1, "f32": 0, "x": 2}[a.dtype]
+    from mmx.llm import LlmEngine
+    LlmEngine.use_v2 = not a.v1
+    if a.cfg:
+        LlmEngine.v2_cfg = dict(LlmEngine.v2_cfg, **{kv.split("=")[0]: tuple(int(v) for v in kv.split("=")[1].split(",")) for kv in a.cfg.split(":")})
     eng = DecodeOnly(synth.synth_state_dict(shapes.llm_manifest(), 0), synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0),
                      synth.synth_state_dict(shapes.dac_decoder_manifest(80), 0), dtype=dt, max_batch=a.per_gpu, max_ctx=640)
     lens = torch.randint(50, 501, (a.per_gpu,), generator=torch.Generator().manual_seed(3)).tolist()
