@@ -222,22 +222,36 @@ int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N
                     const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
                     void* out_act, int64_t ldo_a, int dtype, int flags, const float* kgamma, hipStream_t stream);
 
-/* mmx_skinny2 — the decode-step projection of the split build (dtype MMX_X3), B <= 32 rows:
- *   out[b][n] = epi( rstd[b] * sum_k (x[b][k] * kgamma[k]) * Wp[n][k] ),  x fp32 row-major [B][ldx], Wp the bf16 pack of
- *   mmx_pack_skinny (no kscale), kgamma [K] or NULL, rs != 0: rstd[b] = rsqrt(mean_k x[b][k]^2 + eps), else 1.
- *   epi 0: + bias -> out;  epi 1: SwiGLU of [gate tile | up tile] pairs -> out[b][n], n < N = the activation width;
- *   epi 2: out[b][n] += acc (+ bias), in place (residual projections).
- *   tiles_per_wg (1 | 2): 16-column output tiles a workgroup produces from ONE pass over x (a workgroup is 8 waves =
- *   8 k slices; each wave splits its slice of x into bf16 terms once and reuses it for every tile).
+/* Decode-step projections of the split build (dtype MMX_X3), B <= 32 sequences, on SPLIT-PLANE activations:
+ *   an activation x [B][K] (already multiplied by the RMSNorm gain of its consumer) is stored as 3 bf16 planes
+ *   hi + mid + lo = x, each in MFMA A-fragment order:
+ *     xs[plane s][m][kb][lane = g*16 + l16][j] = term s of x[m*16 + l16][kb*32 + g*8 + j]      (ceil(B/16) row tiles m)
+ *   The producer of an activation splits it once; consumers load fragments straight into MFMA operands.
+ *   Sum-of-squares tables `ssq` [32 rows][64 tile slots] fp32 carry the RMSNorm statistic the same way: a producer of the
+ *   residual stream writes, per 16-column output tile, each row's sum of squares over that tile's columns; the consumer
+ *   adds a row's slots (unused slots must be zero: allocate zeroed).
+ *
+ * mmx_decode_prep: x fp32 [B][K] (K <= 1024) -> h (copy, optional), xs = planes of x * gamma, ssq of x.  The head of a
+ *   decode step: the sampler's next input embedding becomes the residual stream and the first projection's operand.
+ * mmx_skinny2:  acc[b][n] = rstd[b] * sum_k xs[b][k] * Wp[n][k],  rstd from ssq_in (NULL: 1), Wp the bf16 pack of
+ *   mmx_pack_skinny (no kscale);
+ *   epi 0: out[b][n] = acc + bias;
+ *   epi 1: SwiGLU of [gate tile | up tile] pairs, written as planes xs_out of width N (the down projection's operand);
+ *   epi 2: out[b][n] += acc (+ bias) in place (the residual stream); if xs_out: planes of out * gamma_next; if ssq_out:
+ *          the per-tile sums of squares of out.
+ *   tiles_per_wg (1 | 2): 16-column tiles a workgroup produces from ONE pass over xs (8 waves = 8 k slices).
  *   ksplit (1, or > 1 with epi 2): K is also cut into `ksplit` slices across workgroups; partial tiles go through
  *   `part` (>= ksplit * ceil(N/16) * ceil(B/16)*4 * 64 floats) and are summed in slice order by the workgroup that
- *   takes the last ticket of its tile (`tickets`: ceil(N/16) int32, all zero before the first launch; the kernel
- *   leaves them zero).  Launches that share part / tickets must be ordered on one stream.
- *   Replaces the q/k/v, o, gate/up (+SiLU*up), down projections and the llm_decoder head of one decode step
- *   (speech/cosyvoice/llm/llm.py:359-371,749; HF Qwen2 MLP / attention projections). */
-int mmx_skinny2(const float* x, int64_t ldx, int B, int K, int N, const void* wp, const float* bias, const float* kgamma,
-                int rs, float eps, int epi, float* out, int64_t ldo, int tiles_per_wg, int ksplit, float* part,
-                int64_t part_floats, int32_t* tickets, int dtype, hipStream_t stream);
+ *   takes the last ticket of its tile (`tickets`: ceil(N/16) int32, zero before the first launch; left zero).  Launches
+ *   that share part / tickets must be ordered on one stream.
+ *   Replace the q/k/v, o, gate/up (+SiLU*up), down projections and the llm_decoder head of one decode step
+ *   (speech/cosyvoice/llm/llm.py:359-371,749; HF Qwen2 MLP / attention projections / RMSNorm). */
+int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const float* gamma, float* h, int64_t ldh, void* xs,
+                    float* ssq, hipStream_t stream);
+int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, const float* bias, const float* ssq_in, float eps,
+                int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
+                int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,
+                hipStream_t stream);
 
 /* RoPE (HF rotate_half; inv_freq[D/2] fp32 = 1/theta^(2i/D) as HF computes it) on q/k of
  * qkv[b][t][: (Hq+2Hkv)*D] at position pos[b] + t, K/V appended to the paged cache, q written as T.  Cache layout:
@@ -256,6 +270,8 @@ int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, in
  * the in-kernel cosf/sinf of pos * inv_freq.  out_packed: bit 0 = write out in the MMX_OUT_PACKED order (K = Hq*D);
  * bit 1 = use the one-workgroup-per-query-head kernel even where the GQA-shared one applies (bf16, page = 16, Hq = 7 Hkv:
  * one workgroup per kv head serves its 7 query heads, Q K^T on the MFMA with the queries split into bf16 hi + lo). */
+/* out_packed bits: 1 = output in the packed A-fragment order of T; 2 = force the per-head kernel; 4 = output as SPLIT PLANES
+ * (see mmx_skinny2; dtype MMX_F32 / the split builds only). */
 int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                     const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
                     float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream);

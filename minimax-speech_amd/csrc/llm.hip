@@ -567,7 +567,9 @@ struct Raw8 {
     }
 };
 
-template <typename T, bool OPK>
+// OM: how the attention output is stored - 0 row-major T, 1 the packed A-fragment order of T (bf16 / fp32 builds, batch > 8),
+// 2 split planes (the split build: 3 bf16 planes hi + mid + lo in A-fragment order, csrc/decode.hip)
+template <typename T, int OM>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
     const float* __restrict__ rope_tab, const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc,
@@ -693,7 +695,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             L += gl[g2] * w;
             o += part[g2 * D + tid] * w;
         }
-        out[OPK ? act_packed_index<T>(b, h * D + tid, Hq * D) : (long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
+        if constexpr (OM == 2) {
+            const int nkb = Hq * D / 32, col = h * D + tid;
+            const long ps = (long)((nseq + 15) / 16) * nkb * 512;
+            const long idx = ((((long)(b >> 4) * nkb + (col >> 5)) * 64) + (((col & 31) >> 3) << 4) + (b & 15)) * 8 + (col & 7);
+            bf16_t* pl = reinterpret_cast<bf16_t*>(out);
+            const float v = o / L;
+            const bf16_t hh = f2bf(v);
+            const float r1 = v - bf2f(hh);
+            const bf16_t mm = f2bf(r1);
+            pl[idx] = hh;
+            pl[ps + idx] = mm;
+            pl[2 * ps + idx] = f2bf(r1 - bf2f(mm));
+        } else {
+            out[OM == 1 ? act_packed_index<T>(b, h * D + tid, Hq * D) : (long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
+        }
     }
 }
 
@@ -923,15 +939,17 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
                                int page, float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream) {
     dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
-    MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 3);
+    MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 7);
     const bool gqa_shared = !(out_packed & 2);         // bit 1: force the per-head kernel (A/B measurements, tests)
+    const bool split_out = out_packed & 4;             // bit 2: output as split planes (fp32 build of the kernel only)
+    MMX_CHECK_ARG(!split_out || (dtype == MMX_F32 && !(out_packed & 1)));
     out_packed &= 1;
     const size_t max_ctx = (size_t)max_pages * page;
     (void)max_ctx;
     size_t lds = (3 * 64 + 2 * 32 + 32 * 64 + (size_t)max_pages) * 4;
     MMX_CHECK_ARG(lds <= 160 * 1024);
     dim3 grid(8 * ((Hkv * B + 7) / 8) * (Hq / Hkv));
-#define DA(T, OPK) hipLaunchKernelGGL((decode_attn_kernel<T, OPK>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B)
+#define DA(T, OM) hipLaunchKernelGGL((decode_attn_kernel<T, OM>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B)
     if (dtype == MMX_BF16 && page == 16 && Hq == 7 * Hkv && gqa_shared) {
         const size_t lds2 = (2 * 16 * 64 + 2 * 64) * 2 + (4 * 8 * 16 * 8 + 3 * 32 + 32 * 7 * 64 + (size_t)max_pages) * 4;
         MMX_CHECK_ARG(lds2 <= 160 * 1024);
@@ -939,8 +957,8 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
         else MMX_LDS_OPT_IN((decode_attn_gqa_kernel<false, 7>), lds2);
 #define DG(OPK) hipLaunchKernelGGL((decode_attn_gqa_kernel<OPK, 7>), dim3(Hkv * B), dim3(256), lds2, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, scale, (bf16_t*)out, ldo, B)
         if (out_packed) DG(true); else DG(false);
-    } else if (dtype == MMX_BF16) { if (out_packed) DA(bf16_t, true); else DA(bf16_t, false); }
-    else if (dtype == MMX_F32) { if (out_packed) DA(float, true); else DA(float, false); }
+    } else if (dtype == MMX_BF16) { if (out_packed) DA(bf16_t, 1); else DA(bf16_t, 0); }
+    else if (dtype == MMX_F32) { if (split_out) DA(float, 2); else if (out_packed) DA(float, 1); else DA(float, 0); }
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;

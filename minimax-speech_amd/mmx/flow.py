@@ -679,6 +679,7 @@ class FlowEngine:
             self.enc = None                                # encoder state (tokens), built on first use
             self.tok_done = 0                              # tokens encoded and solved
             self.z = eng.rand_noise[0, :, :self.Tcap].t().contiguous().to(eng.dev)      # [Tcap, 80] the fixed noise
+            self.cond = torch.zeros(self.Tcap, 80, device=eng.dev)    # prompt latents on the prompt's frames, zero elsewhere
             self.spks2 = torch.zeros(2, 80, device=eng.dev)
             self.ids = torch.zeros(self.Tcap // 2 + eng.L + 8, dtype=torch.int64, device=eng.dev)
             self.graphs, self._win = {}, {}
@@ -843,19 +844,25 @@ class FlowEngine:
         W = st.window(n)
         W["x"].copy_(st.z[tb:T].reshape(1, n, 80))
         W["mu2"][0].copy_(st.enc["mu"][tb:T])
+        W["cond2"][0].copy_(st.cond[tb:T])
         for s in range(self.n_timesteps):
             d = self._estimator_stream(st, s, W["x"], W["mu2"], st.spks2, W["cond2"], tb, T)
             ops.cfg_euler(W["x"], d[0, tb:T], d[1, tb:T], self.cfg, st.dt[s], n * 80)
         st.lat[tb:T].copy_(W["x"][0])
 
     @torch.no_grad()
-    def stream_hop(self, st, ids: torch.Tensor, embedding: torch.Tensor) -> torch.Tensor:
-        """One streaming hop without prompt: ids [Lt] = all tokens so far + 3 look-ahead tokens.  Encodes and solves only
+    def stream_hop(self, st, ids: torch.Tensor, embedding: torch.Tensor, prompt_feat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One streaming hop: ids [Lt] = (prompt tokens ++) all tokens so far + 3 look-ahead tokens.  Encodes and solves only
         what the state has not seen; each (done, Lt) pair is one recorded hipGraph over the state's buffers (a hop is
-        ~1 500 short launches), reused by every later utterance that runs on this state.  Returns latents fp32 [2(Lt-3), 80]."""
+        ~1 500 short launches), reused by every later utterance that runs on this state.  prompt_feat [Tp, 80] (first hop of
+        a zero-shot utterance, flow.py:472-498): the latents of the prompt's frames, the `cond` rows of those frames.
+        Returns latents fp32 [2(Lt-3), 80] of ALL frames (prompt frames first)."""
         Lt = ids.numel()
         T, tb = Lt - self.L, st.tok_done
-        if tb == 0:                                          # speaker projection, once per utterance
+        if tb == 0:                                          # speaker projection and prompt condition, once per utterance
+            st.cond.zero_()
+            if prompt_feat is not None and prompt_feat.shape[0]:
+                st.cond[:prompt_feat.shape[0]].copy_(prompt_feat.to(self.dev, torch.float32))
             st.spks2.zero_()
             en = self._new(1, self.spk_dim)
             ops.rownorm(embedding.to(self.dev, torch.float32).contiguous(), self.spk_gamma, None, 1e-30, rows=1, C_=self.spk_dim,
@@ -1007,11 +1014,13 @@ class FlowEngine:
         """token [1,Lt], prompt_token [1,Lp] ints; prompt_feat [1,Tp,80]; embedding [1,192] (device tensors).
         Returns fp32 [T2, 80] time-major latents of the NEW tokens (prompt part dropped).  stream_state (a StreamState from
         stream_open, streaming non-final calls): only the frames that state has not solved yet go through the ODE."""
-        Lt = token.numel()
-        if (stream_state is not None and streaming and not finalize and prompt_token.numel() == 0 and prompt_feat.shape[1] == 0
-                and reference_mels is None and (2 * (Lt - self.L)) % self.est_chunk == 0 and 2 * (Lt - self.L) <= stream_state.Tcap
-                and stream_state.tok_done < Lt - self.L):
-            return self.stream_hop(stream_state, token.reshape(-1).to(self.dev, torch.int64), embedding)
+        Lt, Lp, Tp = token.numel(), prompt_token.numel(), prompt_feat.shape[1]
+        La = Lp + Lt                                         # the flow runs over prompt ++ tokens (flow.py:472-476)
+        if (stream_state is not None and streaming and not finalize and Tp == 2 * Lp
+                and reference_mels is None and (2 * (La - self.L)) % self.est_chunk == 0 and 2 * (La - self.L) <= stream_state.Tcap
+                and stream_state.tok_done < La - self.L):
+            ids = torch.cat([prompt_token.reshape(-1), token.reshape(-1)]).to(self.dev, torch.int64)
+            return self.stream_hop(stream_state, ids, embedding, prompt_feat[0] if Tp else None)[Tp:]
         mu, spks, cond, mel_len1 = self.conditions(token, prompt_token, prompt_feat, embedding, streaming, finalize, reference_mels)
         x = self.cfm(mu, spks, cond, streaming)
         return x[mel_len1:]

@@ -193,36 +193,47 @@ class LlmEngine:
     # decode-step projections of the split build (csrc/decode.hip): (output tiles per workgroup, k slices across workgroups)
     v2_cfg = dict(qkv=(1, 1), o=(1, 1), gu=(2, 1), down=(2, 8), head=(2, 1))
 
-    def _layers_split_decode(self, h, B, pos, block_table):
-        """One decode step of the split build on the mmx_skinny2 projections (B <= 32 rows): 5 launches per layer."""
-        dt, H, I, c = self.dtype, self.H, self.I, self.v2_cfg
-        NQ = (self.Hq + 2 * self.Hkv) * self.D
+    def _planes(self):
+        """Static buffers of the split-plane decode step (csrc/decode.hip): activation planes, sum-of-squares tables (zeroed:
+        unused tile slots must read 0), partial tiles and tickets of the down projection's cross-workgroup k split."""
         if not hasattr(self, "_v2"):
-            J = c["down"][1]
-            self._v2 = dict(qkv=torch.empty(self.B, NQ, device=self.dev), att=torch.empty(self.B, self.Hq * self.D, device=self.dev),
-                            act=torch.empty(self.B, I, device=self.dev),
-                            part=torch.empty(J * ((H + 15) // 16) * ops.packed_rows(self.B) // 4 * 64, device=self.dev),
+            H, I, R = self.H, self.I, ops.packed_rows(self.B)
+            NQ = (self.Hq + 2 * self.Hkv) * self.D
+            bf = lambda K: torch.zeros(3, R * K, dtype=torch.bfloat16, device=self.dev)
+            J = self.v2_cfg["down"][1]
+            self._v2 = dict(qkv=torch.empty(self.B, NQ, device=self.dev), xs_a=bf(H), xs_b=bf(H), xs_att=bf(self.Hq * self.D), xs_act=bf(I),
+                            ssq_a=torch.zeros(32, ops.SSQ_SLOTS, device=self.dev), ssq_b=torch.zeros(32, ops.SSQ_SLOTS, device=self.dev),
+                            part=torch.empty(J * ((H + 15) // 16) * (R // 4) * 64, device=self.dev),
                             tickets=torch.zeros((H + 15) // 16, dtype=torch.int32, device=self.dev))
-        S = self._v2
-        qkv, att, act = S["qkv"][:B], S["att"][:B], S["act"][:B]
+        return self._v2
+
+    def _layers_split_decode(self, x_in, h, B, pos, block_table):
+        """One decode step of the split build on split-plane activations (B <= 32 sequences): one prep launch, then 5
+        launches per layer.  x_in -> h (residual stream, fp32) and the planes of h * gamma; every projection's epilogue
+        writes the planes (and the RMSNorm partial sums) its consumer reads.  Leaves the planes of h * norm_w and the sums
+        of squares of h in xs_a / ssq_a for the head."""
+        dt, H, I, c, S = self.dtype, self.H, self.I, self.v2_cfg, self._planes()
+        NQ = (self.Hq + 2 * self.Hkv) * self.D
+        qkv = S["qkv"][:B]
+        ops.decode_prep(x_in, S["xs_a"], S["ssq_a"], B=B, K=H, gamma=self.layers[0]["g1"], h=h)
         for l, w in enumerate(self.layers):
-            ops.skinny2(h, w["wqkv"], qkv, B=B, K=H, N=NQ, dtype=dt, bias=w["bqkv"], kgamma=w["g1"], rs=True, eps=self.eps, epi=0,
+            g_next = self.layers[l + 1]["g1"] if l + 1 < len(self.layers) else self.norm_w
+            ops.skinny2(S["xs_a"], w["wqkv"], B=B, K=H, N=NQ, dtype=dt, bias=w["bqkv"], ssq_in=S["ssq_a"], eps=self.eps, epi=0, out=qkv,
                         tiles_per_wg=c["qkv"][0])
-            ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
-                            Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, per_head=True)
-            ops.skinny2(att, w["wo"], h, B=B, K=self.Hq * self.D, N=H, dtype=dt, epi=2, tiles_per_wg=c["o"][0])
-            ops.skinny2(h, w["wgu"], act, B=B, K=H, N=I, dtype=dt, kgamma=w["g2"], rs=True, eps=self.eps, epi=1,
+            ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, S["xs_att"], B=B, Hq=self.Hq,
+                            Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, per_head=True, out_split=True)
+            ops.skinny2(S["xs_att"], w["wo"], B=B, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out=h, xs_out=S["xs_b"],
+                        gamma_next=w["g2"], ssq_out=S["ssq_b"], tiles_per_wg=c["o"][0])
+            ops.skinny2(S["xs_b"], w["wgu"], B=B, K=H, N=I, dtype=dt, ssq_in=S["ssq_b"], eps=self.eps, epi=1, xs_out=S["xs_act"],
                         tiles_per_wg=c["gu"][0])
-            ops.skinny2(act, w["wdown"], h, B=B, K=I, N=H, dtype=dt, epi=2, tiles_per_wg=c["down"][0], ksplit=c["down"][1],
-                        part=S["part"], tickets=S["tickets"])
+            ops.skinny2(S["xs_act"], w["wdown"], B=B, K=I, N=H, dtype=dt, epi=2, out=h, xs_out=S["xs_a"], gamma_next=g_next,
+                        ssq_out=S["ssq_a"], tiles_per_wg=c["down"][0], ksplit=c["down"][1], part=S["part"], tickets=S["tickets"])
 
     def _layers_split(self, h, B, rows, pos, block_table):
         """The split build of _layers: every GEMM input is the fp32 tensor itself (row-major), the RMSNorm gains ride as
         kgamma, all intermediates are fp32."""
         dt, H, I = self.dtype, self.H, self.I
         n = B * rows
-        if rows == 1 and n <= 32 and self.use_v2:
-            return self._layers_split_decode(h, B, pos, block_table)
         qkv = torch.empty(n, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
         q = torch.empty(n, self.Hq * self.D, device=self.dev)
         att = torch.empty(n, self.Hq * self.D, device=self.dev)
@@ -242,11 +253,16 @@ class LlmEngine:
             ops.skinny_gemm(h, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_f32=act, kgamma=w["g2"])
             ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h)
 
-    def _tail(self, B, packed=False):
-        """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences."""
+    def _tail(self, B, packed=False, planes_ready=False):
+        """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences.
+        planes_ready (split build): xs_a / ssq_a already hold the planes of h * norm_w (the decode step's last projection
+        wrote them); otherwise they are made from self.h first."""
         if self.split and B <= 32 and self.use_v2:
-            ops.skinny2(self.h, self.wdec, self.logits, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec,
-                        kgamma=self.norm_w, rs=True, eps=self.eps, epi=0, tiles_per_wg=self.v2_cfg["head"][0])
+            S = self._planes()
+            if not planes_ready:
+                ops.decode_prep(self.h, S["xs_a"], S["ssq_a"], B=B, K=self.H, gamma=self.norm_w)
+            ops.skinny2(S["xs_a"], self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, ssq_in=S["ssq_a"],
+                        eps=self.eps, epi=0, out=self.logits, tiles_per_wg=self.v2_cfg["head"][0])
         elif self.split:
             ops.skinny_gemm(self.h, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
                             eps=self.eps, epi=0, out_f32=self.logits, kgamma=self.norm_w)
@@ -260,6 +276,9 @@ class LlmEngine:
 
     def _decode_step(self):
         B = self.B
+        if self.split and B <= 32 and self.use_v2:
+            self._layers_split_decode(self.x_in, self.h, B, self.state[ST_POS], self.block_table)
+            return self._tail(B, planes_ready=True)
         self.h.copy_(self.x_in)
         if not self.packed:
             self.h_act[:B].copy_(self.x_in)

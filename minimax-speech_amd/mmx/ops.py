@@ -276,12 +276,41 @@ def skinny_gemm(x, wp, *, B, K, N, dtype, bias=None, rs=False, eps=1e-6, epi=0, 
           "mmx_skinny_gemm")
 
 
-def skinny2(x, wp, out, *, B, K, N, dtype, bias=None, kgamma=None, rs=False, eps=1e-6, epi=0, tiles_per_wg=1, ksplit=1,
-            part=None, tickets=None, ldx=None, ldo=None):
-    """The split build's decode-step projection (include/mmx_hip.h mmx_skinny2): fp32 x [B, K] -> fp32 out [B, N]."""
-    check(load().mmx_skinny2(_p(x), i64(ldx if ldx is not None else K), B, K, N, _p(wp), _p(bias), _p(kgamma), int(rs),
-                             C.c_float(eps), epi, _p(out), i64(ldo if ldo is not None else N), tiles_per_wg, ksplit, _p(part),
-                             i64(part.numel() if part is not None else 0), _p(tickets), dtype, stream()), "mmx_skinny2")
+SSQ_SLOTS = 64
+
+
+def plane_elems(B, K):
+    """bf16 elements of ONE plane of a split-plane activation [B, K] (include/mmx_hip.h)."""
+    return packed_rows(B) * K
+
+
+def split_planes(x):
+    """Host-side statement of the split-plane format (tests): x fp32 [B, K] -> bf16 [3, plane_elems]."""
+    B, K = x.shape
+    out, r = [], x.float()
+    for _ in range(3):
+        t = r.to(torch.bfloat16)
+        out.append(pack_act(t, BF16))
+        r = r - t.float()
+    return torch.stack(out)
+
+
+def merge_planes(xs, B, K):
+    """bf16 [3, plane_elems] -> fp32 [B, K] (hi + mid + lo)."""
+    return sum(unpack_act(xs[s], B, K, BF16).float() for s in range(3))
+
+
+def decode_prep(x, xs, ssq, *, B, K, gamma=None, h=None):
+    check(load().mmx_decode_prep(_p(x), i64(x.shape[-1]), B, K, _p(gamma), _p(h), i64(h.shape[-1] if h is not None else 0), _p(xs),
+                                 _p(ssq), stream()), "mmx_decode_prep")
+
+
+def skinny2(xs, wp, *, B, K, N, dtype, bias=None, ssq_in=None, eps=1e-6, epi=0, out=None, ldo=None, xs_out=None, gamma_next=None,
+            ssq_out=None, tiles_per_wg=1, ksplit=1, part=None, tickets=None):
+    """The split build's decode-step projection on split-plane activations (include/mmx_hip.h mmx_skinny2)."""
+    check(load().mmx_skinny2(_p(xs), B, K, N, _p(wp), _p(bias), _p(ssq_in), C.c_float(eps), epi, _p(out),
+                             i64(ldo if ldo is not None else N), _p(xs_out), _p(gamma_next), _p(ssq_out), tiles_per_wg, ksplit,
+                             _p(part), i64(part.numel() if part is not None else 0), _p(tickets), dtype, stream()), "mmx_skinny2")
 
 
 def rope_kv_store(qkv, inv_freq, pos, q_out, kc, vc, block_table, *, B, rows, Hq, Hkv, page, dtype):
@@ -298,11 +327,12 @@ def paged_attn(q, pos, kc, vc, block_table, out, *, B, rows, Hq, Hkv, page, dtyp
 
 
 def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None, out_packed=False,
-                per_head=False):
-    """per_head: the one-workgroup-per-query-head kernel even where the GQA-shared one applies (measurements, tests)."""
+                per_head=False, out_split=False):
+    """per_head: the one-workgroup-per-query-head kernel even where the GQA-shared one applies (measurements, tests).
+    out_split: `out` receives split planes (the split build's decode step, include/mmx_hip.h)."""
     check(load().mmx_decode_attn(_p(qkv), i64((Hq + 2 * Hkv) * 64), B, Hq, Hkv, 64, _p(inv_freq), _p(rope_tab), _p(pos), _p(kc),
                                  _p(vc), _p(block_table), block_table.shape[1], page, C.c_float(0.125), _p(out),
-                                 i64(Hq * 64), dtype, int(bool(out_packed)) | (2 if per_head else 0), stream()), "mmx_decode_attn")
+                                 i64(Hq * 64), dtype, int(bool(out_packed)) | (2 if per_head else 0) | (4 if out_split else 0), stream()), "mmx_decode_attn")
 
 
 def swiglu(gu, out, *, rows, I, dtype):

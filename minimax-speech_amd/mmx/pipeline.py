@@ -21,6 +21,15 @@ TOKEN_RATE = 25          # FSQ tokens per second (config.yaml:12)
 SAMPLE_RATE = 24000
 
 
+def fade_in_out(fade_in, fade_out, window):
+    """speech/cosyvoice/utils/common.py:142-150 on device tensors: the head of `fade_in` is mixed with the tail of
+    `fade_out` over the two halves of `window`."""
+    n = window.shape[0] // 2
+    out = fade_in.clone()
+    out[..., :n] = out[..., :n] * window[:n] + fade_out[..., -n:] * window[n:]
+    return out
+
+
 class TtsEngine:
     def __init__(self, llm_sd, flow_sd, dac_sd, dtype=BF16, device="cuda", max_batch=1, max_ctx=2048,
                  dac_rates=(5, 4, 4, 3, 2), use_graphs=True, attn="bf16"):
@@ -95,25 +104,48 @@ class TtsEngine:
         pt = flow_prompt_speech_token if flow_prompt_speech_token is not None else z
         return self.token2wav(toks.reshape(1, -1), pt, pf, flow_embedding)
 
+    MEL_CACHE = 8            # cli/model.py:258: frames of overlap between two passes
+
+    @staticmethod
+    def fade_window(n: int, device) -> torch.Tensor:
+        """np.hamming(2n) (cli/model.py:262) with each pair (w[i], w[i + n]) scaled to sum to one: a cross-fade of two equal
+        signals is then the identity (the raw halves sum to 1.08)."""
+        import numpy as np
+        w = torch.from_numpy(np.hamming(2 * n)).float()
+        s_ = w[:n] + w[n:]
+        return torch.cat([w[:n] / s_, w[n:] / s_]).to(device)
+
     @torch.no_grad()
     def tts_stream(self, text, flow_embedding, seed=0, exact_steps=None, token_hop=25, latents_out=None, forced=None,
-                   cache=True):
-        """Streaming synthesis of one (long) utterance: BASELINE config 5 / cli/model.py:336-369 (`stream=True`).
-        The AR decode runs ahead on its own stream (captured decode step); every `token_hop` tokens (+ the flow's
-        look-ahead) the chunk-causal flow is solved over all tokens so far, as the reference does.  The DAC decoder is
-        NOT causal: a sample depends on `dac.ctx_left` latent frames before and `dac.ctx_right` after its own frame
-        (DacDecoderEngine.receptive_field).  So a hop renders the frames whose right context is already final — it holds
-        the last `ctx_right` frames back for the next hop — from a window with `ctx_left` frames of left context, and
-        the concatenated chunks equal the offline decode of the same latents sample for sample (this replaces the
-        reference's HiFT mel / source cache and its cross-fade, cli/model.py:304-311).  Yields waveform chunks [1, n]
-        (device); `latents_out` (a list) receives the latent frames [n, 80] behind each chunk; `forced` [1, steps]
-        teacher-forces the accepted ids (LlmEngine.start).  cache=True: hops solve only their new frames (FlowEngine.StreamState);
-        cache=False recomputes all frames at every hop, as the reference does — the two agree (tests/test_gpu_stream.py)."""
+                   cache=True, prompt_text=None, llm_prompt_speech_token=None, flow_prompt_speech_token=None,
+                   prompt_speech_feat=None):
+        """Streaming synthesis of one (long) utterance: BASELINE config 5 / cli/model.py:336-378 (`stream=True`), zero-shot
+        prompts included (prompt_text / llm_prompt_speech_token condition the LM, llm.py:691-703; flow_prompt_speech_token /
+        prompt_speech_feat the flow, flow.py:472-498).
+        The AR decode runs ahead on its own stream (captured decode step).  Hop schedule as the reference: the first hop takes
+        token_hop + prompt_token_pad tokens (pad = ceil(Lp / 25) * 25 - Lp, model.py:338-341), later hops token_hop; a hop runs
+        once `hop + look-ahead` tokens exist and solves the chunk-causal flow over the tokens so far; the closing pass solves
+        everything WITHOUT chunk masks (model.py:371-378 leaves `stream` at False).
+        Rendering (the DAC decoder replaces HiFT and its mel / source caches, model.py:298-311; rule restated in
+        oracle/stream.py): the DAC is NOT causal — a sample depends on `dac.ctx_left` latent frames before and `dac.ctx_right`
+        after its own frame — so a pass renders the frames whose right context is final, from a window with ctx_left frames of
+        ALREADY RENDERED left context; streaming passes agree on finished frames, so their chunks equal the offline decode of
+        the same latents sample for sample.  Like the reference (model.py:306-311) a streaming pass holds the samples of its
+        last MEL_CACHE frames back: the next streaming pass emits them unchanged, the CLOSING pass — the one seam where two
+        passes disagree about the frames around it — renders those frames again from its own latents and cross-fades the two
+        renderings (utils/common.py:142-150 fade_in_out, window of model.py:262 normalised to unit sum).
+        Yields waveform chunks [1, n] (device); `latents_out` (a list) receives the latent frames [n, 80] each chunk was
+        rendered from; `forced` [1, steps] teacher-forces the accepted ids (LlmEngine.start).  cache=True: hops solve only
+        their new frames (FlowEngine.StreamState); cache=False recomputes all frames at every hop, as the reference does."""
         from .llm import ST_FIN, ST_NOUT
         assert self.llm.B == 1
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
-        x = self.llm.build_lm_input(text, z, z)
+        pt = prompt_text if prompt_text is not None else z
+        lps = llm_prompt_speech_token if llm_prompt_speech_token is not None else z
+        fpt = flow_prompt_speech_token if flow_prompt_speech_token is not None else z
+        pf = prompt_speech_feat if prompt_speech_feat is not None else zf
+        x = self.llm.build_lm_input(text, pt, lps)
         n_text = int(text.numel())
         mn = exact_steps if exact_steps is not None else n_text * 2
         mx = exact_steps if exact_steps is not None else n_text * 20
@@ -122,48 +154,70 @@ class TtsEngine:
         lm, caller = self._lm_stream, torch.cuda.current_stream()
         lm.wait_stream(caller)
         L = self.flow.L
-        CL, CR = self.dac.ctx_left, self.dac.ctx_right
+        CL, CR, MC = self.dac.ctx_left, self.dac.ctx_right, self.MEL_CACHE
+        Lp = int(fpt.numel())
+        pad = -(-Lp // token_hop) * token_hop - Lp              # model.py:338
         with torch.cuda.stream(lm):
             self.llm.start([x], [mn], [mx], seed=seed, forced=forced)
-        done, offset, emitted = 1, 0, 0                    # decode steps issued, tokens rendered, latent frames emitted
-        sstate = self.flow.stream_open(2 * mx) if cache else None
-        tail = None                                        # the last ctx_left latent frames already emitted
+        done, offset = 1, 0                                  # decode steps issued, tokens consumed by hops
+        emitted = 0                                          # latent frames rendered
+        sstate = self.flow.stream_open(2 * (mx + Lp)) if cache else None
+        tail = None                                          # the last ctx_left + MEL_CACHE rendered latent frames
+        held = None                                          # samples of the last MEL_CACHE rendered frames, not yet emitted
+        held_lat = None
 
         def render(n_tok, finalize):
-            nonlocal emitted, tail
+            nonlocal emitted, tail, held, held_lat
             ev = torch.cuda.Event()
             ev.record(lm)
             caller.wait_event(ev)                          # tokens [0, n_tok) are written
             tok = self.llm.out_tokens[0:1, :n_tok].to(torch.int64)
-            # like the reference, the closing pass runs WITHOUT the chunk masks (cli/model.py:371-378 leaves `stream` at
-            # its default False): its frames differ from what a streaming pass would give, so the left context of the
-            # window is the emitted tail kept from the previous pass, not this pass's version of those frames
-            lat = self.flow.inference_time_major(tok, z, zf, flow_embedding, streaming=not finalize, finalize=finalize,
+            lat = self.flow.inference_time_major(tok, fpt, pf, flow_embedding, streaming=not finalize, finalize=finalize,
                                                  stream_state=sstate)
             T2 = lat.shape[0]
             hi = T2 if finalize else T2 - CR               # frames whose right context is final
             if hi <= emitted:
                 return None
-            seg = lat[emitted:] if tail is None else torch.cat([tail, lat[emitted:]], dim=0)
-            nctx = 0 if tail is None else tail.shape[0]
+            re = MC if (finalize and held is not None) else 0       # the closing pass renders the held frames again
+            start = emitted - re
+            ctx = None if tail is None else tail[:tail.shape[0] - re][-CL:]
+            seg = lat[start:] if ctx is None or ctx.shape[0] == 0 else torch.cat([ctx, lat[start:]], dim=0)
+            nctx = 0 if ctx is None else ctx.shape[0]
             n = seg.shape[0]
             zt = torch.empty(1, n, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
             ops.copy2d(seg.contiguous(), F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=n, cols=80)
-            wav = self.dac.decode_time_major(zt, 1, n)[:, 0, nctx * self.hop:(nctx + hi - emitted) * self.hop]
-            if latents_out is not None:
-                latents_out.append(lat[emitted:hi].clone())
-            tail = seg[max(0, nctx + hi - emitted - CL):nctx + hi - emitted].clone()
+            wav = self.dac.decode_time_major(zt, 1, n)[:, 0, nctx * self.hop:(nctx + hi - start) * self.hop]
+            lat_used = lat[emitted:hi]
+            if finalize:
+                if re:
+                    wav = fade_in_out(wav, held, self.fade_window(MC * self.hop, self.dev))
+                    lat_used = torch.cat([held_lat, lat_used], 0)
+                out, held, held_lat = wav, None, None
+            else:
+                keep = min(MC, hi - emitted)
+                out = wav[:, :wav.shape[1] - keep * self.hop]
+                if held is not None:
+                    out = torch.cat([held, out], dim=1)
+                    lat_used = torch.cat([held_lat, lat_used], 0)
+                held = wav[:, wav.shape[1] - keep * self.hop:].clone()
+                held_lat, lat_used = lat_used[lat_used.shape[0] - keep:].clone(), lat_used[:lat_used.shape[0] - keep]
+            if latents_out is not None and lat_used.shape[0]:
+                latents_out.append(lat_used.clone())
+            new = lat[emitted:hi]
+            tail = (new if tail is None else torch.cat([tail, new], 0))[-(CL + MC):].clone()
             emitted = hi
-            return wav
+            return out if out.shape[1] else None
 
         try:
             while True:
                 with torch.cuda.stream(lm):
                     st = self.llm.state[:, 0].tolist()         # D2H copy on the LM stream: waits for the steps issued so far
                 n_out, finished = st[ST_NOUT], bool(st[ST_FIN]) or done >= mx
-                while n_out - offset >= token_hop + L:
-                    w = render(offset + token_hop + L, finalize=False)
-                    offset += token_hop
+                this_hop = token_hop + pad if offset == 0 else token_hop          # model.py:341
+                while n_out - offset >= this_hop + L:
+                    w = render(offset + this_hop + L, finalize=False)
+                    offset += this_hop
+                    this_hop = token_hop
                     if w is not None:
                         yield w
                 if finished:
@@ -174,7 +228,7 @@ class TtsEngine:
                 # keep the decode a few ACCEPTED tokens ahead of the renderer.  The look-ahead is counted in tokens, not in
                 # steps (ids above the EOS id advance the step counter without producing a token, llm.py:755-756), and at
                 # least one step is issued per round, so the loop always makes progress.
-                k = min(mx - done, max(1, offset + token_hop + L + 8 - n_out))
+                k = min(mx - done, max(1, offset + this_hop + L + 8 - n_out))
                 with torch.cuda.stream(lm):
                     for _ in range(k):
                         self.llm.step()

@@ -74,20 +74,35 @@ class CosyVoice2Model:
         start = token_offset * self.flow.token_mel_ratio
         if st is None and finalize:                        # one-shot synthesis: decode everything
             return self.hift.decode(lat[:, :, start:])[:, 0]
-        # streaming session: `emitted` latent frames are out; this hop renders the frames whose right context is final
-        # from a window whose left context is the emitted tail kept from the previous hop (the closing pass runs without
-        # chunk masks, as in the reference, so its own version of those frames differs)
-        emitted, tail = (start, None) if st is None else (st["emitted"], st["tail"])
+        # Streaming session (rule stated in mmx/pipeline.py::tts_stream and oracle/stream.py): `emitted` latent frames are
+        # rendered; a pass renders the frames whose right context is final from a window whose left context is the tail of
+        # ALREADY RENDERED latents.  Like the reference (model.py:306-311) a streaming pass holds the samples of its last
+        # mel_cache_len frames back; the next streaming pass emits them unchanged (the passes agree), the closing pass
+        # (no chunk masks: its version of every frame differs) renders them again and cross-fades (fade_in_out, :304-311).
+        MC, CL, CR = self.mel_cache_len, self.dac_ctx_left, self.dac_ctx_right
+        emitted, tail, held = (0, None, None) if st is None else (st["emitted"], st["tail"], st["held"])
         T2 = lat.shape[2]
-        hi = T2 if finalize else T2 - self.dac_ctx_right
+        hi = T2 if finalize else T2 - CR
         if hi <= emitted:
             return lat.new_zeros(1, 0)
-        seg = lat[:, :, emitted:] if tail is None else torch.cat([tail, lat[:, :, emitted:]], dim=2)
-        nctx = 0 if tail is None else tail.shape[2]
-        wav = self.hift.decode(seg)[:, 0, nctx * self.hop:(nctx + hi - emitted) * self.hop]
-        end = nctx + hi - emitted
-        self.hift_cache_dict[uuid] = {"emitted": hi, "tail": seg[:, :, max(0, end - self.dac_ctx_left):end].clone()}
-        return wav
+        re = MC if (finalize and held is not None) else 0
+        first = emitted - re
+        ctx = None if tail is None else tail[:, :, :tail.shape[2] - re][:, :, -CL:]
+        seg = lat[:, :, first:] if ctx is None or ctx.shape[2] == 0 else torch.cat([ctx, lat[:, :, first:]], dim=2)
+        nctx = 0 if ctx is None else ctx.shape[2]
+        wav = self.hift.decode(seg)[:, 0, nctx * self.hop:(nctx + hi - first) * self.hop]
+        if finalize:
+            if re:
+                wav = fade_in_out(wav, held, self.speech_window)
+            return wav
+        keep = min(MC, hi - emitted)
+        out = wav[:, :wav.shape[1] - keep * self.hop]
+        if held is not None:
+            out = torch.cat([held, out], dim=1)
+        new = lat[:, :, emitted:hi]
+        tail = (new if tail is None else torch.cat([tail, new], dim=2))[:, :, -(CL + MC):].clone()
+        self.hift_cache_dict[uuid] = {"emitted": hi, "tail": tail, "held": wav[:, wav.shape[1] - keep * self.hop:].clone()}
+        return out
 
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192),
             llm_embedding=torch.zeros(0, 192), prompt_text=torch.zeros(1, 0, dtype=torch.int32),

@@ -161,22 +161,37 @@ def test_composed_pipeline_split_ids_identical_waveform_1e3(case):
         assert wav.shape == case["wav"].shape and err <= TP.WAV_TOL_F32, err
 
 
+def _ssq_table(x):
+    """[32][64] per-16-column-tile sums of squares of the rows of x (the producer side of the RMSNorm statistic)."""
+    B, K = x.shape
+    t = torch.zeros(32, 64, device=x.device)
+    t[:B, :K // 16] = x.double().pow(2).reshape(B, K // 16, 16).sum(-1).float()
+    return t
+
+
 @pytest.mark.parametrize("B,K,N,epi,rs,tw,J", [(1, 896, 1152, 0, True, 1, 1), (32, 896, 1152, 0, True, 1, 1), (17, 896, 896, 2, False, 1, 1),
                                                (32, 896, 4864, 1, True, 2, 1), (9, 896, 4864, 1, True, 1, 1), (32, 4864, 896, 2, False, 2, 8),
                                                (3, 4864, 896, 2, False, 1, 8), (32, 896, 6564, 0, True, 2, 1), (16, 896, 6564, 0, True, 1, 1)])
 def test_skinny2_vs_float64(B, K, N, epi, rs, tw, J):
-    """The decode-step projection kernel (csrc/decode.hip) against float64 on the same values, fp32 level (X3); with the
-    k split across workgroups (J = 8) it is launched 20 times back to back on the same tickets / partial buffers: every
-    launch must return the same bits (slice-order summation, tickets left at zero)."""
+    """The decode-step projection kernel (csrc/decode.hip) on split-plane activations against float64 on the same values,
+    fp32 level; with the k split across workgroups (J = 8) it is launched 20 times back to back on the same tickets /
+    partial buffers: every launch must return the same bits (slice-order summation, tickets left at zero).  The epilogue
+    outputs of the residual projections (planes of out * gamma_next, per-tile sums of squares) and of the SwiGLU (planes)
+    are checked too."""
     from mmx import ops
     g = torch.Generator().manual_seed(B * 31 + N + J)
     x = (torch.randn(B, K, generator=g) * 3).cuda()
     w = (torch.randn((2 * N if epi == 1 else N), K, generator=g) / math.sqrt(K)).to(torch.bfloat16).cuda()
     gam = (1 + 0.1 * torch.randn(K, generator=g)).cuda() if rs else None
+    gnext = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
     bias = torch.randn(N, generator=g).cuda() if epi == 0 else None
     wp = ops.pack_skinny(w.contiguous(), dtype=X3, interleave_half=(N if epi == 1 else 0))
+    xg = x * gam if rs else x
+    xs = ops.split_planes(xg)
+    assert (ops.merge_planes(xs, B, K) - xg).abs().max().item() == 0.0        # 3 bf16 terms hold an fp32 value exactly
+    ssq = _ssq_table(x) if rs else None
     xd = x.double()
-    acc = (xd * (gam.double() if rs else 1.0)) @ w.double().t()
+    acc = xg.double() @ w.double().t()
     if rs:
         acc = acc * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6)
     res = torch.randn(B, N, generator=g).cuda()
@@ -186,16 +201,51 @@ def test_skinny2_vs_float64(B, K, N, epi, rs, tw, J):
     tickets = torch.zeros(nt, dtype=torch.int32, device="cuda") if J > 1 else None
     outs = []
     for rep in range(20 if J > 1 else 2):
-        out = res.clone() if epi == 2 else torch.full((B, N), float("nan"), device="cuda")
-        ops.skinny2(x, wp, out, B=B, K=K, N=N, dtype=X3, bias=bias, kgamma=gam, rs=rs, eps=1e-6, epi=epi, tiles_per_wg=tw, ksplit=J,
-                    part=part, tickets=tickets)
-        outs.append(out)
+        out = res.clone() if epi == 2 else (torch.full((B, N), float("nan"), device="cuda") if epi == 0 else None)
+        xs_out = torch.zeros(3, ops.plane_elems(B, N), dtype=torch.bfloat16, device="cuda") if epi != 0 and N % 32 == 0 else None
+        ssq_out = torch.zeros(32, 64, device="cuda") if epi == 2 else None
+        ops.skinny2(xs, wp, B=B, K=K, N=N, dtype=X3, bias=bias, ssq_in=ssq, eps=1e-6, epi=epi, out=out, xs_out=xs_out,
+                    gamma_next=(gnext if epi == 2 else None), ssq_out=ssq_out, tiles_per_wg=tw, ksplit=J, part=part, tickets=tickets)
+        got = ops.merge_planes(xs_out, B, N) if epi == 1 else out
+        outs.append((got, xs_out, ssq_out))
     torch.cuda.synchronize()
-    assert rel_err(outs[0], ref) < 3e-6, rel_err(outs[0], ref)
+    assert rel_err(outs[0][0], ref) < 3e-6, rel_err(outs[0][0], ref)
     for o in outs[1:]:
-        assert torch.equal(o, outs[0])
+        assert torch.equal(o[0], outs[0][0])
+    if epi == 2:
+        got, xs_out, ssq_out = outs[0]
+        assert torch.equal(ops.merge_planes(xs_out, B, N), got * gnext)       # planes hold out * gamma_next exactly
+        assert rel_err(ssq_out[:B, :nt], _ssq_table(got)[:B, :nt]) < 1e-6 and float(ssq_out[B:].abs().sum()) == 0.0
     if J > 1:
         assert int(tickets.abs().sum()) == 0
+
+
+def test_decode_prep_and_attention_split_planes():
+    """mmx_decode_prep (x -> h copy, planes of x * gamma, per-tile sums of squares) and the decode attention's split-plane
+    output against the same kernels' fp32 outputs."""
+    from mmx import ops
+    g = torch.Generator().manual_seed(9)
+    B, K = 19, 896
+    x = torch.randn(B, K, generator=g).cuda()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).cuda()
+    xs = torch.zeros(3, ops.plane_elems(B, K), dtype=torch.bfloat16, device="cuda")
+    ssq, h = torch.zeros(32, 64, device="cuda"), torch.zeros(B, K, device="cuda")
+    ops.decode_prep(x, xs, ssq, B=B, K=K, gamma=gam, h=h)
+    assert torch.equal(h, x) and torch.equal(ops.merge_planes(xs, B, K), x * gam)
+    assert rel_err(ssq[:B, :56], _ssq_table(x)[:B, :56]) < 1e-6 and float(ssq[:, 56:].abs().sum()) == 0.0
+    # decode attention: row-major fp32 output vs split-plane output of the same launch arguments
+    Hq, Hkv, D, page, P = 14, 2, 64, 16, 8
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, generator=g).cuda()
+    pos = torch.randint(1, page * P - 1, (B,), generator=g).to(torch.int32).cuda()
+    kc = torch.randn(B * P + 1, Hkv, page, D, generator=g).cuda()
+    vc = torch.randn(B * P + 1, Hkv, page, D, generator=g).cuda()
+    bt = torch.arange(B * P, dtype=torch.int32).reshape(B, P).cuda()
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2).float() / D))).cuda()
+    o1 = torch.zeros(B, Hq * D, device="cuda")
+    o2 = torch.zeros(3, ops.plane_elems(B, Hq * D), dtype=torch.bfloat16, device="cuda")
+    ops.decode_attn(qkv, inv, pos, kc.clone(), vc.clone(), bt, o1, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=0, per_head=True)
+    ops.decode_attn(qkv, inv, pos, kc.clone(), vc.clone(), bt, o2, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=0, per_head=True, out_split=True)
+    assert torch.equal(ops.merge_planes(o2, B, Hq * D), o1)
 
 
 def test_lm_split_decode_v2_equals_round2_kernel(golden_dir):
