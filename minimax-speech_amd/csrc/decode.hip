@@ -59,8 +59,8 @@ struct Skinny3Args {
     bf16_t* xs_out;          // EPI 1: planes of silu(g)*u [3][MT][N/32][64][8]; EPI 2: planes of (out * gamma_next), or NULL
     const float* gamma_next; // EPI 2: [N] gain of the consumer of xs_out
     float* ssq_out;          // EPI 2: [32][SSQ_SLOTS] partial sums of squares of `out` rows per output tile, or NULL
-    float* part;             // J > 1: partial tiles [J][ntiles][MT*4][64]
-    int* tickets;            // J > 1: [ntiles], zero between launches
+    float* part;             // J > 1: partial tiles [J][tile groups][TW*MT*4][64]
+    int* tickets;            // J > 1: one per tile group (workgroup column), zero between launches
     long ldo;
     int B, K, N, ntiles, kb_per_wg;
     float eps;
@@ -124,22 +124,20 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
         sq += __shfl_xor(sq, 8, 64);
         if (part == 0) rstd[row] = rsqrtf(sq / (float)a.K + a.eps);
     }
-    // epilogue operands, fetched up front by the wave that will need them
-    const bool epi_wave = wave < TW && tile0 + wave < ntiles;
-    const int ncol = (tile0 + wave) * 16 + l16;
-    float pre_bias = 0.f, pre_gn = 1.f, pre_res[MT][4];
-    if (epi_wave) {
-        if (EPI != 1 && a.bias && ncol < a.N) pre_bias = a.bias[ncol];
-        if constexpr (EPI == 2) {
-            if (a.gamma_next && ncol < a.N) pre_gn = a.gamma_next[ncol];
+    // Epilogue work is spread over all 8 waves: unit u = (tile t, row tile m, register r) covers, per lane (g, l16), the
+    // element (row m*16 + 4g + r, column l16) of tile t; wave w takes units w, w + 8, ...  (One wave finishing a whole tile
+    // alone - 8 values per lane through the reduction, the split into planes, the row-statistic shuffles - was the longest
+    // serial stretch of the kernel.)  Operands of the epilogue are fetched up front, before the MFMA phase.
+    constexpr int UNITS = TW * MT * 4, UPW = (UNITS + 7) / 8;
+    float pre_bias[UPW], pre_gn[UPW], pre_res[UPW];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m * 16 + 4 * g + r;
-                    pre_res[m][r] = (row < a.B && ncol < a.N) ? a.out[(long)row * a.ldo + ncol] : 0.f;
-                }
-        }
+    for (int k = 0; k < UPW; ++k) {
+        const int u = wave + 8 * k, t = u / (MT * 4), m = (u / 4) % MT, r = u & 3;
+        const int row = m * 16 + 4 * g + r, ncol = (tile0 + t) * 16 + l16;
+        const bool ok = u < UNITS && tile0 + t < ntiles && row < a.B && ncol < a.N;
+        pre_bias[k] = (EPI != 1 && a.bias && ok) ? a.bias[ncol] : 0.f;
+        pre_gn[k] = (EPI == 2 && a.gamma_next && ok) ? a.gamma_next[ncol] : 1.f;
+        pre_res[k] = (EPI == 2 && ok) ? a.out[(long)row * a.ldo + ncol] : 0.f;
     }
     float4_t acc[TW][NB][MT];
 #pragma unroll
@@ -174,86 +172,76 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
                     for (int r = 0; r < 4; ++r) mine[(((t * NB + n) * MT + m) * 4 + r) * 64] = acc[t][n][m][r];
     }
     __syncthreads();
-    if (!epi_wave) return;
-    const int t = wave;                                // wave e finishes tile e of the workgroup
-    float sum[NB][MT][4];
+    float sum[UPW][NB];
 #pragma unroll
-    for (int n = 0; n < NB; ++n)
+    for (int k = 0; k < UPW; ++k) {
+        const int u = wave + 8 * k, t = u / (MT * 4), m = (u / 4) % MT, r = u & 3;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int n = 0; n < NB; ++n) {
+            float v = 0.f;
+            if (u < UNITS) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum[n][m][r] = 0.f;
-#pragma unroll
-    for (int w2 = 0; w2 < 8; ++w2) {
-        const float* o = red + w2 * PER * 64 + lane;
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sum[n][m][r] += o[(((t * NB + n) * MT + m) * 4 + r) * 64];
+                for (int w2 = 0; w2 < 8; ++w2) v += red[w2 * PER * 64 + (((t * NB + n) * MT + m) * 4 + r) * 64 + lane];
+            }
+            sum[k][n] = v;
+        }
     }
-    const int tile = tile0 + t;
     if constexpr (EPI == 2) {
         if (J > 1) {
-            float* mine = a.part + ((j * ntiles + tile) * (MT * 4)) * 64 + lane;
+            // cross-workgroup k split: every wave publishes its units of this slice's partial tiles (write-through), the
+            // workgroup takes ONE ticket for its tile group behind a barrier (MI355X_MICROARCH.md, Guideline 16 R1: the lane that
+            // signals for other waves does so behind a workgroup barrier that follows every wave's vmcnt(0)), and the
+            // workgroup holding the last ticket sums the J partials in slice order
+            int* flag = reinterpret_cast<int*>(rstd + 32);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st_sc1(mine + (m * 4 + r) * 64, sum[0][m][r]);
+            for (int k = 0; k < UPW; ++k) {
+                const int u = wave + 8 * k;
+                if (u < UNITS) st_sc1(a.part + ((j * gridDim.x + blockIdx.x) * UNITS + u) * 64 + lane, sum[k][0]);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if (old != J - 1) return;
-            if (lane == 0) __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int old = __hip_atomic_fetch_add(a.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == J - 1) __hip_atomic_store(a.tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+                *flag = old == J - 1;
+            }
+            __syncthreads();
+            if (!*flag) return;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sum[0][m][r] = 0.f;
-            for (int j2 = 0; j2 < J; ++j2) {
-                const float* o = a.part + ((j2 * ntiles + tile) * (MT * 4)) * 64 + lane;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sum[0][m][r] += ld_sc1(o + (m * 4 + r) * 64);
+            for (int k = 0; k < UPW; ++k) {
+                const int u = wave + 8 * k;
+                float v = 0.f;
+                if (u < UNITS)
+                    for (int j2 = 0; j2 < J; ++j2) v += ld_sc1(a.part + ((j2 * gridDim.x + blockIdx.x) * UNITS + u) * 64 + lane);
+                sum[k][0] = v;
             }
         }
     }
-    // epilogue: acc rows are 4g + r, column l16
     const int nkb_out = a.N >> 5;
     const int ps_out = MT * nkb_out * 512;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        float q2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m * 16 + 4 * g + r;
-            const float sc = a.ssq_in ? rstd[row] : 1.f;
-            const bool ok = row < a.B && ncol < a.N;
-            if constexpr (EPI == 1) {
-                const float gte = sum[0][m][r] * sc, up = sum[1][m][r] * sc;
-                if (ok) store_split3(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), gte / (1.f + expf(-gte)) * up);
-            } else {
-                float vv = sum[0][m][r] * sc + pre_bias;
-                if constexpr (EPI == 2) vv += pre_res[m][r];
-                if (ok) a.out[(long)row * a.ldo + ncol] = vv;
-                if constexpr (EPI == 2) {
-                    if (ok && a.xs_out) store_split3(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), vv * pre_gn);
-                    q2[r] = ok ? vv * vv : 0.f;
-                }
-            }
-        }
-        if constexpr (EPI == 2) {
-            if (a.ssq_out) {                           // this tile's share of each row's sum of squares: over the 16 columns
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float q = q2[r];
+    for (int k = 0; k < UPW; ++k) {
+        const int u = wave + 8 * k, t = u / (MT * 4), m = (u / 4) % MT, r = u & 3;
+        if (u >= UNITS) break;                         // wave-uniform
+        const int row = m * 16 + 4 * g + r, tile = tile0 + t, ncol = tile * 16 + l16;
+        const float sc = a.ssq_in ? rstd[row] : 1.f;
+        const bool ok = tile < ntiles && row < a.B && ncol < a.N;
+        if constexpr (EPI == 1) {
+            const float gte = sum[k][0] * sc, up = sum[k][1] * sc;
+            if (ok) store_split3(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), gte / (1.f + expf(-gte)) * up);
+        } else {
+            float vv = sum[k][0] * sc + pre_bias[k];
+            if constexpr (EPI == 2) vv += pre_res[k];
+            if (ok) a.out[(long)row * a.ldo + ncol] = vv;
+            if constexpr (EPI == 2) {
+                if (ok && a.xs_out) store_split3(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), vv * pre_gn[k]);
+                if (a.ssq_out) {                       // this tile's share of the row's sum of squares: over its 16 columns
+                    float q = ok ? vv * vv : 0.f;
                     q += __shfl_xor(q, 1, 64);
                     q += __shfl_xor(q, 2, 64);
                     q += __shfl_xor(q, 4, 64);
                     q += __shfl_xor(q, 8, 64);
-                    if (l16 == 0) a.ssq_out[(m * 16 + 4 * g + r) * SSQ_SLOTS + tile] = q;
+                    if (l16 == 0 && tile < ntiles) a.ssq_out[row * SSQ_SLOTS + tile] = q;
                 }
             }
         }
@@ -263,7 +251,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
 template <int MT, int TW, int KPW, int EPI>
 int launch(const Skinny3Args& a, int J, hipStream_t s) {
     constexpr int NB = EPI == 1 ? 2 : 1;
-    const size_t lds = (size_t)8 * (TW * NB * MT * 4) * 64 * sizeof(float) + 32 * sizeof(float);
+    const size_t lds = (size_t)8 * (TW * NB * MT * 4) * 64 * sizeof(float) + 32 * sizeof(float) + 16;
     MMX_LDS_OPT_IN((skinny3_kernel<MT, TW, KPW, EPI>), lds);
     dim3 grid((a.ntiles + TW - 1) / TW, J);
     hipLaunchKernelGGL((skinny3_kernel<MT, TW, KPW, EPI>), grid, dim3(512), lds, s, a);
@@ -319,7 +307,7 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
     MMX_CHECK_ARG(epi != 2 || !ssq_out || (N + 15) / 16 <= SSQ_SLOTS);
     const int nkb = K / 32, ntiles = (N + 15) / 16, mt = (B + 15) / 16;
     const int per_wave = ((nkb + ksplit - 1) / ksplit + 7) / 8;
-    MMX_CHECK_ARG(ksplit == 1 || part_floats >= (int64_t)ksplit * ntiles * mt * 4 * 64);
+    MMX_CHECK_ARG(ksplit == 1 || part_floats >= (int64_t)ksplit * ((ntiles + tiles_per_wg - 1) / tiles_per_wg) * tiles_per_wg * mt * 4 * 64);
     // 32-bit buffer offsets: the packed weights and the planes must stay below 2 GiB
     MMX_CHECK_ARG((double)ntiles * (epi == 1 ? 2 : 1) * nkb * 1024.0 < 2147483000.0);
     Skinny3Args a{(const bf16_t*)xs, (const bf16_t*)wp, bias, ssq_in, out, (bf16_t*)xs_out, gamma_next, ssq_out, part, tickets,

@@ -29,6 +29,9 @@
 //     intermediate lives in the LDS buffer the attention output occupied.
 //
 // bf16 build: v_mfma_f32_16x16x32_bf16; fp32 parity build: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), fp32 tiles.
+// Split build (NS = 2, MMX_X2): bf16 weights as in the bf16 build; every activation that is a GEMM operand lives in LDS as
+// TWO bf16 planes (hi = bf16(x), lo = bf16(x - hi)) and costs two MFMAs per weight fragment; activations in HBM (attention
+// output in, Q | K | V out, the masked copy) are fp32.  The weight stream from L2 - what bounds these kernels - is unchanged.
 #include "common.h"
 #include "../../include/mmx_hip.h"
 #include <type_traits>
@@ -81,22 +84,25 @@ struct WRing {
 // K is walked as `taps` groups of `cin_steps` k-steps; tap t reads the tile `t` rows further down (causal conv k3:
 // taps = 3; Linear: taps = 1).  wb / ns / nk: packed weights of this stage for this wave (lane offset included),
 // elements between n-fragments, k-steps (even).  wbn / nsn: the next stage's (NULL: none).
-template <typename T, int MF, int NF, int PF>
+// NS / plane: the A tile is NS planes, `plane` bytes apart (split build); every plane is multiplied with the same B fragment.
+template <typename T, int MF, int NF, int PF, int NS = 1>
 __device__ __forceinline__ void stage_run(WRing<T, 4, PF>& ring, const char* a_lane, int pitch, int cin_steps,
                                           const T* wb, long ns, int nk, const T* wbn, long nsn, int nkn, int nfn,
-                                          float4_t (&acc)[MF][NF]) {
+                                          float4_t (&acc)[MF][NF], int plane = 0) {
     constexpr int E = FT<T>::E, KB = FT<T>::KB;
     typedef typename FT<T>::frag_t frag_t;
     // A fragments come from LDS AD - 1 k-steps ahead of their use (a k-step is MF*NF MFMAs = 64 cycles at MF = 1,
     // 256 at MF = 4; the LDS latency is ~130 cycles)
     constexpr int AD = (MF == 1 && PF >= 4) ? 4 : 2;
     static_assert(PF % AD == 0, "ring depths");
-    frag_t a[AD][MF];
+    frag_t a[AD][NS][MF];
     int rt = 0, rc = 0, rs = 0;                        // tap / k-step inside the tap / k-step of the next A read
-    auto read_a = [&](frag_t (&dst)[MF]) {
+    auto read_a = [&](frag_t (&dst)[NS][MF]) {
         const char* ap = a_lane + rt * pitch + rc * (KB * (int)sizeof(T));
 #pragma unroll
-        for (int i = 0; i < MF; ++i) dst[i] = *reinterpret_cast<const frag_t*>(ap + i * 16 * pitch);
+        for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+            for (int i = 0; i < MF; ++i) dst[s2][i] = *reinterpret_cast<const frag_t*>(ap + s2 * plane + i * 16 * pitch);
         if (rs + 1 < nk) {                             // past the end: re-read the last k-step (never used)
             ++rs;
             if (++rc == cin_steps) { rc = 0; ++rt; }
@@ -129,9 +135,11 @@ __device__ __forceinline__ void stage_run(WRing<T, 4, PF>& ring, const char* a_l
             // (measured: the same kernel time at ring depth 2, 4 and 8)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
+            for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-                for (int jj = 0; jj < NF; ++jj) acc[i][jj] = mma<T>(a[p % AD][i], b[jj], acc[i][jj]);
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NF; ++jj) acc[i][jj] = mma<T>(a[p % AD][s2][i], b[jj], acc[i][jj]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -203,6 +211,32 @@ __device__ __forceinline__ void storen_T(T* p, const float (&v)[N]) {
     }
 }
 
+// N consecutive values into an A tile in LDS at byte address `p`: as T (one plane) or as bf16 hi + lo planes `plane` bytes apart
+template <typename T, int NS, int N>
+__device__ __forceinline__ void store_tile(char* p, int plane, const float (&v)[N]) {
+    if constexpr (NS == 1) {
+        storen_T<T, N>(reinterpret_cast<T*>(p), v);
+    } else {
+        float lo[N];
+#pragma unroll
+        for (int c = 0; c < N; c += 8) {
+            uint4 pk;
+            pk.x = pack_bf16x2(v[c], v[c + 1]);
+            pk.y = pack_bf16x2(v[c + 2], v[c + 3]);
+            pk.z = pack_bf16x2(v[c + 4], v[c + 5]);
+            pk.w = pack_bf16x2(v[c + 6], v[c + 7]);
+            *reinterpret_cast<uint4*>(p + c * 2) = pk;
+            const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[c + 2 * e] = v[c + 2 * e] - __uint_as_float(w[e] << 16);
+                lo[c + 2 * e + 1] = v[c + 2 * e + 1] - __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
+        storen_T<bf16_t, N>(reinterpret_cast<bf16_t*>(p + plane), lo);
+    }
+}
+
 // LayerNorm of the rows of a [rows x 256] tile held in the row layout (v[i][CW] per wave, NW waves x 256/NW columns).
 // Two-pass statistics like torch (mean, then the mean of squared deviations), partial sums exchanged through
 // stats[rows][NW].  Contains 4 workgroup barriers; all waves must call it.  Leaves normalised*gamma+beta in v.
@@ -269,6 +303,25 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ src, long ld, in
         *reinterpret_cast<uint4*>(tile + r * pitch + ch * 16) = v;
     }
 }
+// split build: fp32 rows -> bf16 hi + lo planes (`plane` bytes apart), 4 values per 16-byte global chunk
+__device__ __forceinline__ void load_tile_split(const float* __restrict__ src, long ld, int r0, int nvalid, int rows, int K,
+                                                char* tile, int pitch, int plane, int tid, int nthreads) {
+    const int cpr = K / 4;
+    const int total = rows * cpr;
+    for (int id = tid; id < total; id += nthreads) {
+        const int r = id / cpr, ch = id - r * cpr;
+        const int gr = r0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr >= 0 && gr < nvalid) v = *reinterpret_cast<const float4*>(src + (long)gr * ld + ch * 4);
+        uint2 hi, lo;
+        hi.x = pack_bf16x2(v.x, v.y);
+        hi.y = pack_bf16x2(v.z, v.w);
+        lo.x = pack_bf16x2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack_bf16x2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+        *reinterpret_cast<uint2*>(tile + r * pitch + ch * 8) = hi;
+        *reinterpret_cast<uint2*>(tile + plane + r * pitch + ch * 8) = lo;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Shared tail of both kernels: x (row layout) -> LayerNorm(n1) -> A1 tile -> Q/K/V projection.
@@ -284,10 +337,11 @@ __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lan
 }
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
-template <typename T, int MF, int PF, int NW>
+template <typename T, int MF, int PF, int NW, int NS = 1>
 __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n1g)[64 / NW], const float (&n1b)[64 / NW],
                                        const MmxEstNext& nx, float eps, char* a1, float* patch, float* stats,
-                                       WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane) {
+                                       WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0) {
+    typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
     constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256, CW = 64 / NW, PPK = 512 / (64 * NW), NP = 3 * PPK;
     constexpr int P1 = tile_pitch(C, sizeof(T));
     constexpr int NK = C / KB;
@@ -296,16 +350,16 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
     const long ns = (long)NK * 64 * E;
     layernorm_rows<MF, CW, NW>(xv, stats, n1g, n1b, eps, wave, lane);
 #pragma unroll
-    for (int i = 0; i < MF; ++i) storen_T<T, CW>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + col0, xv[i]);
+    for (int i = 0; i < MF; ++i) store_tile<T, NS, CW>(a1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), plane, xv[i]);
     __syncthreads();
     const char* a_lane = a1 + l16 * P1 + g * 16;
-    constexpr bool VT = sizeof(T) == 2;
+    constexpr bool VT = sizeof(T) == 2 && NS == 1;
     constexpr int PV = 16 * (int)sizeof(T) + 16;       // V^T patch pitch: [64 columns][16 frames] inside the wave's patch
     for (int p = 0; p < NP; ++p) {
         float4_t acc[MF][4];
         zero_acc(acc);
         const T* wn = p + 1 < NP ? qkv_pass<T, NW>(nx.wqkv, wave, lane, p + 1) : nullptr;
-        stage_run<T, MF, 4, PF>(ring, a_lane, P1, NK, qkv_pass<T, NW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, 4, acc);
+        stage_run<T, MF, 4, PF, NS>(ring, a_lane, P1, NK, qkv_pass<T, NW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, 4, acc, plane);
         const int kind = p / PPK, cw = (wave * PPK + p % PPK) * 64;     // 64 columns at cw inside the 512-wide Q / K / V
         if (VT && kind == 2) {
             // C layout -> [column][frame] patch, one 16-frame fragment at a time: a lane holds 4 consecutive frames of
@@ -340,14 +394,14 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
                 __builtin_amdgcn_wave_barrier();
             }
         } else {
-            T* out = reinterpret_cast<T*>(nx.q_out) + (long)b * nx.q_bs;
+            TI* out = reinterpret_cast<TI*>(nx.q_out) + (long)b * nx.q_bs;
             const int col = kind * 512 + cw + (lane & 3) * 16;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[16];
                 to_rows<4>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
-                if (t < Tn) storen_T<T, 16>(out + (long)t * nx.ldq + col, v);
+                if (t < Tn) storen_T<TI, 16>(out + (long)t * nx.ldq + col, v);
             }
         }
     }
@@ -358,16 +412,18 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 // slices: the VALU-heavy epilogues (GELU, layout changes, LayerNorm) of one wave run under the MFMA stage of the other,
 // which a single wave per SIMD cannot do for itself (measured at 64 rows: 60 us = weight stream 23 + MFMA 17 + VALU ~20,
 // one after the other).
-template <typename T, int BM, int PF, int NW>
+template <typename T, int BM, int PF, int NW, int NS = 1>
 __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PPC = CH / (64 * NW);
     constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
-    constexpr bool PRECISE = sizeof(T) == 4;
+    constexpr int PL0 = BM * P0, PL1 = BM * P1;        // bytes between the planes of a tile (split build)
+    constexpr bool PRECISE = sizeof(T) == 4 || NS > 1;
+    typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* buf0 = smem;                                 // [BM][512] attention output, then the FF intermediate chunk
-    char* a1 = buf0 + BM * P0;                         // [BM][256] LayerNorm output (A operand of FF1 / QKV)
-    float* patch_all = reinterpret_cast<float*>(a1 + BM * P1);
+    char* buf0 = smem;                                 // [NS][BM][512] attention output, then the FF intermediate chunk
+    char* a1 = buf0 + NS * PL0;                        // [NS][BM][256] LayerNorm output (A operand of FF1 / QKV)
+    float* patch_all = reinterpret_cast<float*>(a1 + NS * PL1);
     float* stats = patch_all + NW * PATCH_FLOATS;      // [BM][NW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
@@ -405,11 +461,12 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
         loadn<CW>(p.bo + col0, bo);
         loadn<CW>(p.n3g + col0, n3g);
         loadn<CW>(p.n3b + col0, n3b);
-        load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
+        if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
+        else load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, PL0, tid, 64 * NW);
         __syncthreads();
         float4_t acc[MF][NFN];
         zero_acc(acc);
-        stage_run<T, MF, NFN, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, 4, acc);
+        stage_run<T, MF, NFN, PF, NS>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, 4, acc, PL0);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[CW];
@@ -427,7 +484,7 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
             for (int c = 0; c < CW; ++c) hn[i][c] = x1[i][c];
         layernorm_rows<MF, CW, NW>(hn, stats, n3g, n3b, p.eps, wave, lane);
 #pragma unroll
-        for (int i = 0; i < MF; ++i) storen_T<T, CW>(reinterpret_cast<T*>(a1 + (i * 16 + rl) * P1) + col0, hn[i]);
+        for (int i = 0; i < MF; ++i) store_tile<T, NS, CW>(a1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), PL1, hn[i]);
     }
     __syncthreads();                                   // A1 complete; every wave is done with the attention tile
     // ---- FF1 + GELU -> LDS chunk -> FF2 accumulate  (transformer.py:306-313, diffusers GELU = Linear + exact gelu)
@@ -445,15 +502,15 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
             zero_acc(acc);
             const bool more = h + 1 < PPC;
             const T* wn = more ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
-            stage_run<T, MF, 4, PF>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
-                                    more ? NK1 : NK2, more ? 4 : NFN, acc);
+            stage_run<T, MF, 4, PF, NS>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
+                                        more ? NK1 : NK2, more ? 4 : NFN, acc, PL1);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[16];
                 to_rows<4>(acc[i], patch, lane, v);
 #pragma unroll
                 for (int c = 0; c < 16; ++c) v[c] = act_c<ACT_GELU, PRECISE>(v[c] + b1[c], 0.f);
-                storen_T<T, 16>(reinterpret_cast<T*>(buf0 + (i * 16 + rl) * P0) + hc, v);
+                store_tile<T, NS, 16>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
             }
         }
         __syncthreads();                               // the chunk is complete
@@ -468,7 +525,7 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
             }
         }
         const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW>(p.next.wqkv, wave, lane, 0) : nullptr);
-        stage_run<T, MF, NFN, PF>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, 4, acc2);
+        stage_run<T, MF, NFN, PF, NS>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, 4, acc2, PL0);
         __syncthreads();                               // every wave is done reading the chunk
     }
     // ---- + bias + residual -> x (fp32 residual stream, in place)
@@ -484,26 +541,28 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
             if (t < Tn) {
                 storen<CW>(xw + (long)t * C + col0, x1[i]);
                 if (p.act_out)
-                    storen_T<T, CW>(reinterpret_cast<T*>(p.act_out) + (long)b * p.act_bs + (long)t * p.act_ld + col0, x1[i]);
+                    storen_T<TI, CW>(reinterpret_cast<TI*>(p.act_out) + (long)b * p.act_bs + (long)t * p.act_ld + col0, x1[i]);
             }
         }
     }
-    if (p.next.wqkv) ln_qkv<T, MF, PF, NW>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane);
+    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int PF, int NW>
+template <typename T, int BM, int PF, int NW, int NS = 1>
 __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams p) {
     constexpr int MF = BM / 16, MH = MF + 1, E = FT<T>::E, KB = FT<T>::KB, C = 256;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16;
     constexpr int P1 = tile_pitch(C, sizeof(T));
-    constexpr bool PRECISE = sizeof(T) == 4;
+    constexpr int PLH = (BM + 16) * P1;                // bytes between the planes of h1 (split build)
+    constexpr bool PRECISE = sizeof(T) == 4 || NS > 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cin = p.cin;
     const int PA = tile_pitch(cin, sizeof(T));
-    char* ain = smem;                                  // [BM + 18][cin]: input rows t0-18 .. t0+BM-1
-    char* h1 = ain + (BM + 18) * PA;                   // [BM + 16][256]: block1 output rows t0-16 ..; later the A1 tile
-    float* patch_all = reinterpret_cast<float*>(h1 + (BM + 16) * P1);
+    const int PLA = (BM + 18) * PA;                    // bytes between the planes of ain
+    char* ain = smem;                                  // [NS][BM + 18][cin]: input rows t0-18 .. t0+BM-1
+    char* h1 = ain + NS * PLA;                         // [NS][BM + 16][256]: block1 output rows t0-16 ..; later the A1 tile
+    float* patch_all = reinterpret_cast<float*>(h1 + NS * PLH);
     float* stats = patch_all + NW * PATCH_FLOATS;      // [BM + 16][NW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
@@ -533,7 +592,8 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
         const int t = t0 - 16 + i * 16 + rl;
         rm1[i] = (t >= 0 && t < Tn) ? (rmk ? rmk[t] : 1.f) : 0.f;
     }
-    load_tile<T>(reinterpret_cast<const T*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, tid, 64 * NW);
+    if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, tid, 64 * NW);
+    else load_tile_split(reinterpret_cast<const float*>(p.a_in) + (long)b * p.a_bs, p.lda, t0 - 18, Tn, BM + 18, cin, ain, PA, PLA, tid, 64 * NW);
     __syncthreads();
 
     // ---- block1: causal conv k3 (cin -> 256) + bias -> LayerNorm -> Mish -> * mask, + time embedding, * mask
@@ -541,7 +601,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
     {
         float4_t acc[MH][NFN];
         zero_acc(acc);
-        stage_run<T, MH, NFN, PF>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, NFN, acc);
+        stage_run<T, MH, NFN, PF, NS>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, NFN, acc, PLA);
         float hv[MH][CW];
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
@@ -559,7 +619,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
                 const float y = act_c<ACT_MISH, PRECISE>(hv[i][c], 0.f) * rm1[i];
                 o[c] = t >= 0 ? (y + tv[c]) * rm1[i] : 0.f;           // rows before the sequence start are conv padding
             }
-            storen_T<T, CW>(reinterpret_cast<T*>(h1 + (i * 16 + rl) * P1) + col0, o);
+            store_tile<T, NS, CW>(h1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), PLH, o);
         }
     }
     // operands of block2's epilogue and of the residual conv's
@@ -574,7 +634,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
     {
         float4_t acc[MF][NFN];
         zero_acc(acc);
-        stage_run<T, MF, NFN, PF>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, NFN, acc);
+        stage_run<T, MF, NFN, PF, NS>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, NFN, acc, PLH);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             to_rows<NFN>(acc[i], patch, lane, h2[i]);
@@ -593,7 +653,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
         float4_t acc[MF][NFN];
         zero_acc(acc);
         const T* wq0 = p.next.wqkv ? qkv_pass<T, NW>(p.next.wqkv, wave, lane, 0) : nullptr;
-        stage_run<T, MF, NFN, PF>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, 4, acc);
+        stage_run<T, MF, NFN, PF, NS>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, 4, acc, PLA);
         float* xw = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -606,16 +666,16 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
         }
     }
     __syncthreads();                                   // every wave is done with ain / h1 (h1 is reused by ln_qkv)
-    if (p.next.wqkv) ln_qkv<T, MF, PF, NW>(h2, gg, be, p.next, p.eps, h1, patch, stats, ring, b, t0, Tn, wave, lane);
+    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS>(h2, gg, be, p.next, p.eps, h1, patch, stats, ring, b, t0, Tn, wave, lane, PLH);
 }
 
-template <typename T, int BM, int NW>
+template <typename T, int BM, int NW, int NS = 1>
 size_t tail_lds() {
-    return (size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T)) + (size_t)NW * PATCH_FLOATS * 4 + (size_t)BM * NW * 4;
+    return NS * ((size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T))) + (size_t)NW * PATCH_FLOATS * 4 + (size_t)BM * NW * 4;
 }
-template <typename T, int BM, int NW>
+template <typename T, int BM, int NW, int NS = 1>
 size_t resnet_lds(int cin) {
-    return (size_t)(BM + 18) * tile_pitch(cin, sizeof(T)) + (size_t)(BM + 16) * tile_pitch(256, sizeof(T)) + (size_t)NW * PATCH_FLOATS * 4 +
+    return NS * ((size_t)(BM + 18) * tile_pitch(cin, sizeof(T)) + (size_t)(BM + 16) * tile_pitch(256, sizeof(T))) + (size_t)NW * PATCH_FLOATS * 4 +
            (size_t)(BM + 16) * NW * 4;
 }
 
@@ -623,7 +683,9 @@ int check_next(const MmxEstNext& nx, int dtype, int T_) {
     if (!nx.wqkv) return MMX_OK;
     MMX_CHECK_ARG(nx.n1g && nx.n1b && nx.q_out);
     MMX_CHECK_ARG(((uintptr_t)nx.q_out % 16) == 0 && nx.q_bs % 8 == 0);
-    if (dtype == MMX_BF16) {
+    if (dtype == MMX_X2) {
+        MMX_CHECK_ARG(nx.ldq % 4 == 0 && nx.ldq >= 1536 && nx.q_bs % 4 == 0);
+    } else if (dtype == MMX_BF16) {
         MMX_CHECK_ARG(nx.vt_out && nx.ldq % 8 == 0 && nx.ldq >= 1024 && nx.ldvt % 8 == 0 && nx.ldvt >= ((T_ + 7) / 8) * 8);
         MMX_CHECK_ARG(((uintptr_t)nx.vt_out % 16) == 0 && nx.vt_bs % 8 == 0);
     } else {
@@ -641,19 +703,25 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     const MmxEstTailParams& p = *pp;
     MMX_CHECK_ARG(p.ao && p.x && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.n3g && p.n3b && p.B > 0 && p.T > 0);
     MMX_CHECK_ARG(p.t_begin >= 0 && p.t_begin < p.T && p.t_begin % 16 == 0);
-    MMX_CHECK_ARG(p.ldao >= 512 && p.ldao % 8 == 0 && p.ao_bs % 8 == 0 && p.x_bs % 4 == 0);
+    MMX_CHECK_ARG(p.ldao >= 512 && p.ldao % (dtype == MMX_X2 ? 4 : 8) == 0 && p.ao_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && p.x_bs % 4 == 0);
     MMX_CHECK_ARG(((uintptr_t)p.ao % 16) == 0 && ((uintptr_t)p.x % 16) == 0);
-    MMX_CHECK_ARG(!p.act_out || (p.act_ld % 8 == 0 && p.act_bs % 8 == 0 && ((uintptr_t)p.act_out % 16) == 0));
+    MMX_CHECK_ARG(!p.act_out || (p.act_ld % (dtype == MMX_X2 ? 4 : 8) == 0 && p.act_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
     const int pf = cfg & 15, nw = cfg >> 4;
-#define TAIL(TT, BM, PF, NW)                                                                              \
+#define TAILN(TT, BM, PF, NW, NS)                                                                         \
     do {                                                                                                   \
-        const size_t lds = tail_lds<TT, BM, NW>();                                                         \
+        const size_t lds = tail_lds<TT, BM, NW, NS>();                                                     \
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW>), lds);                                            \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS>), lds);                                        \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
-    if (dtype == MMX_BF16) {
+#define TAIL(TT, BM, PF, NW) TAILN(TT, BM, PF, NW, 1)
+    if (dtype == MMX_X2) {
+        // split build: two bf16 planes per LDS tile, so the largest tile is 32 rows (137 KB with 8 waves)
+        if (bm == 32) { if (nw == 4) TAILN(bf16_t, 32, 4, 4, 2); else TAILN(bf16_t, 32, 2, 8, 2); }
+        else if (bm == 16) { if (nw == 8) TAILN(bf16_t, 16, 4, 8, 2); else TAILN(bf16_t, 16, 8, 4, 2); }
+        else return MMX_EARG;
+    } else if (dtype == MMX_BF16) {
         if (bm == 64) {
             if (nw == 0 || nw == 4) { if (pf == 4) TAIL(bf16_t, 64, 4, 4); else TAIL(bf16_t, 64, 2, 4); }
             else if (nw == 8) TAIL(bf16_t, 64, 2, 8);
@@ -674,6 +742,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
         else return MMX_EARG;
     } else return MMX_EARG;
 #undef TAIL
+#undef TAILN
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
@@ -683,20 +752,37 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     const MmxEstResnetParams& p = *pp;
     MMX_CHECK_ARG(p.a_in && p.x && p.w1 && p.w2 && p.wr && p.b1 && p.b2 && p.br && p.g1 && p.be1 && p.g2 && p.be2 && p.tv);
     MMX_CHECK_ARG(p.t_begin >= 0 && p.t_begin < p.T && p.t_begin % 16 == 0);
-    MMX_CHECK_ARG(p.B > 0 && p.T > 0 && p.cin >= 64 && p.cin % 32 == 0 && p.cin <= 512 && p.lda >= p.cin && p.lda % 8 == 0 && p.a_bs % 8 == 0);
+    MMX_CHECK_ARG(p.B > 0 && p.T > 0 && p.cin >= 64 && p.cin % 32 == 0 && p.cin <= 512 && p.lda >= p.cin);
+    MMX_CHECK_ARG(p.lda % (dtype == MMX_X2 ? 4 : 8) == 0 && p.a_bs % (dtype == MMX_X2 ? 4 : 8) == 0);
     MMX_CHECK_ARG(((uintptr_t)p.a_in % 16) == 0 && ((uintptr_t)p.x % 16) == 0 && p.x_bs % 4 == 0 && p.tv_bs % 4 == 0 && ((uintptr_t)p.tv % 16) == 0);
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
     const int pf_req = cfg & 15, nw = cfg >> 4;
-#define RESN(TT, BM, PF, NW)                                                                              \
+#define RESNN(TT, BM, PF, NW, NS)                                                                         \
     do {                                                                                                   \
-        const size_t lds = resnet_lds<TT, BM, NW>(p.cin);                                                  \
+        const size_t lds = resnet_lds<TT, BM, NW, NS>(p.cin);                                              \
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        MMX_LDS_OPT_IN((est_resnet_kernel<TT, BM, PF, NW>), lds);                                          \
-        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF, NW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_LDS_OPT_IN((est_resnet_kernel<TT, BM, PF, NW, NS>), lds);                                      \
+        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF, NW, NS>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
+#define RESN(TT, BM, PF, NW) RESNN(TT, BM, PF, NW, 1)
     // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count
     // (conv k3 over cin, conv k3 over 256, 1x1 over cin, Q/K/V over 256); cin = 320 allows 2 (bf16) / 4 (fp32) only
-    const int kb = dtype == MMX_BF16 ? 32 : 16;
+    const int kb = dtype == MMX_F32 ? 16 : 32;
+    if (dtype == MMX_X2) {
+        // split build (two bf16 planes per LDS tile): 32-row tiles while the input tile leaves room (cin <= 320: 150 KB with
+        // 4 waves), 16 rows for the 512-channel input of the up block; ring depth as the bf16 build's rule below
+        int pfx = pf_req > 0 ? pf_req : 4;
+        while (pfx > 2 && ((3 * p.cin / kb) % pfx || (p.cin / kb) % pfx || (256 / kb) % pfx)) pfx /= 2;
+        MMX_CHECK_ARG((p.cin / kb) % 2 == 0);
+        if (bm == 32) {
+            MMX_CHECK_ARG((resnet_lds<bf16_t, 32, 4, 2>(p.cin)) <= 160 * 1024);
+            if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2); else RESNN(bf16_t, 32, 2, 4, 2);
+        } else if (bm == 16) {
+            if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2); else RESNN(bf16_t, 16, 2, 4, 2);
+        } else return MMX_EARG;
+        MMX_LAUNCH_CHECK();
+        return MMX_OK;
+    }
     // 8 waves (two per SIMD) measured faster for the 64-row ResNet tile (50.6 vs 59.7 us at 14 336 rows); they need 17 KB
     // more LDS for the per-wave patches, which the 512-channel input tile (up block) does not leave
     // (and for the smaller tiles: 31.7 vs 36.2 us at 32 rows, 26.9 vs 29.0 us at 16 rows)
@@ -724,6 +810,7 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
         else return MMX_EARG;
     } else return MMX_EARG;
 #undef RESN
+#undef RESNN
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     };
     // cached keys: U keys per thread in flight at a time (the loop is a chain of memory round trips otherwise:
     // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys
-    constexpr int U = sizeof(T) == 2 ? 12 : 6;
+    constexpr int U = sizeof(T) == 2 ? 12 : 10;       // (fp32 cache: 10 x 64 B per thread in flight, 320 keys per pass)
     for (int j0 = kg; j0 < p; j0 += NG * U) {
         Raw8<T> rk[U], rv[U];
 #pragma unroll

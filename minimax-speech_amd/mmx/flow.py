@@ -134,8 +134,6 @@ class FlowEngine:
         # split N over all CUs (measured, one 10 s utterance, fp32: 175 ms fused, 104 ms per-op)
         self.fused = fused
         self.split = is_split(dtype)
-        if self.split and fused is None:
-            self.fused = False                      # the row-tile fused kernels have no split variant yet
         # attn="fp8": the estimator's full-length attention launches run the fp8 MFMA variant (bf16 build only; BASELINE
         # config 5).  The split-key launches of streaming hops stay bf16.
         assert attn in ("bf16", "fp8")
@@ -516,7 +514,7 @@ class FlowEngine:
     def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None, klen=None):
         """All inputs fp32 time-major device tensors: x [x_mod,T,80] (batch b reads x[b % x_mod]), mu/cond [B,T,80],
         spks [B,80], t [B]; mask fp32 [B,T] or None.  Returns fp32 [B,T,80]."""
-        if self.fused or (self.fused is None and (self.dtype == BF16 or B * ((T + 15) // 16) >= 256)):
+        if self.fused or (self.fused is None and (self.dtype == BF16 or self.split or B * ((T + 15) // 16) >= 256)):
             return self._estimator_fused(x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod, klen)
         dt, C = self.dtype, self.C
         chunk = self.est_chunk if streaming else 0
@@ -580,6 +578,11 @@ class FlowEngine:
             bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (cost(b), -b))
             bm = max(bm, getattr(self, "min_tile_rows", 16), 64 if self.polite else 16)
             return bm, bm
+        if self.split:
+            # two bf16 planes per LDS tile: 32 rows is the largest tile (the 512-channel ResNet of the up block: 16, see
+            # _estimator_fused); 16-row tiles only when 32-row ones would leave most of the chip idle
+            bm = 32 if (tiles(32) >= 128 or self.polite) else 16
+            return bm, bm
         return (32 if tiles(32) >= 128 else 16), 16            # fp32: tail, resnet (LDS: fp32 tiles are twice as large)
 
     def _estimator_fused(self, x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod, klen=None):
@@ -618,6 +621,10 @@ class FlowEngine:
                 ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
                                     k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125,
                                     keymask=(None if klen is not None else mask), chunk=chunk, fp8=self.attn_fp8, klen=klen)
+            elif self.split:
+                ops.attn_flash_x(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, T=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                                 q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125,
+                                 keymask=(None if klen is not None else mask), chunk=chunk, klen=klen)
             else:
                 ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
                                q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, keymask=mask,
@@ -625,8 +632,8 @@ class FlowEngine:
 
         def stage(st, a_in, lda, cin, act_out, act_ld):
             r, blocks = st["res"], st["blocks"]
-            ops.est_resnet(a_in, lda, cin, xs, r, tv[:, r["idx"] * C:], ntv, B=B, T=T, dtype=dt, bm=bm_r, rowmask=mask,
-                           nxt=nxt(blocks[0]))
+            ops.est_resnet(a_in, lda, cin, xs, r, tv[:, r["idx"] * C:], ntv, B=B, T=T, dtype=dt,
+                           bm=(16 if (self.split and cin > 320) else bm_r), rowmask=mask, nxt=nxt(blocks[0]))
             for j, w in enumerate(blocks):
                 attention()
                 last = j == len(blocks) - 1
@@ -796,6 +803,9 @@ class FlowEngine:
             if bf:
                 ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, st.ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tc, ldo=512, q_bs=Tc * 1024,
                                     k_bs=Tc * 1024, vt_bs=512 * Tc, o_bs=Tc * 512, scale=0.125, chunk=chunk, q_begin=r0)
+            elif self.split:
+                ops.attn_flash_x(qk, qk[:, :, 512:], qk[:, :, 1024:], st.ao, B=B, H=8, T=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                                 q_bs=Tc * 1536, k_bs=Tc * 1536, v_bs=Tc * 1536, o_bs=Tc * 512, scale=0.125, chunk=chunk, q_begin=r0)
             else:
                 ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], st.ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
                                q_bs=Tc * 1536, k_bs=Tc * 1536, v_bs=Tc * 1536, o_bs=Tc * 512, scale=0.125, dtype=dt, chunk=chunk,
@@ -804,8 +814,8 @@ class FlowEngine:
         def stage(sw, a_in, lda, cin, act_out, act_ld):
             r, blocks = sw["res"], sw["blocks"]
             i0 = blk[0]
-            ops.est_resnet(a_in, lda, cin, st.xs, r, tv[:, r["idx"] * C:], ntv, B=B, T=T, dtype=dt, bm=bm_r, nxt=nxt(blocks[0], i0),
-                           t_begin=r0, Tcap=Tc)
+            ops.est_resnet(a_in, lda, cin, st.xs, r, tv[:, r["idx"] * C:], ntv, B=B, T=T, dtype=dt,
+                           bm=(16 if (self.split and cin > 320) else bm_r), nxt=nxt(blocks[0], i0), t_begin=r0, Tcap=Tc)
             for j, w in enumerate(blocks):
                 attention(i0 + j)
                 last = j == len(blocks) - 1

@@ -255,12 +255,16 @@ class TtsEngine:
             i = j
         return out
 
-    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum, flow=None):
+    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum, flow=None, prompts=None):
         """Flow + DAC for a group of finished utterances: per-utterance conformer encoder, one batched ODE solve, per-
-        utterance DAC decode.  MMX_TIMING=3 prints the three stage times (with stream syncs between them)."""
+        utterance DAC decode.  prompts: per utterance (flow_prompt_speech_token [1, Lp], prompt_speech_feat [1, Tp, 80]) or
+        None (flow.py:472-498: the prompt's tokens go through the encoder in front of the utterance's, its latents are the
+        `cond` rows of its frames, and its frames are dropped from the result).
+        MMX_TIMING=3 prints the three stage times (with stream syncs between them)."""
         flow = flow or self.flow
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
+        pr = lambda b: (z, zf) if (prompts is None or prompts[b] is None) else prompts[b]
         trace = os.environ.get("MMX_TIMING") == "3"
         marks = []
 
@@ -270,11 +274,12 @@ class TtsEngine:
                 marks.append(time.perf_counter())
 
         mark()
-        conds = [flow.conditions(toks[b].reshape(1, -1), z, zf, embs[b]) for b in grp]
+        conds = [flow.conditions(toks[b].reshape(1, -1), pr(b)[0], pr(b)[1], embs[b]) for b in grp]
         mark()
         xs = flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
         mark()
-        for b, lat in zip(grp, xs):
+        for b, lat, c in zip(grp, xs, conds):
+            lat = lat[c[3]:]                                 # the prompt's frames are not rendered (flow.py:509)
             T2 = lat.shape[0]
             zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
             ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
@@ -287,13 +292,18 @@ class TtsEngine:
 
     @torch.no_grad()
     def tts_batch(self, texts, flow_embeddings, seed=0, exact_steps=None, group_size=8, max_pad_ratio=2.0,
-                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=60, tail_active=0, polite=True) -> List[torch.Tensor]:
+                  frame_quantum=32, overlap=True, poll_every=8, flow_workers=2, hold_steps=60, tail_active=0, polite=True,
+                  prompt_texts=None, llm_prompt_speech_tokens=None, flow_prompt_speech_tokens=None,
+                  prompt_speech_feats=None) -> List[torch.Tensor]:
         """Throughput path for a batch of independent utterances (BASELINE config 4, one rank's share): one batched
         AR decode for all of them; as sequences finish (shortest first) their flow + DAC work — per-utterance
         conformer encoder, ODE solves batched over groups of similar length (zero padded + masked), DAC decode — is
         issued by a second host thread on a second HIP stream, so the latency-bound decode loop and the MFMA-bound
         flow overlap on the chip (the reference overlaps the same two stages with its llm_job thread,
-        cli/model.py:332-335).  overlap=False runs the stages back to back.  No prompts (synthetic load).
+        cli/model.py:332-335).  overlap=False runs the stages back to back.
+        Zero-shot prompts (cli/cosyvoice.py:92-104 -> cli/model.py:321-326), each a per-utterance list or None: prompt_texts
+        and llm_prompt_speech_tokens condition the LM (llm.py:691-703), flow_prompt_speech_tokens / prompt_speech_feats the
+        flow (flow.py:472-498).
         group_size / hold_steps: a finished utterance waits at most hold_steps decode steps for up to group_size companions
         of similar length.  Large groups pay twice: a launch of the fused flow kernels costs about the same from 500 to
         8 000 rows (it is bound by every workgroup streaming the block's weights), so fewer, fuller groups are less GPU
@@ -316,7 +326,15 @@ class TtsEngine:
         if exact_steps is not None and not isinstance(exact_steps, (list, tuple)):
             exact_steps = [exact_steps] * B
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
-        xs = [self.llm.build_lm_input(t, z, z) for t in texts]
+        pick = lambda lst, b: z if (lst is None or lst[b] is None) else lst[b]
+        xs = [self.llm.build_lm_input(t, pick(prompt_texts, b), pick(llm_prompt_speech_tokens, b)) for b, t in enumerate(texts)]
+        prompts = None
+        if flow_prompt_speech_tokens is not None:
+            zf = torch.zeros(1, 0, 80, device=self.dev)
+            prompts = [None if flow_prompt_speech_tokens[b] is None else
+                       (flow_prompt_speech_tokens[b], zf if prompt_speech_feats is None or prompt_speech_feats[b] is None else prompt_speech_feats[b])
+                       for b in range(B)]
+        plen = [0 if (prompts is None or prompts[b] is None) else int(prompts[b][0].numel()) for b in range(B)]   # prompt tokens in the flow
         mins = [exact_steps[b] if exact_steps is not None else int(texts[b].numel() * 2) for b in range(B)]
         maxs = [exact_steps[b] if exact_steps is not None else int(texts[b].numel() * 20) for b in range(B)]
         wavs: List[Optional[torch.Tensor]] = [None] * B
@@ -328,8 +346,8 @@ class TtsEngine:
             for b in range(B):
                 toks[b] = self.llm.out_tokens[b, :n[b]].to(torch.int64)
             order = sorted(range(B), key=lambda b: (n[b], b))
-            for grp in self._groups(order, [2 * v for v in n], group_size, max_pad_ratio, frame_quantum):
-                self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum)
+            for grp in self._groups(order, [2 * (v + plen[b]) for b, v in enumerate(n)], group_size, max_pad_ratio, frame_quantum):
+                self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, prompts=prompts)
             self.last_tokens = toks
             return wavs
 
@@ -359,7 +377,7 @@ class TtsEngine:
                         grp, ev, flow.polite = item
                         side.wait_event(ev)                      # the group's token ids were written on the LM stream
                         t_in = _time.perf_counter()
-                        self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow)
+                        self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow, prompts)
                         if _trace:
                             side.synchronize()
                             print(f"[tts_batch]   worker {wi}: group of {len(grp)} ({[2 * toks[b].numel() for b in grp]} frames) "
@@ -415,7 +433,7 @@ class TtsEngine:
                 act = [s_ for s_ in range(len(slots)) if slots[s_] not in seen]
                 self.llm_small.compact_from(self.llm, act)
                 cur[0], cur[1] = self.llm_small, [slots[s_] for s_ in act]
-            frames = {b: 2 * toks[b].numel() for b in pending}
+            frames = {b: 2 * (toks[b].numel() + plen[b]) for b in pending}
             groups = self._groups(pending, frames, group_size, max_pad_ratio, frame_quantum, first=issued[0])
             sizes = group_size if isinstance(group_size, (list, tuple)) else [group_size]
             now = steps_done[0] * STEP_MS

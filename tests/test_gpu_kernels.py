@@ -577,7 +577,8 @@ def test_est_resnet_fused(env, dt, B, T, cin, lda, masked):
         _check_qkv(ops, dt, hn, wq(wqkv), qk, vt, B, T, tol, bm)
 
 
-@pytest.mark.parametrize("dt,tol", [(0, 2e-4), (1, 8e-2)])
+# dtype 2 = the split build (two bf16 planes per LDS tile): 2^-17 per operand, bounded like the split golden tests
+@pytest.mark.parametrize("dt,tol", [(0, 2e-4), (1, 8e-2), (2, 5e-4)])
 @pytest.mark.parametrize("B,T,masked,streaming", [(2, 64, False, False), (2, 500, False, False), (4, 130, True, True), (16, 320, True, False)])
 def test_estimator_fused_equals_unfused(dt, tol, B, T, masked, streaming):
     """The whole estimator on the row-tile kernels (every tile size the host picks: 16 / 32 / 64 rows) vs the

@@ -23,16 +23,17 @@ def _inputs():
 
 # the window of a hop has the full receptive field of the DAC decoder on both sides, so the arithmetic per sample is
 # the same as in the offline decode: fp32 build to rounding, bf16 build to the rounding of the bf16 activations
-STREAM_TOL = {0: 2e-5, 1: 2e-2}
+STREAM_TOL = {0: 2e-5, 1: 2e-2, 2: 2e-5}
+MC = 8                                                     # frames a streaming pass holds back (cli/model.py:258)
 
 
-@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("dt", [0, 1, 2])
 def test_stream_chunks_equal_offline_decode_of_the_same_latents(weights, dt):
-    """TtsEngine.tts_stream: chunk sizes follow the hop schedule with the right context held back; the concatenated
-    chunks equal ONE offline DAC decode of the concatenated latents.  Only the last `ctx_right` frames ahead of the
-    closing chunk may differ: like the reference, the closing flow pass runs without chunk masks, so the right context
-    those frames were rendered with is not what the closing pass then emits (bounded, checked separately)."""
-    from mmx import ops
+    """TtsEngine.tts_stream: chunk sizes follow the hop schedule (right context + the MEL_CACHE frames of the possible
+    closing cross-fade held back); up to the closing seam the concatenated chunks equal ONE offline DAC decode of the
+    latents they were rendered from, sample for sample.  The closing chunk (different latents for every frame: the closing
+    flow pass runs without chunk masks, like the reference's) is checked against the oracle's schedule in
+    test_stream_vs_oracle_schedule_with_prompts."""
     from mmx.pipeline import TtsEngine
     eng = TtsEngine(*weights, dtype=dt, max_batch=1, max_ctx=512)
     text, emb = _inputs()
@@ -45,23 +46,64 @@ def test_stream_chunks_equal_offline_decode_of_the_same_latents(weights, dt):
         assert 108 <= n_out <= 118                         # ids above the EOS id are skipped (llm.py:755)
         nh = (n_out - 3) // 25                             # full hops (25 tokens + 3 look-ahead available)
         sizes = [c.shape[-1] for c in chunks]
-        assert sizes[:nh] == [(50 - CR) * HOP] + [50 * HOP] * (nh - 1), sizes
+        assert sizes[:nh] == [(50 - CR - MC) * HOP] + [50 * HOP] * (nh - 1), sizes
         assert sum(sizes) == n_out * 2 * HOP and len(chunks) == nh + 1
         lat = torch.cat(lats, 0)
         assert lat.shape == (2 * n_out, 80)
-        zt = lat.to(eng.dac.tdt).reshape(1, -1, 80).contiguous()
-        off = eng.dac.decode_time_major(zt, 1, lat.shape[0])[0, 0]
+        ns = sum(sizes[:nh])                               # samples emitted by the streaming passes
+        nf = ns // HOP + MC                                # frames the streaming passes rendered
+        zt = lat[:nf + CR].to(eng.dac.tdt).reshape(1, -1, 80).contiguous()   # + their right context, streaming values
         got = torch.cat([c.reshape(-1) for c in chunks])
-        edge = (nh * 50 - CR) * HOP                        # first sample of the closing chunk
-        d = (got - off).abs()
-        lo = edge - CR * HOP
-        err_in = max(d[:lo].max().item(), d[edge:].max().item())
-        print(f"stream vs offline dtype {dt} rep {rep}: max abs err {err_in:.3e} (closing boundary: {d[lo:edge].max().item():.3e})")
-        assert err_in < STREAM_TOL[dt], err_in
-        assert d[lo:edge].max().item() < 0.5 and torch.isfinite(got).all()
+        assert torch.isfinite(got).all()
+        # the latents behind the streamed samples are the streaming passes' values; their right context too (the closing
+        # pass's re-solve of those frames starts MC frames later): decode a prefix of the streamed latents offline
+        off = eng.dac.decode_time_major(zt[:, :nf], 1, nf)[0, 0]
+        d = (got[:ns - CR * HOP] - off[:ns - CR * HOP]).abs().max().item()
+        print(f"stream vs offline dtype {dt} rep {rep}: max abs err {d:.3e} over {ns - CR * HOP} samples")
+        assert d < STREAM_TOL[dt], d
 
 
-@pytest.mark.parametrize("dt,tol", [(0, 2e-5), (1, 2e-2)])
+def _prompted_inputs():
+    g = torch.Generator().manual_seed(12)
+    return dict(text=torch.randint(0, 151936, (1, 20), generator=g), prompt_text=torch.randint(0, 151936, (1, 5), generator=g),
+                llm_prompt=torch.randint(0, 6561, (1, 30), generator=g), flow_prompt=torch.randint(0, 6561, (1, 30), generator=g),
+                feat=torch.randn(1, 60, 80, generator=g) * 0.5, emb=torch.randn(1, 192, generator=g))
+
+
+@pytest.mark.parametrize("dt", [0, 2])
+def test_stream_vs_oracle_schedule_with_prompts(weights, dt):
+    """SURVEY 8f-1 against the ORACLE (oracle/stream.py restates cli/model.py:336-378 over oracle.flow / oracle.dac): a
+    zero-shot utterance (LM prompt text + prompt speech tokens, flow prompt tokens + prompt latents: 30 prompt tokens ->
+    prompt_token_pad 20, first hop 45 tokens) of 130 tokens = 4 streaming hops + the closing pass.  TtsEngine.tts_stream with
+    the estimator state cache and with per-hop recompute: the same chunk sizes as the oracle's schedule and every sample
+    within 1e-3 (north-star bound), the closing seam included."""
+    from mmx.pipeline import TtsEngine
+    from oracle import stream as OS
+    llm_sd, flow_sd, dac_sd = weights
+    I = _prompted_inputs()
+    c = lambda t: t.cuda()
+    eng = TtsEngine(*weights, dtype=dt, max_batch=1, max_ctx=512)
+    outs = {}
+    for cache in (True, False):
+        chunks = [w.reshape(-1).cpu() for w in eng.tts_stream(c(I["text"]), c(I["emb"]), seed=5, exact_steps=134, cache=cache,
+                                                              prompt_text=c(I["prompt_text"]), llm_prompt_speech_token=c(I["llm_prompt"]),
+                                                              flow_prompt_speech_token=c(I["flow_prompt"]), prompt_speech_feat=c(I["feat"]))]
+        n_out = int(eng.llm.state[2, 0])
+        outs[cache] = (chunks, eng.llm.out_tokens[0, :n_out].cpu().to(torch.int64).reshape(1, -1))
+    toks = outs[True][1]
+    assert torch.equal(toks, outs[False][1]) and 123 <= toks.shape[1] <= 134
+    with torch.no_grad():
+        want = OS.tts_stream(flow_sd, dac_sd, [5, 4, 4, 3, 2], toks, I["flow_prompt"], I["feat"], I["emb"], eng.dac.ctx_left, eng.dac.ctx_right)
+    assert len(OS.hop_schedule(toks.shape[1], 30)) == 5
+    for cache in (True, False):
+        got = outs[cache][0]
+        assert [g.shape[0] for g in got] == [w.shape[0] for w in want], ([g.shape[0] for g in got], [w.shape[0] for w in want])
+        errs = [(g - w).abs().max().item() for g, w in zip(got, want)]
+        print(f"tts_stream (cache={cache}) dtype {dt} vs oracle schedule: per-chunk max abs err {[f'{e:.2e}' for e in errs]}")
+        assert max(errs) <= 1e-3, errs
+
+
+@pytest.mark.parametrize("dt,tol", [(0, 2e-5), (1, 2e-2), (2, 2e-5)])
 def test_stream_cached_state_equals_recompute(weights, dt, tol):
     """Config 5: hops that solve only their new frames from the cached K / V rows and conv inputs of earlier hops
     (FlowEngine.StreamState) give the waveform of the reference's schedule, which re-solves every frame at every hop
@@ -114,15 +156,16 @@ def test_stream_makes_progress_when_many_ids_are_skipped(weights):
     assert sum(c.shape[-1] for c in res["chunks"]) == n_out * 2 * HOP
 
 
-def test_dropin_tts_stream_equals_offline_decode(weights):
-    """CosyVoice2Model.tts(stream=True) (drop-in): same tokens as stream=False under the same seed, chunks follow the
-    hop schedule, and every chunk except the samples next to the closing boundary equals the engine-level stream."""
+def test_dropin_tts_stream_vs_oracle_and_engine(weights):
+    """CosyVoice2Model.tts(stream=True) (drop-in), zero-shot prompts included: the same chunks as the engine-level stream
+    (same tokens under the same seed) and, through it, within 1e-3 of the oracle's schedule (oracle/stream.py)."""
     from functools import partial
     from cosyvoice.cli.model import CosyVoice2Model
     from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM
     from cosyvoice.utils.common import ras_sampling
     from test_dropin_api import build_dac, build_flow
     from mmx.pipeline import TtsEngine
+    from oracle import stream as OS
     llm_sd, flow_sd, dac_sd = weights
     lm = Qwen2LM(896, 896, 6561, Qwen2Encoder({"num_hidden_layers": 2}), partial(ras_sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1))
     lm.load_state_dict(llm_sd, strict=True)
@@ -131,13 +174,30 @@ def test_dropin_tts_stream_equals_offline_decode(weights):
     dac.load_state_dict(dac_sd, strict=False)
     for m in (lm, flow, dac):
         m.to("cuda").float_parity()
-    lm.seed = 3
+    lm.seed = 5
     model = CosyVoice2Model(lm, flow, dac)
-    _, emb = _inputs()
-    text = torch.randint(0, 151936, (1, 6), generator=torch.Generator().manual_seed(8)).cuda()   # <= 120 tokens: 4 hops
-    chunks = [c["tts_speech"] for c in model.tts(text=text.cpu(), flow_embedding=emb.cpu(), llm_embedding=emb.cpu(), stream=True)]
+    I = _prompted_inputs()
+    N = 134
+    ratio = (N + 0.5) / I["text"].shape[1]                  # exactly N decode steps: min == max token / text ratio
+    orig = lm.inference
+    lm.inference = lambda **kw: orig(**{**kw, "min_token_text_ratio": ratio, "max_token_text_ratio": ratio})
+    chunks = [c["tts_speech"].reshape(-1) for c in model.tts(text=I["text"], flow_embedding=I["emb"], llm_embedding=I["emb"],
+                                                             prompt_text=I["prompt_text"], llm_prompt_speech_token=I["llm_prompt"],
+                                                             flow_prompt_speech_token=I["flow_prompt"], prompt_speech_feat=I["feat"],
+                                                             stream=True)]
+    c = lambda t: t.cuda()
     eng = TtsEngine(llm_sd, flow_sd, dac_sd, dtype=0, max_batch=1, max_ctx=2048)
-    ref = [c.cpu() for c in eng.tts_stream(text, emb, seed=3)]
-    assert [c.shape[-1] for c in chunks] == [c.shape[-1] for c in ref]
-    a, b = torch.cat([c.reshape(-1) for c in chunks]), torch.cat([c.reshape(-1) for c in ref])
+    ref = [w.reshape(-1).cpu() for w in eng.tts_stream(c(I["text"]), c(I["emb"]), seed=5, exact_steps=N, prompt_text=c(I["prompt_text"]),
+                                                       llm_prompt_speech_token=c(I["llm_prompt"]), flow_prompt_speech_token=c(I["flow_prompt"]),
+                                                       prompt_speech_feat=c(I["feat"]), cache=False)]
+    assert [x.shape[0] for x in chunks] == [x.shape[0] for x in ref]
+    a, b = torch.cat(chunks), torch.cat(ref)
     assert (a - b).abs().max().item() < 2e-5
+    n_out = int(eng.llm.state[2, 0])
+    toks = eng.llm.out_tokens[0, :n_out].cpu().to(torch.int64).reshape(1, -1)
+    with torch.no_grad():
+        want = torch.cat(OS.tts_stream(flow_sd, dac_sd, [5, 4, 4, 3, 2], toks, I["flow_prompt"], I["feat"], I["emb"], eng.dac.ctx_left,
+                                       eng.dac.ctx_right))
+    err = (a - want).abs().max().item()
+    print(f"drop-in tts(stream=True) with prompts vs oracle schedule: max abs err {err:.3e}")
+    assert a.shape == want.shape and err <= 1e-3, err

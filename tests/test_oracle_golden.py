@@ -228,3 +228,36 @@ def test_flow_sub_blocks_match_reference(golden_dir, flow_sd):
     for name in ("pad", "chunk"):
         y = OFLOW.basic_transformer_block(flow_sd, e + ".mid_blocks.0.1.0", t("tb_hs"), t(f"tb_bias_{name}"))
         assert (y - t(f"tb_out_{name}")).abs().max() < 2e-5, name
+
+
+
+def test_stream_schedule_restates_reference_hops():
+    """oracle/stream.py hop_schedule against cli/model.py:336-378 worked by hand: (visible tokens, token_offset, finalize)."""
+    from oracle import stream as OS
+    # no prompt, 118 tokens: hops of 25 once 28 tokens past the offset exist, then the closing pass over everything
+    assert OS.hop_schedule(118, 0) == [(28, 0, False), (53, 25, False), (78, 50, False), (103, 75, False), (118, 100, True)]
+    # 30 prompt tokens: prompt_token_pad = ceil(30 / 25) * 25 - 30 = 20 -> the first hop takes 45 tokens
+    assert OS.hop_schedule(130, 30) == [(48, 0, False), (73, 45, False), (98, 70, False), (123, 95, False), (130, 120, True)]
+    # too short for a single hop: only the closing pass
+    assert OS.hop_schedule(20, 0) == [(20, 0, True)]
+    # exactly hop + look-ahead tokens: one hop, then the closing pass over the same tokens
+    assert OS.hop_schedule(28, 0) == [(28, 0, False), (28, 25, True)]
+
+
+def test_stream_rendering_rule_is_exact_when_passes_agree(golden_dir):
+    """The DAC context rule of oracle/stream.py (restated from mmx/pipeline.py::tts_stream): when every pass holds the same
+    latents (streaming passes do; here the closing pass too), hold-back, context windows and the unit-sum cross-fade must
+    reproduce ONE offline decode of the latents sample for sample."""
+    from mmx.dac import DacDecoderEngine
+    from oracle import dac as ODAC, stream as OS
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_dac80.json")), SEED)
+    rates = [5, 4, 4, 3, 2]
+    CL, CR = DacDecoderEngine.receptive_field(rates)
+    lat = torch.randn(130, 80, generator=torch.Generator().manual_seed(3))
+    passes = [(0, lat[:50], False), (50, lat[:100], False), (100, lat, True)]
+    with torch.no_grad():
+        got = torch.cat(OS.render_passes(sd, rates, passes, CL, CR))
+        ref = ODAC.decode(sd, lat.t().unsqueeze(0).contiguous(), rates)[0, 0]
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-6
+    w = OS.fade_window(8 * 480)
+    assert (w[:3840] + w[3840:] - 1).abs().max().item() < 1e-6
