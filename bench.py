@@ -84,6 +84,39 @@ def measure_lm_kernel(eng, iters=240):
             "traffic": traffic, "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
 
 
+def measure_lm_step(eng, ctx=300, iters=96):
+    """HBM roofline of ONE WHOLE decode step of the LM at the workload's batch size - the critical path of the step (the
+    decode loop is 85 % of it): the captured decode step (every projection, the decode attention, the head, the sampler)
+    replayed `iters` times from context length `ctx`, timed with HIP events on the stream the graph replays on.
+    Algorithmic bytes per step: the bf16 weights once per step, 715.8 MB backbone + 11.8 MB llm_decoder =
+    727.6 MB whatever the batch, + the KV cache rows read, batch * ctx * 2 (K, V) * 2 kv heads * 64 * 24 layers * element
+    size (the split build keeps the cache in fp32)."""
+    llm = eng.llm
+    B = llm.B
+    z = torch.zeros(1, 0, dtype=torch.long, device=llm.dev)
+    g = torch.Generator().manual_seed(11)
+    xs = [llm.build_lm_input(torch.randint(0, 151936, (1, 48), generator=g).to(llm.dev), z, z) for _ in range(B)]
+    n = ctx - 50 + iters + 16
+    llm.start(xs, [n] * B, [n] * B, seed=0)
+    for _ in range(ctx - 50):                               # the first call of a new graph key runs eagerly, the second records
+        llm.step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(torch.cuda.current_stream())
+    for _ in range(iters):
+        llm.step()
+    e1.record(torch.cuda.current_stream())
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    kv_esz = 2 if llm.tdt == torch.bfloat16 else 4
+    wbytes = 727.6e6 if llm.layers[0]["wqkv"].dtype == torch.bfloat16 else 2 * 727.6e6
+    nbytes = wbytes + B * (ctx + iters / 2) * 2 * llm.Hkv * llm.D * llm.n_layers * kv_esz
+    achieved = nbytes / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": f"one captured LM decode step at batch {B}, context {ctx}..{ctx + iters} ({llm.n_layers} layers x 5 launches + head + sampler)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "bytes_per_launch": int(nbytes), "us_per_launch": round(us, 2), "launches_per_step": None}
+
+
 def _event_time_graph(fn, iters):
     """Average duration (us) of `fn`'s launches: recorded `iters` times into one hipGraph (the launch mechanism of the
     pipeline), replayed once untimed and once between two HIP events on the launch stream."""
@@ -462,9 +495,12 @@ def main():
                "rtf": round(el / audio_s * world, 5),
                "config": {"workload": wl, "utterances_per_gpu": PER_GPU, "audio_s_per_step": round(audio_s / a.steps, 2),
                           "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
+        out["collective"] = {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None)}
+        if world == 1 and a.workload == "batch":
+            out["roofline_lm_step"] = measure_lm_step(eng)
         if world == 1 and dt != 2:
             out["roofline_lm"] = measure_lm_kernel(eng)
-            out["roofline"] = measure_flow_kernel(eng, shape_log, a.steps) if (dt == 1 and a.workload == "batch" and shape_log) else out["roofline_lm"]
+            out["roofline"] = measure_flow_kernel(eng, shape_log, a.steps) if (dt == 1 and a.workload == "batch" and shape_log) else out.get("roofline_lm", out.get("roofline_lm_step"))
             if dt == 1 and a.workload == "batch" and shape_log:
                 out["roofline_attn"] = measure_attn_kernel(eng, shape_log, a.steps)
             if a.workload == "batch" and not a.no_extras:

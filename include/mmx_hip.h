@@ -168,13 +168,19 @@ int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                         int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk, int q_begin,
                         const int32_t* klen, hipStream_t stream);
-/* The same contract on the split build (MMX_X2): q / k / v / out fp32, V ROW-major (v[b][t][h*D + d], ldv elements per
+/* mmx_attn_flash_xs: the split build's attention on operands the PRODUCER has already split (MmxEstNext, MMX_X2 with
+ * vt_out): qk bf16 [B][T][ldqk >= 2048] = [hi Q | hi K | lo Q | lo K], vt bf16 [B][2][512][ldvt], out fp32 [B][T][ldo].
+ * mmx_attn_flash_x: the same contract on fp32 operands:
+ * q / k / v / out fp32, V ROW-major (v[b][t][h*D + d], ldv elements per
  * row — the QKV projection's own output, no transposed copy), both operands of Q K^T and P V split into bf16 hi + lo
  * (3 MFMAs per product).  Replaces the same reference lines as mmx_attn_flash_bf16. */
 int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const float* k, int64_t ldk, int64_t k_bs,
                      const float* v, int64_t ldv, int64_t v_bs, float* out, int64_t ldo, int64_t o_bs,
                      int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk,
                      int q_begin, const int32_t* klen, hipStream_t stream);
+int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, const void* vt, int64_t ldvt, int64_t vt_bs,
+                      float* out, int64_t ldo, int64_t o_bs, int B, int H, int T, float scale, const float* keymask,
+                      int64_t km_bs, int chunk, int q_begin, const int32_t* klen, hipStream_t stream);
 /* The same contract (bf16 tensors in HBM) with Q, K, V^T and P quantised to OCP fp8 e4m3 inside the kernel and both
  * products on the fp8 MFMA (BASELINE config 5).  Accuracy: the bound stated in tests/test_gpu_kernels.py (<= 7 % of the output RMS). */
 int mmx_attn_flash_fp8(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
@@ -303,6 +309,9 @@ int mmx_sample_step(const float* logits, int64_t ldl, int V, int B, int eos_id, 
  *   transformer block (matcha transformer.py:256-285: norm1 -> attn1.to_q/to_k/to_v, no bias).
  *   MMX_BF16: q_out = [B][T][ldq >= 1024] (Q | K) and vt_out = V transposed [B][512][ldvt] (frames >= T written as 0);
  *   MMX_F32 : q_out = [B][T][ldq >= 1536] (Q | K | V), vt_out unused.
+ *   MMX_X2  : vt_out == NULL: fp32 q_out = [B][T][ldq >= 1536] (Q | K | V);  vt_out != NULL: the operands of
+ *             mmx_attn_flash_xs, split here once: q_out bf16 [B][T][ldq >= 2048] = [hi Q | hi K | lo Q | lo K] and
+ *             vt_out bf16 [B][2 planes][512][ldvt] (V transposed, hi then lo; vt_bs >= 2 * 512 * ldvt).
  * mmx_est_tail: x += attn1.to_out(ao) ; x += ff(norm3(x))  (transformer.py:286-313), x fp32 [B][T][256] in place;
  *   rowmask (optional) multiplies the result; act_out (optional) receives T(x) with row stride act_ld.
  * mmx_est_resnet: CausalResnetBlock1D (flow/decoder.py:65-85 + matcha decoder.py:56-61):

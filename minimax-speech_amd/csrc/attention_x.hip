@@ -27,12 +27,22 @@ __device__ __forceinline__ void split4(const float x[4], uint2& hi, uint2& lo) {
     lo.y = pack_bf16x2(x[2] - __uint_as_float(hi.y << 16), x[3] - __uint_as_float(hi.y & 0xffff0000u));
 }
 
-template <int MF>
+// PRE = false: q / k / v fp32 row-major, split (and V transposed) by this kernel tile by tile.
+// PRE = true : the PRODUCER already split them (csrc/fused.hip ln_qkv, split build): q / k point at bf16 rows [hi Q | hi K |
+//              lo Q | lo K] (the lo terms 1024 columns behind the hi terms), v at V TRANSPOSED as bf16 planes
+//              vt[plane][h*D + d][t] (plane stride 512 * ldv); tiles go from HBM to LDS as they are.  Every key / value tile
+//              is used by all query tiles of its (batch, head): splitting it once at the producer instead of once per query
+//              tile removes the conversion VALU work (and its shuffles) from this kernel's loop.
+template <int MF, bool PRE>
 __global__ __launch_bounds__(256) void attn_flash_x_kernel(
-    const float* __restrict__ q, long ldq, long q_bs, const float* __restrict__ k, long ldk, long k_bs,
-    const float* __restrict__ v, long ldv, long v_bs, float* __restrict__ out, long ldo, long o_bs,
+    const void* __restrict__ q_, long ldq, long q_bs, const void* __restrict__ k_, long ldk, long k_bs,
+    const void* __restrict__ v_, long ldv, long v_bs, float* __restrict__ out, long ldo, long o_bs,
     int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
     int q_begin, const int32_t* __restrict__ klen) {
+    typedef std::conditional_t<PRE, bf16_t, float> TI;
+    const TI* q = reinterpret_cast<const TI*>(q_);
+    const TI* k = reinterpret_cast<const TI*>(k_);
+    const TI* v = reinterpret_cast<const TI*>(v_);
     constexpr int D = 64, KT = 64, QW = 16 * MF;
     constexpr int TILE = KT * 128;                     // bytes of one [64][64] bf16 image
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     const int qb = q_begin + qt * (4 * QW) + wave * QW;
     q += (long)b * q_bs + h * D;
     k += (long)b * k_bs + h * D;
-    v += (long)b * v_bs + h * D;
+    v += PRE ? (long)b * v_bs + (long)h * D * ldv : (long)b * v_bs + h * D;
     out += (long)b * o_bs + h * D;
     const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
     const float sc2 = scale * 1.44269504088896341f;
@@ -73,14 +83,20 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
         row = row < Tn ? row : Tn - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const float* qp = q + (long)row * ldq + ks * 32 + 8 * g;
-            const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
-            const float x0[4] = {a.x, a.y, a.z, a.w}, x1[4] = {c.x, c.y, c.z, c.w};
-            uint2 h0, l0, h1, l1;
-            split4(x0, h0, l0);
-            split4(x1, h1, l1);
-            aqh[mf][ks] = __builtin_bit_cast(short8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
-            aql[mf][ks] = __builtin_bit_cast(short8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            if constexpr (PRE) {
+                const bf16_t* qp = reinterpret_cast<const bf16_t*>(q) + (long)row * ldq + ks * 32 + 8 * g;
+                aqh[mf][ks] = *reinterpret_cast<const short8_t*>(qp);
+                aql[mf][ks] = *reinterpret_cast<const short8_t*>(qp + 1024);
+            } else {
+                const float* qp = reinterpret_cast<const float*>(q) + (long)row * ldq + ks * 32 + 8 * g;
+                const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
+                const float x0[4] = {a.x, a.y, a.z, a.w}, x1[4] = {c.x, c.y, c.z, c.w};
+                uint2 h0, l0, h1, l1;
+                split4(x0, h0, l0);
+                split4(x1, h1, l1);
+                aqh[mf][ks] = __builtin_bit_cast(short8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                aql[mf][ks] = __builtin_bit_cast(short8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            }
         }
     }
     float4_t o[MF][4];
@@ -120,16 +136,46 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     //      (key 2p, key 2p+1) as one dword of the transposed image
     float4 kreg[4], vreg[4];
     auto load_tiles = [&](int j0) {
+        if constexpr (PRE) {
+            // 512 chunks of 8 bf16 per plane and operand: chunk id -> (row r = id >> 3, 16-byte chunk id & 7); kreg / vreg
+            // [2p + plane]: p-th chunk of this thread, hi / lo plane
+            const bf16_t* kb = reinterpret_cast<const bf16_t*>(k);
+            const bf16_t* vb = reinterpret_cast<const bf16_t*>(v);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                const int id = tid + pi * 256, r = id >> 3, c = (id & 7) * 8;
+                const int key = j0 + r;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    kreg[2 * pi + pl] = key < Tk ? *reinterpret_cast<const float4*>(kb + (long)key * ldk + pl * 1024 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    // V^T rows are channels; columns j0 + c .. +7 (the buffer is zero padded to a multiple of 8 columns)
+                    vreg[2 * pi + pl] = (j0 + c < Tk) ? *reinterpret_cast<const float4*>(vb + (long)pl * 512 * ldv + (long)r * ldv + j0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + i * 256;
             const int kr = j0 + (id >> 4);
-            kreg[i] = kr < Tk ? *reinterpret_cast<const float4*>(k + (long)kr * ldk + (id & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            kreg[i] = kr < Tk ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(k) + (long)kr * ldk + (id & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             const int vr = j0 + 2 * (id >> 5) + (id & 1);
-            vreg[i] = vr < Tk ? *reinterpret_cast<const float4*>(v + (long)vr * ldv + ((id >> 1) & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vreg[i] = vr < Tk ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(v) + (long)vr * ldv + ((id >> 1) & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_tiles = [&](int buf) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                const int id = tid + pi * 256, r = id >> 3, c8 = id & 7;
+                const int off = buf * TILE + swz(r, c8);
+                *reinterpret_cast<float4*>(Kh + off) = kreg[2 * pi];
+                *reinterpret_cast<float4*>(Kl + off) = kreg[2 * pi + 1];
+                *reinterpret_cast<float4*>(Vh + off) = vreg[2 * pi];
+                *reinterpret_cast<float4*>(Vl + off) = vreg[2 * pi + 1];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + i * 256;
@@ -299,13 +345,13 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     }
 }
 
-template <int MF>
-int launch_flash_x(dim3 grid, hipStream_t stream, const float* q, long ldq, long q_bs, const float* k, long ldk, long k_bs,
-                   const float* v, long ldv, long v_bs, float* out, long ldo, long o_bs, int T_, float scale,
+template <int MF, bool PRE>
+int launch_flash_x(dim3 grid, hipStream_t stream, const void* q, long ldq, long q_bs, const void* k, long ldk, long k_bs,
+                   const void* v, long ldv, long v_bs, float* out, long ldo, long o_bs, int T_, float scale,
                    const float* keymask, long km_bs, int chunk, int nq, int H, int npairs, int q_begin, const int32_t* klen) {
     const size_t lds = (size_t)8 * 64 * 128 + (size_t)2 * 4 * 16 * MF * 128;
-    MMX_LDS_OPT_IN(attn_flash_x_kernel<MF>, lds);
-    hipLaunchKernelGGL((attn_flash_x_kernel<MF>), grid, dim3(256), lds, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_,
+    MMX_LDS_OPT_IN((attn_flash_x_kernel<MF, PRE>), lds);
+    hipLaunchKernelGGL((attn_flash_x_kernel<MF, PRE>), grid, dim3(256), lds, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_,
                        scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
@@ -325,6 +371,24 @@ extern "C" int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const
     const bool small = (long)npairs * ((Tq + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
-    if (small) return launch_flash_x<1>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
-    return launch_flash_x<2>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    if (small) return launch_flash_x<1, false>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    return launch_flash_x<2, false>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+}
+
+// The same attention on operands the producer has already split (csrc/fused.hip, split build): qk bf16 [B][T][ldqk >= 2048] =
+// [hi Q | hi K | lo Q | lo K], vt bf16 [B][2 planes][512][ldvt] (V transposed, zero padded columns), out fp32.
+extern "C" int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, const void* vt, int64_t ldvt, int64_t vt_bs,
+                                 float* out, int64_t ldo, int64_t o_bs, int B, int H, int T_, float scale, const float* keymask,
+                                 int64_t km_bs, int chunk, int q_begin, const int32_t* klen, hipStream_t stream) {
+    MMX_CHECK_ARG(qk && vt && out && B > 0 && H > 0 && H * 64 <= 512 && T_ > 0 && chunk >= 0);
+    MMX_CHECK_ARG(q_begin >= 0 && q_begin < T_ && q_begin % 16 == 0);
+    MMX_CHECK_ARG(ldqk >= 2048 && ldqk % 8 == 0 && qk_bs % 8 == 0 && ldvt % 8 == 0 && ldvt >= ((T_ + 7) / 8) * 8 && vt_bs % 8 == 0 && vt_bs >= 2 * 512 * ldvt);
+    MMX_CHECK_ARG(ldo % 4 == 0 && o_bs % 4 == 0 && ((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 16) == 0);
+    const int npairs = H * B, Tq = T_ - q_begin;
+    const bool small = (long)npairs * ((Tq + 127) / 128) < 192;
+    const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
+    dim3 grid(8 * ((npairs + 7) / 8) * nq);
+    const bf16_t* q = (const bf16_t*)qk;
+    if (small) return launch_flash_x<1, true>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    return launch_flash_x<2, true>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
 }

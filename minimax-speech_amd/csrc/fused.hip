@@ -353,45 +353,73 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
     for (int i = 0; i < MF; ++i) store_tile<T, NS, CW>(a1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), plane, xv[i]);
     __syncthreads();
     const char* a_lane = a1 + l16 * P1 + g * 16;
-    constexpr bool VT = sizeof(T) == 2 && NS == 1;
-    constexpr int PV = 16 * (int)sizeof(T) + 16;       // V^T patch pitch: [64 columns][16 frames] inside the wave's patch
+    // bf16 build: Q | K as bf16 rows and V transposed.  Split build: the same two layouts as bf16 PLANES when the caller
+    // gives vt_out (q_out bf16 [B][T][ldq >= 2048] = [hi Q | hi K | lo Q | lo K], vt_out [B][2][512][ldvt]: what
+    // mmx_attn_flash_xs reads - the operands are split here, once, instead of in every query tile of the attention), or
+    // fp32 rows Q | K | V when vt_out is NULL.
+    constexpr bool VTC = sizeof(T) == 2;
+    const bool planes = NS > 1 && nx.vt_out != nullptr;
+    const bool vt_path = VTC && (NS == 1 || planes);
+    constexpr int PV = 16 * 2 + 16;                    // V^T patch pitch: [64 columns][16 frames] of bf16 inside the wave's patch
     for (int p = 0; p < NP; ++p) {
         float4_t acc[MF][4];
         zero_acc(acc);
         const T* wn = p + 1 < NP ? qkv_pass<T, NW>(nx.wqkv, wave, lane, p + 1) : nullptr;
         stage_run<T, MF, 4, PF, NS>(ring, a_lane, P1, NK, qkv_pass<T, NW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, 4, acc, plane);
         const int kind = p / PPK, cw = (wave * PPK + p % PPK) * 64;     // 64 columns at cw inside the 512-wide Q / K / V
-        if (VT && kind == 2) {
+        if (vt_path && kind == 2) {
             // C layout -> [column][frame] patch, one 16-frame fragment at a time: a lane holds 4 consecutive frames of
             // one column; then lane = column writes two 16-byte chunks of 8 frames (frames >= Tn as zeros: the pad of
-            // the transposed buffer stays finite)
+            // the transposed buffer stays finite).  Split build: once for the hi terms, once for the remainders.
             char* vw = reinterpret_cast<char*>(patch);
-            bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)(cw + lane) * nx.ldvt + t0;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)s2 * 512 * nx.ldvt + (long)(cw + lane) * nx.ldvt + t0;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                        pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                        *reinterpret_cast<uint2*>(vw + (j * 16 + l16) * PV + (4 * g) * 2) = pk;
+                        if (s2 + 1 < NS) {             // the remainders become the next plane
+                            acc[i][j][0] -= __uint_as_float(pk.x << 16); acc[i][j][1] -= __uint_as_float(pk.x & 0xffff0000u);
+                            acc[i][j][2] -= __uint_as_float(pk.y << 16); acc[i][j][3] -= __uint_as_float(pk.y & 0xffff0000u);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int c8 = 0; c8 < 2; ++c8) {
+                        uint4 v = *reinterpret_cast<const uint4*>(vw + lane * PV + c8 * 16);
+                        const int t = t0 + i * 16 + c8 * 8;
+                        if (t >= Tn) continue;
+                        if (t + 8 > Tn) {
+                            unsigned short* h = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (t + e >= Tn) h[e] = 0;
+                        }
+                        *reinterpret_cast<uint4*>(dst + i * 16 + c8 * 8) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        } else if (planes) {
+            bf16_t* out = reinterpret_cast<bf16_t*>(nx.q_out) + (long)b * nx.q_bs;
+            const int col = kind * 512 + cw + (lane & 3) * 16;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
+                float v[16], lo[16];
+                to_rows<4>(acc[i], patch, lane, v);
+                const int t = t0 + i * 16 + rl;
+                if (t < Tn) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                    pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                    *reinterpret_cast<uint2*>(vw + (j * 16 + l16) * PV + (4 * g) * 2) = pk;
+                    for (int c = 0; c < 16; ++c) lo[c] = v[c] - bf2f(f2bf(v[c]));
+                    storen_T<bf16_t, 16>(out + (long)t * nx.ldq + col, v);
+                    storen_T<bf16_t, 16>(out + (long)t * nx.ldq + 1024 + col, lo);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int c8 = 0; c8 < 2; ++c8) {
-                    uint4 v = *reinterpret_cast<const uint4*>(vw + lane * PV + c8 * 16);
-                    const int t = t0 + i * 16 + c8 * 8;
-                    if (t >= Tn) continue;
-                    if (t + 8 > Tn) {
-                        unsigned short* h = reinterpret_cast<unsigned short*>(&v);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (t + e >= Tn) h[e] = 0;
-                    }
-                    *reinterpret_cast<uint4*>(dst + i * 16 + c8 * 8) = v;
-                }
-                __builtin_amdgcn_wave_barrier();
             }
         } else {
             TI* out = reinterpret_cast<TI*>(nx.q_out) + (long)b * nx.q_bs;
@@ -684,7 +712,12 @@ int check_next(const MmxEstNext& nx, int dtype, int T_) {
     MMX_CHECK_ARG(nx.n1g && nx.n1b && nx.q_out);
     MMX_CHECK_ARG(((uintptr_t)nx.q_out % 16) == 0 && nx.q_bs % 8 == 0);
     if (dtype == MMX_X2) {
-        MMX_CHECK_ARG(nx.ldq % 4 == 0 && nx.ldq >= 1536 && nx.q_bs % 4 == 0);
+        if (nx.vt_out) {                               // pre-split planes for mmx_attn_flash_xs
+            MMX_CHECK_ARG(nx.ldq % 8 == 0 && nx.ldq >= 2048 && nx.q_bs % 8 == 0 && nx.ldvt % 8 == 0 && nx.ldvt >= ((T_ + 7) / 8) * 8);
+            MMX_CHECK_ARG(((uintptr_t)nx.vt_out % 16) == 0 && nx.vt_bs % 8 == 0 && nx.vt_bs >= 2 * 512 * (int64_t)nx.ldvt);
+        } else {
+            MMX_CHECK_ARG(nx.ldq % 4 == 0 && nx.ldq >= 1536 && nx.q_bs % 4 == 0);
+        }
     } else if (dtype == MMX_BF16) {
         MMX_CHECK_ARG(nx.vt_out && nx.ldq % 8 == 0 && nx.ldq >= 1024 && nx.ldvt % 8 == 0 && nx.ldvt >= ((T_ + 7) / 8) * 8);
         MMX_CHECK_ARG(((uintptr_t)nx.vt_out % 16) == 0 && nx.vt_bs % 8 == 0);

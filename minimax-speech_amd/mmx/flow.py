@@ -505,10 +505,10 @@ class FlowEngine:
                  rowmask=(mask if act_out is not None else None), rm_bstride=T,
                  out_act=act_out, ldo_a=act_ld, oa_bstride=T * act_ld)
 
-    def _vt_buf(self, B, Tp):
-        key = (B, Tp)                                  # referenced by recorded graphs: never evicted (<= 15 MB each)
+    def _vt_buf(self, B, Tp, planes=1):
+        key = (B, Tp, planes)                          # referenced by recorded graphs: never evicted (<= 15 MB each)
         if key not in self._vt:
-            self._vt[key] = torch.zeros(B, 512, Tp, dtype=self.tdt, device=self.dev)      # pad columns stay zero
+            self._vt[key] = torch.zeros(B, planes * 512, Tp, dtype=torch.bfloat16 if planes > 1 else self.tdt, device=self.dev)   # pad columns stay zero
         return self._vt[key]
 
     def estimator(self, x, x_bstride, mu, spks, cond, t, B, T, mask=None, streaming=False, out=None, x_mod=None, klen=None):
@@ -608,13 +608,20 @@ class FlowEngine:
         if bf:
             Tp = ops.round_up(T, 8)
             qk, vt = self._new(B, T, 1024), self._vt_buf(B, Tp)
+            vt_bs = 512 * Tp
+        elif self.split:
+            # the producer splits the attention operands once: bf16 [hi Q | hi K | lo Q | lo K] rows and V^T planes
+            Tp = ops.round_up(T, 8)
+            qk = torch.empty(B, T, 2048, dtype=torch.bfloat16, device=self.dev)
+            vt = self._vt_buf(B, Tp, planes=2)
+            vt_bs = 2 * 512 * Tp
         else:
-            qk, vt, Tp = self._new(B, T, 1536), None, 0
+            qk, vt, Tp, vt_bs = self._new(B, T, 1536), None, 0, 0
         ldq = qk.shape[-1]
 
         def nxt(w):
             return ops.est_next(wqkv=w["wqkv_p"], n1g=w["n1g"], n1b=w["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
-                                vt_bs=512 * Tp)
+                                vt_bs=vt_bs)
 
         def attention():
             if bf:
@@ -622,9 +629,8 @@ class FlowEngine:
                                     k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125,
                                     keymask=(None if klen is not None else mask), chunk=chunk, fp8=self.attn_fp8, klen=klen)
             elif self.split:
-                ops.attn_flash_x(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, T=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
-                                 q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125,
-                                 keymask=(None if klen is not None else mask), chunk=chunk, klen=klen)
+                ops.attn_flash_xs(qk, vt, ao, B=B, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=vt_bs, o_bs=T * 512,
+                                  scale=0.125, keymask=(None if klen is not None else mask), chunk=chunk, klen=klen)
             else:
                 ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
                                q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, keymask=mask,

@@ -18,7 +18,7 @@ from mmx.pipeline import TtsEngine  # noqa: E402
 
 
 class DecodeOnly(TtsEngine):
-    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum, flow=None):
+    def _flow_dac_group(self, grp, toks, embs, wavs, frame_quantum, flow=None, prompts=None):
         for b in grp:
             wavs[b] = torch.zeros(1, 1, 2 * toks[b].numel() * self.hop, device=self.dev)
 
