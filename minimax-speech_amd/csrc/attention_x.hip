@@ -33,8 +33,11 @@ __device__ __forceinline__ void split4(const float x[4], uint2& hi, uint2& lo) {
 //              vt[plane][h*D + d][t] (plane stride 512 * ldv); tiles go from HBM to LDS as they are.  Every key / value tile
 //              is used by all query tiles of its (batch, head): splitting it once at the producer instead of once per query
 //              tile removes the conversion VALU work (and its shuffles) from this kernel's loop.
-template <int MF, bool PRE>
-__global__ __launch_bounds__(256) void attn_flash_x_kernel(
+// NW waves of 16 * MF queries each.  NW = 8, MF = 1 (two waves per SIMD): with three MFMAs per product and the hi / lo split
+// of P, one wave per SIMD runs its MFMA phase and its softmax / split VALU phase one after the other (~1500 cycles each per
+// key tile); two waves per SIMD overlap one's VALU with the other's MFMAs on the same SIMD for the same LDS footprint.
+template <int MF, bool PRE, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_flash_x_kernel(
     const void* __restrict__ q_, long ldq, long q_bs, const void* __restrict__ k_, long ldk, long k_bs,
     const void* __restrict__ v_, long ldv, long v_bs, float* __restrict__ out, long ldo, long o_bs,
     int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     char* Vh = Kl + 2 * TILE;                          // [2 bufs][TILE]   channels x keys (V^T)
     char* Vl = Vh + 2 * TILE;
     char* Ph = Vl + 2 * TILE;                          // [4 waves][QW rows x 128 B]   queries x keys
-    char* Pl = Ph + 4 * QW * 128;
+    char* Pl = Ph + NW * QW * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     if (pair >= npairs) return;
     const int qt = slot % nq;
     const int b = pair / nheads, h = pair % nheads;
-    const int qb = q_begin + qt * (4 * QW) + wave * QW;
+    const int qb = q_begin + qt * (NW * QW) + wave * QW;
     q += (long)b * q_bs + h * D;
     k += (long)b * k_bs + h * D;
     v += PRE ? (long)b * v_bs + (long)h * D * ldv : (long)b * v_bs + h * D;
@@ -67,9 +70,9 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     const float* km = keymask ? keymask + (long)b * km_bs : nullptr;
     const float sc2 = scale * 1.44269504088896341f;
     const int Tk = klen ? (klen[b] < Tn ? klen[b] : Tn) : Tn;
-    if (klen && q_begin + qt * (4 * QW) >= Tk) {        // a workgroup of pure padding rows
-        for (int id = tid; id < 4 * QW * 16; id += 256) {
-            const int i = q_begin + qt * (4 * QW) + (id >> 4);
+    if (klen && q_begin + qt * (NW * QW) >= Tk) {        // a workgroup of pure padding rows
+        for (int id = tid; id < NW * QW * 16; id += 64 * NW) {
+            const int i = q_begin + qt * (NW * QW) + (id >> 4);
             if (i < Tn) *reinterpret_cast<float4*>(out + (long)i * ldo + (id & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         return;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     }
     int kend = Tk;
     if (chunk > 0) {
-        int qlast = q_begin + qt * (4 * QW) + 4 * QW - 1;
+        int qlast = q_begin + qt * (NW * QW) + NW * QW - 1;
         if (qlast > Tn - 1) qlast = Tn - 1;
         int e = (qlast / chunk + 1) * chunk;
         if (e < kend) kend = e;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     const int ntile = (kend + KT - 1) / KT;
     int vis_all = Tk;
     if (chunk > 0) {
-        const int e = ((q_begin + qt * (4 * QW)) / chunk + 1) * chunk;
+        const int e = ((q_begin + qt * (NW * QW)) / chunk + 1) * chunk;
         if (e < vis_all) vis_all = e;
     }
     char* Pwh = Ph + wave * QW * 128;
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     //   V: chunk id -> (key 2*(id >> 5) + (id & 1), channels 4*((id >> 1) & 15) ..): ADJACENT LANES hold the two keys of a
     //      pair for the same channels; they swap halves (one shuffle pair) so each lane owns 2 channels x 2 keys and writes
     //      (key 2p, key 2p+1) as one dword of the transposed image
-    float4 kreg[4], vreg[4];
+    constexpr int NT = 64 * NW, CPT = 1024 / NT;       // threads; fp32 chunks (or 2 x bf16 chunks) per thread, tile and operand
+    float4 kreg[CPT], vreg[CPT];
     auto load_tiles = [&](int j0) {
         if constexpr (PRE) {
             // 512 chunks of 8 bf16 per plane and operand: chunk id -> (row r = id >> 3, 16-byte chunk id & 7); kreg / vreg
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
             const bf16_t* kb = reinterpret_cast<const bf16_t*>(k);
             const bf16_t* vb = reinterpret_cast<const bf16_t*>(v);
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
-                const int id = tid + pi * 256, r = id >> 3, c = (id & 7) * 8;
+            for (int pi = 0; pi < CPT / 2; ++pi) {
+                const int id = tid + pi * NT, r = id >> 3, c = (id & 7) * 8;
                 const int key = j0 + r;
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
@@ -155,8 +159,8 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * 256;
+        for (int i = 0; i < CPT; ++i) {
+            const int id = tid + i * NT;
             const int kr = j0 + (id >> 4);
             kreg[i] = kr < Tk ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(k) + (long)kr * ldk + (id & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             const int vr = j0 + 2 * (id >> 5) + (id & 1);
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     auto store_tiles = [&](int buf) {
         if constexpr (PRE) {
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
-                const int id = tid + pi * 256, r = id >> 3, c8 = id & 7;
+            for (int pi = 0; pi < CPT / 2; ++pi) {
+                const int id = tid + pi * NT, r = id >> 3, c8 = id & 7;
                 const int off = buf * TILE + swz(r, c8);
                 *reinterpret_cast<float4*>(Kh + off) = kreg[2 * pi];
                 *reinterpret_cast<float4*>(Kl + off) = kreg[2 * pi + 1];
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * 256;
+        for (int i = 0; i < CPT; ++i) {
+            const int id = tid + i * NT;
             {
                 const int r = id >> 4, c4 = id & 15;   // 4 channels = half a 16-byte chunk of bf16
                 const float x[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
@@ -345,13 +349,13 @@ __global__ __launch_bounds__(256) void attn_flash_x_kernel(
     }
 }
 
-template <int MF, bool PRE>
+template <int MF, bool PRE, int NW>
 int launch_flash_x(dim3 grid, hipStream_t stream, const void* q, long ldq, long q_bs, const void* k, long ldk, long k_bs,
                    const void* v, long ldv, long v_bs, float* out, long ldo, long o_bs, int T_, float scale,
                    const float* keymask, long km_bs, int chunk, int nq, int H, int npairs, int q_begin, const int32_t* klen) {
-    const size_t lds = (size_t)8 * 64 * 128 + (size_t)2 * 4 * 16 * MF * 128;
-    MMX_LDS_OPT_IN((attn_flash_x_kernel<MF, PRE>), lds);
-    hipLaunchKernelGGL((attn_flash_x_kernel<MF, PRE>), grid, dim3(256), lds, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_,
+    const size_t lds = (size_t)8 * 64 * 128 + (size_t)2 * NW * 16 * MF * 128;
+    MMX_LDS_OPT_IN((attn_flash_x_kernel<MF, PRE, NW>), lds);
+    hipLaunchKernelGGL((attn_flash_x_kernel<MF, PRE, NW>), grid, dim3(64 * NW), lds, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_,
                        scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
@@ -371,8 +375,8 @@ extern "C" int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const
     const bool small = (long)npairs * ((Tq + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
-    if (small) return launch_flash_x<1, false>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
-    return launch_flash_x<2, false>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    if (small) return launch_flash_x<1, false, 4>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    return launch_flash_x<1, false, 8>(grid, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
 }
 
 // The same attention on operands the producer has already split (csrc/fused.hip, split build): qk bf16 [B][T][ldqk >= 2048] =
@@ -389,6 +393,6 @@ extern "C" int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, co
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
     const bf16_t* q = (const bf16_t*)qk;
-    if (small) return launch_flash_x<1, true>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
-    return launch_flash_x<2, true>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    if (small) return launch_flash_x<1, true, 4>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+    return launch_flash_x<1, true, 8>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
 }
