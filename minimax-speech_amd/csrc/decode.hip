@@ -64,7 +64,10 @@ struct Skinny3Args {
     long ldo;
     int B, K, N, ntiles, kb_per_wg;
     float eps;
+    unsigned long long* stamps;   // measurement hook (NULL in the product path): [workgroup][wave][8] shader-clock stamps
 };
+
+#define STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // MT: 16-row tiles of the batch; TW: output tiles (EPI 1: gate/up tile pairs) per workgroup; KPW: k-blocks per wave (bound)
 template <int MT, int TW, int KPW, int EPI>
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     const int tile0 = blockIdx.x * TW;
     const int ntiles = a.ntiles;
 
+    STAMP(0);
     // every load is a buffer load with a per-lane offset of lane*16 and a scalar offset; an index outside the work of this
     // wave gets the offset OOB (returns zeros: a zero fragment adds nothing) - no branch around any load
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wp), 0, 0x7fffffff, 0x00020000);
@@ -139,6 +143,8 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
         pre_gn[k] = (EPI == 2 && a.gamma_next && ok) ? a.gamma_next[ncol] : 1.f;
         pre_res[k] = (EPI == 2 && ok) ? a.out[(long)row * a.ldo + ncol] : 0.f;
     }
+    STAMP(1);                                          // loads issued
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); }   // (measurement only) loads landed
     float4_t acc[TW][NB][MT];
 #pragma unroll
     for (int t = 0; t < TW; ++t)
@@ -171,7 +177,9 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mine[(((t * NB + n) * MT + m) * 4 + r) * 64] = acc[t][n][m][r];
     }
+    STAMP(3);                                          // MFMAs done, partials in LDS
     __syncthreads();
+    STAMP(4);
     float sum[UPW][NB];
 #pragma unroll
     for (int k = 0; k < UPW; ++k) {
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
                 *flag = old == J - 1;
             }
             __syncthreads();
+            STAMP(5);
             if (!*flag) return;
 #pragma unroll
             for (int k = 0; k < UPW; ++k) {
@@ -246,6 +255,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
             }
         }
     }
+    STAMP(6);
 }
 
 template <int MT, int TW, int KPW, int EPI>
@@ -298,7 +308,7 @@ extern "C" int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const 
 extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, const float* bias, const float* ssq_in, float eps,
                            int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
                            int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,
-                           hipStream_t stream) {
+                           void* debug_stamps, hipStream_t stream) {
     MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 && dtype == MMX_X3);
     MMX_CHECK_ARG(((uintptr_t)xs % 16) == 0 && ((uintptr_t)wp % 16) == 0 && (!ssq_in || ((uintptr_t)ssq_in % 16) == 0));
     MMX_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || (epi == 2 && part && tickets)));
@@ -311,7 +321,7 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
     // 32-bit buffer offsets: the packed weights and the planes must stay below 2 GiB
     MMX_CHECK_ARG((double)ntiles * (epi == 1 ? 2 : 1) * nkb * 1024.0 < 2147483000.0);
     Skinny3Args a{(const bf16_t*)xs, (const bf16_t*)wp, bias, ssq_in, out, (bf16_t*)xs_out, gamma_next, ssq_out, part, tickets,
-                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps};
+                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps, (unsigned long long*)debug_stamps};
 #define GO(MT, TW, KPW, EPI) return launch<MT, TW, KPW, EPI>(a, ksplit, stream)
 #define BY_MT(TW, KPW, EPI) do { if (mt == 1) GO(1, TW, KPW, EPI); else GO(2, TW, KPW, EPI); } while (0)
     if (per_wave <= 4) {

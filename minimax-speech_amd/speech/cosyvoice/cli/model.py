@@ -3,11 +3,13 @@ streaming hop schedule) and `token2wav`, with the HiFT vocoder call (model.py:31
 composition the README and the flow's training target imply.
 
 Streaming follows the reference's schedule (poll until token_hop_len + pre_lookahead tokens are available, re-run the
-flow over all tokens so far with chunk-causal masks, emit the new part).  The HiFT source / mel caches and the Hamming
-cross-fade (model.py:258-261,304-311) have no DAC equivalent and are not needed: the DAC decoder's receptive field is
-finite (16 latent frames to the left, 15 to the right for configx2.yml), so each hop decodes a window with that much
-context, emits only the frames whose right context is final and holds the last 15 frames back for the next hop.  The
-concatenated chunks equal the offline decode of the same latents (tests/test_gpu_stream.py).
+flow over all tokens so far with chunk-causal masks, emit the new part; closing pass without masks).  The HiFT source / mel
+caches (model.py:258-261,298-311) have no DAC equivalent: the DAC decoder's receptive field is finite (16 latent frames to
+the left, 15 to the right for configx2.yml), so each pass decodes a window with that much context and renders only the frames
+whose right context is final.  Where two streaming passes meet they agree, and the chunks equal the offline decode of the
+same latents; at the closing seam (the closing pass re-solves every frame) the last mel_cache_len frames are rendered by
+both passes and cross-faded with fade_in_out, as the reference does at every seam (model.py:304-311).  The rule is restated
+on the CPU in oracle/stream.py and checked against it in tests/test_gpu_stream.py.
 """
 import threading
 import time
@@ -17,6 +19,7 @@ from typing import Generator
 import numpy as np
 import torch
 
+from cosyvoice.utils.common import fade_in_out
 
 
 class CosyVoice2Model:
@@ -26,9 +29,15 @@ class CosyVoice2Model:
         self.llm, self.flow, self.hift = llm, flow, hift
         self.fp16 = fp16                                  # the HIP engines pick bf16 / fp32 themselves
         self.token_hop_len = 25                           # must match the training static_chunk_size
+        self.mel_cache_len = 8                            # model.py:258: frames two passes overlap by
         self.hop = int(np.prod(getattr(hift, "decoder_rates", [5, 4, 4, 3, 2])))   # samples per latent frame
         from mmx.dac import DacDecoderEngine
         self.dac_ctx_left, self.dac_ctx_right = DacDecoderEngine.receptive_field(getattr(hift, "decoder_rates", [5, 4, 4, 3, 2]))
+        # model.py:262 speech_window = np.hamming(2 * source_cache_len), here over mel_cache_len DAC frames and with each pair
+        # of halves scaled to sum to one (a cross-fade of two equal renderings is then the identity)
+        w = np.hamming(2 * self.mel_cache_len * self.hop)
+        n = w.shape[0] // 2
+        self.speech_window = torch.from_numpy(np.concatenate([w[:n] / (w[:n] + w[n:]), w[n:] / (w[:n] + w[n:])])).float()
         self.llm_stream = None                            # the llm_job thread launches on its own stream (mmx/flow.py rule)
         self.lock = threading.Lock()
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict = {}, {}, {}

@@ -37,6 +37,7 @@ def test_estimator_seam(engines, gold, dt):
         y = eng.estimator_channels_first(t("est_x"), mk, t("est_mu"), t("est_t"), t("est_spks"), t("est_cond"), streaming)
         ref = t(name)
         err = (y - ref).abs().max().item()
+        print(f"estimator seam {name} dtype {dt}: max abs err {err:.3e} (std {ref.std().item():.2f})")
         assert err < EST_TOL[dt], (name, dt, err)
 
 
@@ -146,6 +147,8 @@ def test_flow_inference_vs_reference_golden(engines, gold, dt):
             ref = t(name)
             assert y.shape == ref.shape, (name, y.shape, ref.shape)
             err = (y - ref).abs().max().item()
+            if rep == 0:
+                print(f"flow.inference {name} dtype {dt}: max abs err {err:.3e} (std {ref.std().item():.2f})")
             assert err < FLOW_TOL[dt], (name, dt, rep, err)
 
 

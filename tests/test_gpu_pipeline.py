@@ -174,30 +174,38 @@ def test_config5_long_form_streaming_full_size(case):
         n_out = int(eng.llm.state[2, 0])
         toks = eng.llm.out_tokens[0, :n_out].tolist()
         wav, lat = torch.cat(chunks), torch.cat(lats, 0)
-        off = eng.dac.decode_time_major(lat.to(eng.dac.tdt).reshape(1, -1, 80).contiguous(), 1, lat.shape[0])[0, 0]
+        # the streaming passes rendered frames [0, nf): their samples (all but the 8 frames held back for the closing cross-fade)
+        # must equal one offline decode of those latents wherever the offline decode has the same right context
+        ns = wav.shape[0] - chunks[-1].shape[0]
+        nf = ns // 480 + 8
+        off = eng.dac.decode_time_major(lat[:nf].to(eng.dac.tdt).reshape(1, -1, 80).contiguous(), 1, nf)[0, 0]
         CR, nh = eng.dac.ctx_right, (n_out - 3) // 25
         del eng
         torch.cuda.empty_cache()
-        return wav, lat, off, toks, CR, nh
+        return wav, lat, off, toks, CR, nh, ns
 
-    wav, lat, off, toks, CR, nh = run("bf16", True)
+    wav, lat, off, toks, CR, nh, ns = run("bf16", True)
     assert N - 20 <= len(toks) <= N and wav.shape[0] == len(toks) * 960 and lat.shape == (2 * len(toks), 80)
-    edge = (nh * 50 - CR) * 480
-    d = (wav - off).abs()
-    err = max(d[:edge - CR * 480].max().item(), d[edge:].max().item())
-    print(f"config 5 (60 s, {len(toks)} ids, {nh + 1} chunks): stream vs offline decode of the same latents {err:.3e}")
+    ncmp = ns - CR * 480
+    err = (wav[:ncmp] - off[:ncmp]).abs().max().item()
+    print(f"config 5 (60 s, {len(toks)} ids, {nh + 1} chunks): streamed samples vs offline decode of the same latents {err:.3e}")
     assert err < 2e-2 and torch.isfinite(wav).all()
-    wav_r, lat_r, _, toks_r, _, _ = run("bf16", False)
+    wav_r, lat_r, _, toks_r, _, _, _ = run("bf16", False)
     dl, dw = (lat - lat_r).abs().max().item(), (wav - wav_r).abs().max().item()
     snr_r = _snr_db(wav_r, wav)
     print(f"config 5: cached state vs prefix recompute: latents {dl:.3e}, waveform {dw:.3e}, SNR {snr_r:.1f} dB")
-    # different kernel variants (16-query hop kernels vs whole-prefix tiles) round bf16 activations differently: requirement
-    # 30 dB / 5e-2 abs, measured 38 dB / 1.9e-2 (the fp32 build agrees to 3.5e-6: tests/test_gpu_stream.py)
-    assert toks_r == toks and dw < 5e-2 and snr_r > 30.0, (dw, snr_r)
-    wav_8, _, _, toks_8, _, _ = run("fp8", True)
+    # The two schedules run different kernel variants (16-query hop kernels vs whole-prefix tiles), so every bf16 activation
+    # is rounded on a different value.  Each schedule is one bf16 evaluation of the same exact path, i.e. within the bf16
+    # build's own distance from it - BF16_MIN_SNR_DB + 10 = 35 dB measured against the oracle at config-3 size
+    # (test_composed_pipeline_bf16_bound) - and two such evaluations differ by at most the sum of their errors: 35 - 3 = 32 dB.
+    # (The fp32 and split builds agree to 2e-5: tests/test_gpu_stream.py.)
+    assert toks_r == toks and snr_r >= 32.0, (dw, snr_r)
+    wav_8, _, _, toks_8, _, _, _ = run("fp8", True)
     snr = _snr_db(wav, wav_8)
     print(f"config 5: fp8 attention vs bf16 attention: waveform SNR {snr:.1f} dB, max abs diff {(wav - wav_8).abs().max().item():.3e}")
-    assert toks_8 == toks and torch.isfinite(wav_8).all() and snr > 10.0, snr
+    # e4m3 attention operands (3-bit mantissa, 2^-4 per operand) against bf16's 2^-9 only inside the 56 x 10 attention products
+    # of the estimator: stated 45 dB (measured 53.8 dB in round 2)
+    assert toks_8 == toks and torch.isfinite(wav_8).all() and snr >= 45.0, snr
 
 
 def test_graft_entry_smoke():
