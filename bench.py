@@ -521,6 +521,34 @@ def main():
                                               "value": round(sum(lens_q) / TOKEN_RATE / (msq / 1e3), 2), "unit": "audio_s/s",
                                               "note": f"{QB} batches of the step's workload queued into one call; not the headline "
                                                       "(a step there is one batch, finished before the next starts)"}
+                # (0b) the north-star target's own workload: a batch of UNIFORM 10 s utterances (32 x 250 tokens).  All sequences
+                # finish together, so nothing of the flow / DAC stage overlaps the decode loop inside one batch (the scheduler's
+                # constants, fitted on the mixed-length batch, have nothing to decide here); with batches queued the next
+                # batch's decode runs beside this batch's flow.
+                uni = [250] * len(lens)
+                fu = lambda: eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=uni)
+                msu = _time_steps(fu, build=2, warmup=0, steps=2)
+                uni_q = uni * QB
+                fuq = lambda: eng.tts_batch(texts_q, [emb] * len(texts_q), seed=0, exact_steps=uni_q)
+                msuq = _time_steps(fuq, build=2, warmup=0, steps=2)
+                out["uniform_10s"] = {"workload": f"{len(uni)} utterances of exactly 250 tokens (10 s) per step", "ms_per_step": round(msu, 1),
+                                      "value": round(sum(uni) / TOKEN_RATE / (msu / 1e3), 2), "unit": "audio_s/s",
+                                      "rtf_per_utterance": round(msu / 1e3 / 10.0, 5),
+                                      "queued": {"utterances_per_call": len(uni_q), "ms_per_call": round(msuq, 1),
+                                                 "value": round(sum(uni_q) / TOKEN_RATE / (msuq / 1e3), 2)}}
+                # (0c) zero-shot synthesis (the reference's main entry, cli/cosyvoice.py:92-104): the step's workload with a 3 s
+                # prompt per utterance - 8 prompt text ids + 75 prompt speech tokens in front of the LM input, 75 prompt tokens
+                # + 150 prompt latent frames through the flow (their frames are solved and dropped, flow.py:472-509)
+                gz = torch.Generator().manual_seed(9)
+                zs = dict(prompt_texts=[torch.randint(0, 151936, (1, 8), generator=gz).to(dev) for _ in lens],
+                          llm_prompt_speech_tokens=[torch.randint(0, 6561, (1, 75), generator=gz).to(dev) for _ in lens],
+                          flow_prompt_speech_tokens=[torch.randint(0, 6561, (1, 75), generator=gz).to(dev) for _ in lens],
+                          prompt_speech_feats=[(torch.randn(1, 150, 80, generator=gz) * 0.5).to(dev) for _ in lens])
+                fz = lambda: eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, **zs)
+                msz = _time_steps(fz, build=2, warmup=0, steps=2)
+                out["zero_shot"] = {"workload": "the step's 32 utterances, each with a 3 s prompt (8 text ids + 75 speech tokens to the LM, 75 "
+                                                "tokens + 150 latent frames to the flow)", "ms_per_step": round(msz, 1),
+                                    "value": round(sum(lens) / TOKEN_RATE / (msz / 1e3), 2), "unit": "audio_s/s (generated audio only)"}
                 del eng
                 torch.cuda.empty_cache()
                 w3 = build_weights(0)

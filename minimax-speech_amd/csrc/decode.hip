@@ -72,6 +72,7 @@ struct Skinny3Args {
 // MT: 16-row tiles of the batch; TW: output tiles (EPI 1: gate/up tile pairs) per workgroup; KPW: k-blocks per wave (bound)
 template <int MT, int TW, int KPW, int EPI>
 __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();      // (used by the measurement hook only)
     constexpr int NS = 3, NB = EPI == 1 ? 2 : 1;
     constexpr int PER = TW * NB * MT * 4;              // floats per lane a wave hands to the reduction
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     const int ntiles = a.ntiles;
 
     STAMP(0);
+    if (a.stamps && lane == 0) a.stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + 7] = t_entry;
     // every load is a buffer load with a per-lane offset of lane*16 and a scalar offset; an index outside the work of this
     // wave gets the offset OOB (returns zeros: a zero fragment adds nothing) - no branch around any load
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wp), 0, 0x7fffffff, 0x00020000);

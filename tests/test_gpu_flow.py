@@ -11,7 +11,10 @@ SEED = 7
 # fp32 build: exact-fp32 MFMA, only summation order differs.  bf16 build: bf16 weights/GEMM inputs through 70
 # blocks x 10 Euler steps; the bound is what this test measures and pins, relative to outputs of std ~1.2.
 EST_TOL = {0: 2e-4, 1: 6e-2}
-FLOW_TOL = {0: 1e-3, 1: 2.5e-1}
+# flow.inference = 10 Euler steps of the estimator with classifier-free guidance: x += dt * ((1 + cfg) d_cond - cfg d_uncond),
+# sum dt = 1, cfg = 0.7, so an estimator error e per call gives at most (1 + 2 cfg) e = 2.4 e on the latents:
+# bf16 2.4 x EST_TOL = 0.144 (measured 1.5e-2), fp32 2.4 x 2e-4 = 4.8e-4
+FLOW_TOL = {0: 4.8e-4, 1: 1.44e-1}
 
 
 @pytest.fixture(scope="module")

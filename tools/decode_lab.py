@@ -65,15 +65,20 @@ def main():
         run(L - 1, stamps)
         torch.cuda.synchronize()
         st = stamps.cpu().reshape(nwg, 8, 8).double()
-        t0 = st[:, :, 0][st[:, :, 0] > 0].min()
-        names = ["start", "loads issued", "loads landed", "mfma done", "after barrier", "ticket", "end"]
+        # stamps are per-XCD counters: only differences inside one wave mean anything.  Slot 7 = kernel entry of the wave.
+        order = [(7, "entry"), (0, "arguments in, indices computed"), (1, "loads issued"), (2, "loads landed"), (3, "mfma done, partials in LDS"),
+                 (4, "after the barrier"), (5, "ticket taken"), (6, "end")]
         print(f"{name}: K={K} N={N} epi={epi} tw={tw} J={J}: {nwg} workgroups, {us:.2f} us per launch (hipGraph, back to back)")
-        for i, nm in enumerate(names):
-            v = st[:, :, i]
-            ok = v > 0
-            if ok.any():
-                d = (v[ok] - t0)
-                print(f"    {nm:14s} min {d.min():9.0f}  median {d.median():9.0f}  max {d.max():9.0f}  ticks")
+        prev = 7
+        for slot, nm in order[1:]:
+            v, p0 = st[:, :, slot], st[:, :, prev]
+            ok = (v > 0) & (p0 > 0)
+            if not ok.any():
+                continue
+            d = (v - p0)[ok]
+            tot = (v - st[:, :, 7])[ok]
+            print(f"    {nm:32s} +{d.median():7.0f} ticks (median; max +{d.max():7.0f})   since entry: median {tot.median():7.0f} max {tot.max():7.0f}")
+            prev = slot
     # floor of a dependent chain of trivial launches
     y = torch.zeros(B, H, device=dev)
     gr = torch.cuda.CUDAGraph()
