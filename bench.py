@@ -35,53 +35,25 @@ def build_weights(seed=0):
 
 
 def measure_lm_kernel(eng, iters=240):
-    """Roofline of the LM decode's dominant kernel: the weight-streaming GEMM of the LM decode (skinny_gemm_kernel),
-    gate/up projection + SwiGLU instance (the largest of the 4 per layer), at the batch size of the workload.
-    Timed live with HIP events on the stream the kernel is launched on, rotating over the 24 layers' weights so
-    the 256 MiB Infinity Cache cannot serve the stream.  Algorithmic bytes per launch (bf16 weights
-    are the traffic of a decode step) = the packed bf16 weight matrix 2 x 4864 x 896 x 2 B + the activation rows in
-    and out.  `traffic` = HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-    collected in separate passes with tools/pmc_skinny.py and committed as profiles/r01_pmc_skinny.json."""
+    """Roofline of the LM decode step's largest projection: gate/up + SwiGLU (17.4 MB of the 727.6 MB of weights a step
+    streams) on the decode-step projection kernel (csrc/decode.hip: skinny3_kernel) at the workload's batch size.
+    Timed live with HIP events on the stream the kernel is launched on, a hipGraph of `iters` launches rotating over the 24
+    layers' weights so that the 256 MiB Infinity Cache cannot serve the stream.  Algorithmic bytes per launch (SURVEY.md 8d:
+    bf16 weights are the traffic of a decode step) = the packed bf16 weight matrix 2 x 4864 x 896 x 2 B + the activation
+    planes in and out."""
     from mmx import ops
     llm = eng.llm
     B, H, I = llm.B, llm.H, llm.I
-    pk = llm.packed                              # the activation layout the decode step uses at this batch size
-    x = torch.randn(B, H, device=llm.dev).to(llm.tdt)
-    if pk:
-        x = ops.pack_act(x, llm.dtype)
-    act = torch.empty(ops.packed_rows(B), I, dtype=llm.tdt, device=llm.dev)
-    esz = 2 if llm.dtype == 1 else 4
-    nbytes = 2 * I * H * esz + B * H * esz + B * I * esz
-    s = torch.cuda.current_stream()
-    run = lambda l: ops.skinny_gemm(x, llm.layers[l]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, rs=True, eps=llm.eps, epi=1, out_act=act,
-                                    x_packed=pk, out_packed=pk)
-    for l in range(llm.n_layers):
-        run(l)
-    g = torch.cuda.CUDAGraph()                  # same launch mechanism as the decode step (hipGraph replay)
-    torch.cuda.synchronize()
-    gc.collect()                                # no cyclic collection inside a capture (mmx/flow.py: Graphed)
-    gc.disable()
-    try:
-        with torch.cuda.graph(g):
-            for i in range(iters):
-                run(i % llm.n_layers)
-    finally:
-        gc.enable()
-    g.replay()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(torch.cuda.current_stream())
-    g.replay()
-    e1.record(torch.cuda.current_stream())
-    e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
+    S = llm._planes()
+    ns = S["xs_b"].shape[0]
+    nbytes = 2 * I * H * 2 + ns * (B * H + B * I) * 2
+    run = lambda l: ops.skinny2(S["xs_b"], llm.layers[l % llm.n_layers]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, ssq_in=S["ssq_b"],
+                                eps=llm.eps, epi=1, xs_out=S["xs_act"], tiles_per_wg=llm.v2_cfg["gu"][0])
+    us = _event_time_graph(run, iters)
     achieved = nbytes / (us * 1e-6) / 1e9
-    traffic = None
-    pj = os.path.join(ROOT, "profiles", "r01_pmc_skinny.json")
-    if os.path.exists(pj) and B in (1, 32):
-        traffic = json.load(open(pj)).get("hbm_bytes_per_launch" if B == 1 else "batch32_hbm_bytes_per_launch")
-    return {"bound": "hbm", "kernel": f"skinny_gemm_kernel (LM gate/up + SwiGLU, K=896, N=2x4864, batch {B})",
+    return {"bound": "hbm", "kernel": f"skinny3_kernel (LM gate/up + SwiGLU, K=896, N=2x4864, batch {B}, {ns} activation plane(s))",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
+            "traffic": None, "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
 
 
 def measure_lm_step(eng, ctx=300, iters=96):
@@ -120,7 +92,7 @@ def measure_lm_step(eng, ctx=300, iters=96):
 def _event_time_graph(fn, iters):
     """Average duration (us) of `fn`'s launches: recorded `iters` times into one hipGraph (the launch mechanism of the
     pipeline), replayed once untimed and once between two HIP events on the launch stream."""
-    fn()
+    fn(0)
     g = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
     gc.collect()
@@ -498,10 +470,16 @@ def main():
         out["collective"] = {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None)}
         if world == 1 and a.workload == "batch":
             out["roofline_lm_step"] = measure_lm_step(eng)
-        if world == 1 and dt != 2:
+        if world == 1 and dt != 0:
             out["roofline_lm"] = measure_lm_kernel(eng)
-            out["roofline"] = measure_flow_kernel(eng, shape_log, a.steps) if (dt == 1 and a.workload == "batch" and shape_log) else out.get("roofline_lm", out.get("roofline_lm_step"))
+        if world == 1:
+            # `roofline`: the LM decode step as a whole - its projection family is the largest share of the step's GPU time
+            # (profiles/r03_bench_kernel_stats.csv) and the decode loop is the step's critical path; the other objects are the
+            # largest single projection (roofline_lm) and, for the bf16 build, the two flow kernels (roofline_flow / _attn)
+            out["roofline"] = out.get("roofline_lm_step") or out.get("roofline_lm")
+        if world == 1 and dt != 2:
             if dt == 1 and a.workload == "batch" and shape_log:
+                out["roofline_flow"] = measure_flow_kernel(eng, shape_log, a.steps)
                 out["roofline_attn"] = measure_attn_kernel(eng, shape_log, a.steps)
             if a.workload == "batch" and not a.no_extras:
                 # extra keys, measured after the timed region: (1) BASELINE config 3 (one 10 s utterance) for the

@@ -218,7 +218,8 @@ int mmx_conv_cout1_tanh(const void* act, int64_t a_bs, int T, int C, int k, cons
  *   Pays at batch > 8, where every workgroup re-reads the whole activation matrix from L2.
  *   dtype MMX_X2 / MMX_X3 (split build): x fp32 row-major (flags 0), Wp the bf16 pack made WITHOUT kscale, kgamma [K] fp32
  *   (or NULL) = the RMSNorm gain applied to x before the split, results to out_f32 only (epi 1 writes silu(g)*u there).
- *   kgamma must be NULL for the other dtypes.
+ *   MMX_BF16 with fp32 x (flags 0) also takes kgamma (epi 0 / 1): the gain is applied to x before it is rounded to bf16, Wp
+ *   packed without kscale (the form the bf16 build's prompt chunks use, its decode step running on mmx_skinny2).
  */
 #define MMX_X_PACKED 1
 #define MMX_OUT_PACKED 2
@@ -228,7 +229,8 @@ int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N
                     const float* bias, int rs, float eps, int epi, float* out_f32, int64_t ldo_f,
                     void* out_act, int64_t ldo_a, int dtype, int flags, const float* kgamma, hipStream_t stream);
 
-/* Decode-step projections of the split build (dtype MMX_X3), B <= 32 sequences, on SPLIT-PLANE activations:
+/* Decode-step projections, B <= 32 sequences, on SPLIT-PLANE activations (dtype MMX_X3: 3 planes as below; dtype MMX_BF16:
+ * ONE plane = bf16(x), which is the packed A-fragment order of MMX_X_PACKED):
  *   an activation x [B][K] (already multiplied by the RMSNorm gain of its consumer) is stored as 3 bf16 planes
  *   hi + mid + lo = x, each in MFMA A-fragment order:
  *     xs[plane s][m][kb][lane = g*16 + l16][j] = term s of x[m*16 + l16][kb*32 + g*8 + j]      (ceil(B/16) row tiles m)
@@ -255,7 +257,7 @@ int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N
  *   Replace the q/k/v, o, gate/up (+SiLU*up), down projections and the llm_decoder head of one decode step
  *   (speech/cosyvoice/llm/llm.py:359-371,749; HF Qwen2 MLP / attention projections / RMSNorm). */
 int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const float* gamma, float* h, int64_t ldh, void* xs,
-                    float* ssq, hipStream_t stream);
+                    float* ssq, int dtype, hipStream_t stream);
 int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, const float* bias, const float* ssq_in, float eps,
                 int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
                 int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,

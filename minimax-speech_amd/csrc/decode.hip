@@ -1,4 +1,4 @@
-// Decode-step projections of the split build (MMX_X3) for B <= 32 sequences: out = epilogue( rstd * (xs W^T) ), bf16 weights
+// Decode-step projections for B <= 32 sequences (split build MMX_X3: NS = 3 planes; bf16 build: NS = 1 plane): out = epilogue( rstd * (xs W^T) ), bf16 weights
 // in MFMA-fragment order (mmx_pack_skinny, no kscale), activations as PRE-SPLIT bf16 planes.  Replaces, per decode step and
 // layer, the q/k/v, o, gate/up (+ SwiGLU) and down projections of HF Qwen2 as driven by
 // speech/cosyvoice/llm/llm.py:359-371,745-760, and the llm_decoder head (llm.py:749).
@@ -40,14 +40,15 @@ constexpr int SSQ_SLOTS = 64;                          // tile slots per row of 
 __device__ __forceinline__ int plane_index(int row, int col, int nkb) {
     return (((((row >> 4) * nkb + (col >> 5)) << 6) + (((col & 31) >> 3) << 4) + (row & 15)) << 3) + (col & 7);
 }
-// v -> 3 bf16 terms at `idx` of planes that are `ps` elements apart
-__device__ __forceinline__ void store_split3(bf16_t* planes, int ps, int idx, float v) {
-    const bf16_t h = f2bf(v);
-    const float r1 = v - bf2f(h);
-    const bf16_t m = f2bf(r1);
-    planes[idx] = h;
-    planes[ps + idx] = m;
-    planes[2 * ps + idx] = f2bf(r1 - bf2f(m));
+// v -> NS bf16 terms (NS = 3: hi + mid + lo = v; NS = 1, the bf16 build: bf16(v)) at `idx` of planes `ps` elements apart
+template <int NS>
+__device__ __forceinline__ void store_split(bf16_t* planes, int ps, int idx, float v) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bf16_t h = f2bf(v);
+        planes[s * ps + idx] = h;
+        v -= bf2f(h);
+    }
 }
 
 struct Skinny3Args {
@@ -70,10 +71,10 @@ struct Skinny3Args {
 #define STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // MT: 16-row tiles of the batch; TW: output tiles (EPI 1: gate/up tile pairs) per workgroup; KPW: k-blocks per wave (bound)
-template <int MT, int TW, int KPW, int EPI>
+template <int MT, int TW, int KPW, int EPI, int NS>
 __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();      // (used by the measurement hook only)
-    constexpr int NS = 3, NB = EPI == 1 ? 2 : 1;
+    constexpr int NB = EPI == 1 ? 2 : 1;
     constexpr int PER = TW * NB * MT * 4;              // floats per lane a wave hands to the reduction
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);       // [8 waves][PER][64 lanes]
@@ -218,12 +219,24 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
             __syncthreads();
             STAMP(5);
             if (!*flag) return;
+            // all J x UPW partial loads in flight before the first add (summed one by one behind a wait each, the last
+            // arriver's epilogue was the longest phase of the kernel: 4.8 us of the down projection's 12.7)
+            constexpr int JMAX = 8;
+            float pv[UPW][JMAX];
+#pragma unroll
+            for (int k = 0; k < UPW; ++k)
+#pragma unroll
+                for (int j2 = 0; j2 < JMAX; ++j2) {
+                    // clamped indices instead of predicated loads: no branch sits between two loads
+                    const int u = min(wave + 8 * k, UNITS - 1), jc = min(j2, J - 1);
+                    const float v = ld_sc1(a.part + ((jc * gridDim.x + blockIdx.x) * UNITS + u) * 64 + lane);
+                    pv[k][j2] = j2 < J ? v : 0.f;
+                }
 #pragma unroll
             for (int k = 0; k < UPW; ++k) {
-                const int u = wave + 8 * k;
                 float v = 0.f;
-                if (u < UNITS)
-                    for (int j2 = 0; j2 < J; ++j2) v += ld_sc1(a.part + ((j2 * gridDim.x + blockIdx.x) * UNITS + u) * 64 + lane);
+#pragma unroll
+                for (int j2 = 0; j2 < JMAX; ++j2) v += pv[k][j2];            // slice order
                 sum[k][0] = v;
             }
         }
@@ -239,13 +252,13 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
         const bool ok = tile < ntiles && row < a.B && ncol < a.N;
         if constexpr (EPI == 1) {
             const float gte = sum[k][0] * sc, up = sum[k][1] * sc;
-            if (ok) store_split3(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), gte / (1.f + expf(-gte)) * up);
+            if (ok) store_split<NS>(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), gte / (1.f + expf(-gte)) * up);
         } else {
             float vv = sum[k][0] * sc + pre_bias[k];
             if constexpr (EPI == 2) vv += pre_res[k];
             if (ok) a.out[(long)row * a.ldo + ncol] = vv;
             if constexpr (EPI == 2) {
-                if (ok && a.xs_out) store_split3(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), vv * pre_gn[k]);
+                if (ok && a.xs_out) store_split<NS>(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), vv * pre_gn[k]);
                 if (a.ssq_out) {                       // this tile's share of the row's sum of squares: over its 16 columns
                     float q = ok ? vv * vv : 0.f;
                     q += __shfl_xor(q, 1, 64);
@@ -260,19 +273,20 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     STAMP(6);
 }
 
-template <int MT, int TW, int KPW, int EPI>
+template <int MT, int TW, int KPW, int EPI, int NS>
 int launch(const Skinny3Args& a, int J, hipStream_t s) {
     constexpr int NB = EPI == 1 ? 2 : 1;
     const size_t lds = (size_t)8 * (TW * NB * MT * 4) * 64 * sizeof(float) + 32 * sizeof(float) + 16;
-    MMX_LDS_OPT_IN((skinny3_kernel<MT, TW, KPW, EPI>), lds);
+    MMX_LDS_OPT_IN((skinny3_kernel<MT, TW, KPW, EPI, NS>), lds);
     dim3 grid((a.ntiles + TW - 1) / TW, J);
-    hipLaunchKernelGGL((skinny3_kernel<MT, TW, KPW, EPI>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((skinny3_kernel<MT, TW, KPW, EPI, NS>), grid, dim3(512), lds, s, a);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
 
 // x fp32 [B][K] -> residual stream copy h, planes of (x * gamma) and the per-tile sums of squares of x: the form in which
 // the first projection of a decode step wants the sampler's output (the next input embedding)
+template <int NS>
 __global__ __launch_bounds__(256) void decode_prep_kernel(const float* __restrict__ x, long ldx, int B, int K, const float* __restrict__ gamma,
                                                           float* __restrict__ h, long ldh, bf16_t* __restrict__ xs, int mt,
                                                           float* __restrict__ ssq) {
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256) void decode_prep_kernel(const float* __restric
         if (col < K) {
             v = x[(long)row * ldx + col];
             if (h) h[(long)row * ldh + col] = v;
-            store_split3(xs, ps, plane_index(row, col, nkb), v * (gamma ? gamma[col] : 1.f));
+            store_split<NS>(xs, ps, plane_index(row, col, nkb), v * (gamma ? gamma[col] : 1.f));
         }
         float q = v * v;
         q += __shfl_xor(q, 1, 64);
@@ -298,9 +312,10 @@ __global__ __launch_bounds__(256) void decode_prep_kernel(const float* __restric
 }  // namespace
 
 extern "C" int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const float* gamma, float* h, int64_t ldh, void* xs,
-                               float* ssq, hipStream_t stream) {
-    MMX_CHECK_ARG(x && xs && ssq && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && K <= SSQ_SLOTS * 16);
-    hipLaunchKernelGGL(decode_prep_kernel, dim3(B), dim3(256), 0, stream, x, ldx, B, K, gamma, h, ldh, (bf16_t*)xs, (B + 15) / 16, ssq);
+                               float* ssq, int dtype, hipStream_t stream) {
+    MMX_CHECK_ARG(x && xs && ssq && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && K <= SSQ_SLOTS * 16 && (dtype == MMX_X3 || dtype == MMX_BF16));
+    if (dtype == MMX_X3) hipLaunchKernelGGL(decode_prep_kernel<3>, dim3(B), dim3(256), 0, stream, x, ldx, B, K, gamma, h, ldh, (bf16_t*)xs, (B + 15) / 16, ssq);
+    else hipLaunchKernelGGL(decode_prep_kernel<1>, dim3(B), dim3(256), 0, stream, x, ldx, B, K, gamma, h, ldh, (bf16_t*)xs, (B + 15) / 16, ssq);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
@@ -311,9 +326,9 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
                            int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
                            int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,
                            void* debug_stamps, hipStream_t stream) {
-    MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 && dtype == MMX_X3);
+    MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 && (dtype == MMX_X3 || dtype == MMX_BF16));
     MMX_CHECK_ARG(((uintptr_t)xs % 16) == 0 && ((uintptr_t)wp % 16) == 0 && (!ssq_in || ((uintptr_t)ssq_in % 16) == 0));
-    MMX_CHECK_ARG(ksplit >= 1 && (ksplit == 1 || (epi == 2 && part && tickets)));
+    MMX_CHECK_ARG(ksplit >= 1 && ksplit <= 8 && (ksplit == 1 || (epi == 2 && part && tickets)));
     MMX_CHECK_ARG(epi == 1 ? (xs_out != nullptr && N % 32 == 0) : out != nullptr);
     MMX_CHECK_ARG(epi != 2 || !xs_out || N % 32 == 0);
     MMX_CHECK_ARG(epi != 2 || !ssq_out || (N + 15) / 16 <= SSQ_SLOTS);
@@ -324,7 +339,7 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
     MMX_CHECK_ARG((double)ntiles * (epi == 1 ? 2 : 1) * nkb * 1024.0 < 2147483000.0);
     Skinny3Args a{(const bf16_t*)xs, (const bf16_t*)wp, bias, ssq_in, out, (bf16_t*)xs_out, gamma_next, ssq_out, part, tickets,
                   ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps, (unsigned long long*)debug_stamps};
-#define GO(MT, TW, KPW, EPI) return launch<MT, TW, KPW, EPI>(a, ksplit, stream)
+#define GO(MT, TW, KPW, EPI) do { if (dtype == MMX_X3) return launch<MT, TW, KPW, EPI, 3>(a, ksplit, stream); return launch<MT, TW, KPW, EPI, 1>(a, ksplit, stream); } while (0)
 #define BY_MT(TW, KPW, EPI) do { if (mt == 1) GO(1, TW, KPW, EPI); else GO(2, TW, KPW, EPI); } while (0)
     if (per_wave <= 4) {
         if (epi == 0) { if (tiles_per_wg == 1) BY_MT(1, 4, 0); if (tiles_per_wg == 2) BY_MT(2, 4, 0); }

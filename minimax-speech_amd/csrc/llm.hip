@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const TX* __restrict__
 #pragma unroll
                         for (int e = 0; e < E; ++e) ssq[m] += xv[e] * xv[e];
                     }
-                    if constexpr (NS > 1) {
+                    if constexpr (NS > 1 || (BF && sizeof(TX) == 4)) {         // fp32 activations: gain, then NS bf16 terms
                         if (kgamma) {
                             const float4 g0 = *reinterpret_cast<const float4*>(kgamma + (kc + i) * KB + g * E);
                             const float4 g1 = *reinterpret_cast<const float4*>(kgamma + (kc + i) * KB + g * E + 4);
@@ -387,7 +387,14 @@ extern "C" int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, i
         return dtype == MMX_X2 ? skinny_launch_split<2>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, stream, kgamma)
                                : skinny_launch_split<3>(epi, x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, stream, kgamma);
     }
-    MMX_CHECK_ARG(!kgamma);                            // the other builds fold the RMSNorm gain into the packed weights
+    if (kgamma) {
+        // bf16 build with the gain applied to fp32 activations in the kernel (weights packed WITHOUT kscale: the decode step
+        // of that build runs on csrc/decode.hip, whose producers apply the gain; this kernel serves its prompt chunks)
+        MMX_CHECK_ARG(dtype == MMX_BF16 && x_dtype == MMX_F32 && flags == 0 && ((uintptr_t)kgamma % 16) == 0 && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0);
+        if (epi == 0) return skinny_launch_mt<bf16_t, float, 0, false, false, 1>(x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream, kgamma);
+        if (epi == 1) return skinny_launch_mt<bf16_t, float, 1, false, false, 1>(x, ldx, B, K, N, wp, bias, rs, eps, out_f32, ldo_f, out_act, ldo_a, stream, kgamma);
+        return MMX_EARG;
+    }
     MMX_CHECK_ARG((flags == 0 || flags == MMX_X_PACKED || flags == (MMX_X_PACKED | MMX_OUT_PACKED)) && (flags == 0 || x_dtype == dtype) &&
                   (!(flags & MMX_OUT_PACKED) || N % 32 == 0));
     MMX_CHECK_ARG(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wp % 16) == 0);

@@ -51,7 +51,7 @@ class LlmEngine:
     # decode attention: batches of at least this many sequences use the GQA-shared kernel (one workgroup per kv head serving
     # its 7 query heads), smaller ones the per-head kernel (more workgroups for the few sequences there are)
     gqa_min_batch = 1 << 30
-    use_v2 = True            # split build: decode-step projections on csrc/decode.hip (False: the round-2 kernel with NS terms)
+    use_v2 = True            # bf16 / split builds: decode step on csrc/decode.hip (False: the round-2 projection kernel)
 
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
@@ -68,7 +68,7 @@ class LlmEngine:
             # (used to continue a partly finished batch at a smaller, cheaper batch size: see compact_from)
             o = share_from
             for k in ("n_layers", "H", "I", "layers", "wdec", "bdec", "embed_tokens", "speech_emb", "llm_emb", "inv_freq",
-                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page", "pf_layers", "norm_w", "pages"):
+                      "rope_tab", "kc", "vc", "max_pages", "max_out", "trash_page", "pf_layers", "norm_w", "pages", "unfolded"):
                 setattr(self, k, getattr(o, k))
             self.B = max_batch
             self.block_table = torch.full((self.B, self.max_pages), self.trash_page, dtype=torch.int32, device=self.dev)
@@ -77,7 +77,11 @@ class LlmEngine:
             return
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         c = lambda t: t.to(WEIGHT_DT[dtype]).contiguous()
-        ks = (lambda g: None) if self.split else (lambda g: g)   # split build: the gain stays out of the (exact bf16) weights
+        # The RMSNorm gain is folded into the packed weights only in the fp32 build.  The bf16 and split builds keep the
+        # checkpoint's bf16 weights as they are and apply the gain to the activations: in the producer's epilogue on the
+        # decode step (csrc/decode.hip), in the kernel for prompt chunks (kgamma).
+        self.unfolded = dtype != F32
+        ks = (lambda g: None) if self.unfolded else (lambda g: g)
         self.n_layers = len({k.split(".")[4] for k in sd if k.startswith(prefix + ".layers.")})
         self.H = sd[prefix + ".norm.weight"].shape[0]
         self.I = sd[prefix + ".layers.0.mlp.gate_proj.weight"].shape[0]
@@ -142,7 +146,7 @@ class LlmEngine:
         self.h = torch.zeros(B, self.H, device=self.dev)            # residual stream of the step
         # its compute-dtype copy; at batch > 8 the decode step keeps it (and every other GEMM input) in the packed
         # MFMA-fragment order of include/mmx_hip.h (whole 16-row tiles)
-        self.packed = B >= 4 and not self.split
+        self.packed = B >= 4 and not self.unfolded
         self.h_act = torch.zeros(ops.packed_rows(B), self.H, dtype=self.tdt, device=self.dev)
         self.logits = torch.zeros(B, self.V, device=self.dev)
         self.logp = torch.zeros(B, self.V, device=self.dev)
@@ -170,10 +174,11 @@ class LlmEngine:
         att = torch.empty(nr, self.Hq * self.D, dtype=self.tdt, device=self.dev)
         act = torch.empty(nr, I, dtype=self.tdt, device=self.dev)
         pk = packed
+        kg = (lambda g: g) if self.unfolded else (lambda g: None)     # bf16 build: gain applied to the fp32 residual stream in-kernel
         for l, w in enumerate(self.layers):
-            first = packed and l == 0
+            first = (packed and l == 0) or self.unfolded
             ops.skinny_gemm(h if first else ha, w["wqkv"], B=n, K=H, N=qkv.shape[1], dtype=dt, bias=w["bqkv"], rs=True,
-                            eps=self.eps, epi=0, out_f32=qkv, x_packed=pk and not first)
+                            eps=self.eps, epi=0, out_f32=qkv, x_packed=pk and not first, kgamma=kg(w["g1"]))
             if rows == 1:
                 ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, att, B=B, Hq=self.Hq,
                                 Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, out_packed=pk,
@@ -185,8 +190,8 @@ class LlmEngine:
                                Hkv=self.Hkv, page=self.page, dtype=dt)
             ops.skinny_gemm(att, w["wo"], B=n, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha,
                             x_packed=pk, out_packed=pk)
-            ops.skinny_gemm(ha, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act,
-                            x_packed=pk, out_packed=pk)
+            ops.skinny_gemm(h if self.unfolded else ha, w["wgu"], B=n, K=H, N=I, dtype=dt, rs=True, eps=self.eps, epi=1, out_act=act,
+                            x_packed=pk, out_packed=pk, kgamma=kg(w["g2"]))
             ops.skinny_gemm(act, w["wdown"], B=n, K=I, N=H, dtype=dt, epi=2, out_f32=h, out_act=ha,
                             x_packed=pk, out_packed=pk)
 
@@ -199,7 +204,7 @@ class LlmEngine:
         if not hasattr(self, "_v2"):
             H, I, R = self.H, self.I, ops.packed_rows(self.B)
             NQ = (self.Hq + 2 * self.Hkv) * self.D
-            bf = lambda K: torch.zeros(3, R * K, dtype=torch.bfloat16, device=self.dev)
+            bf = lambda K: torch.zeros(3 if self.split else 1, R * K, dtype=torch.bfloat16, device=self.dev)
             J = self.v2_cfg["down"][1]
             self._v2 = dict(qkv=torch.empty(self.B, NQ, device=self.dev), xs_a=bf(H), xs_b=bf(H), xs_att=bf(self.Hq * self.D), xs_act=bf(I),
                             ssq_a=torch.zeros(32, ops.SSQ_SLOTS, device=self.dev), ssq_b=torch.zeros(32, ops.SSQ_SLOTS, device=self.dev),
@@ -215,13 +220,15 @@ class LlmEngine:
         dt, H, I, c, S = self.dtype, self.H, self.I, self.v2_cfg, self._planes()
         NQ = (self.Hq + 2 * self.Hkv) * self.D
         qkv = S["qkv"][:B]
-        ops.decode_prep(x_in, S["xs_a"], S["ssq_a"], B=B, K=H, gamma=self.layers[0]["g1"], h=h)
+        ops.decode_prep(x_in, S["xs_a"], S["ssq_a"], B=B, K=H, gamma=self.layers[0]["g1"], h=h, dtype=dt)
         for l, w in enumerate(self.layers):
             g_next = self.layers[l + 1]["g1"] if l + 1 < len(self.layers) else self.norm_w
             ops.skinny2(S["xs_a"], w["wqkv"], B=B, K=H, N=NQ, dtype=dt, bias=w["bqkv"], ssq_in=S["ssq_a"], eps=self.eps, epi=0, out=qkv,
                         tiles_per_wg=c["qkv"][0])
+            # (bf16 build: one plane = the packed A-fragment order the attention kernels already write)
             ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, S["xs_att"], B=B, Hq=self.Hq,
-                            Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, per_head=True, out_split=True)
+                            Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, per_head=(self.split or B < self.gqa_min_batch),
+                            out_split=self.split, out_packed=not self.split)
             ops.skinny2(S["xs_att"], w["wo"], B=B, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out=h, xs_out=S["xs_b"],
                         gamma_next=w["g2"], ssq_out=S["ssq_b"], tiles_per_wg=c["o"][0])
             ops.skinny2(S["xs_b"], w["wgu"], B=B, K=H, N=I, dtype=dt, ssq_in=S["ssq_b"], eps=self.eps, epi=1, xs_out=S["xs_act"],
@@ -257,13 +264,13 @@ class LlmEngine:
         """final RMSNorm (folded) + llm_decoder + log_softmax + sampler + loop bookkeeping for all B sequences.
         planes_ready (split build): xs_a / ssq_a already hold the planes of h * norm_w (the decode step's last projection
         wrote them); otherwise they are made from self.h first."""
-        if self.split and B <= 32 and self.use_v2:
+        if self.unfolded and B <= 32 and self.use_v2:
             S = self._planes()
             if not planes_ready:
-                ops.decode_prep(self.h, S["xs_a"], S["ssq_a"], B=B, K=self.H, gamma=self.norm_w)
+                ops.decode_prep(self.h, S["xs_a"], S["ssq_a"], B=B, K=self.H, gamma=self.norm_w, dtype=self.dtype)
             ops.skinny2(S["xs_a"], self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, ssq_in=S["ssq_a"],
                         eps=self.eps, epi=0, out=self.logits, tiles_per_wg=self.v2_cfg["head"][0])
-        elif self.split:
+        elif self.unfolded:
             ops.skinny_gemm(self.h, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
                             eps=self.eps, epi=0, out_f32=self.logits, kgamma=self.norm_w)
         else:
@@ -276,7 +283,7 @@ class LlmEngine:
 
     def _decode_step(self):
         B = self.B
-        if self.split and B <= 32 and self.use_v2:
+        if self.unfolded and B <= 32 and self.use_v2:
             self._layers_split_decode(self.x_in, self.h, B, self.state[ST_POS], self.block_table)
             return self._tail(B, planes_ready=True)
         self.h.copy_(self.x_in)

@@ -310,9 +310,9 @@ def merge_planes(xs, B, K):
     return sum(unpack_act(xs[s], B, K, BF16).float() for s in range(3))
 
 
-def decode_prep(x, xs, ssq, *, B, K, gamma=None, h=None):
+def decode_prep(x, xs, ssq, *, B, K, gamma=None, h=None, dtype=L.X3):
     check(load().mmx_decode_prep(_p(x), i64(x.shape[-1]), B, K, _p(gamma), _p(h), i64(h.shape[-1] if h is not None else 0), _p(xs),
-                                 _p(ssq), stream()), "mmx_decode_prep")
+                                 _p(ssq), dtype, stream()), "mmx_decode_prep")
 
 
 def skinny2(xs, wp, *, B, K, N, dtype, bias=None, ssq_in=None, eps=1e-6, epi=0, out=None, ldo=None, xs_out=None, gamma_next=None,
