@@ -158,8 +158,11 @@ __device__ __forceinline__ uint2 bf16x8_to_fp8(uint4 v) {      // 8 bf16 -> 8 e4
     return make_uint2(pk_fp8x4(f[0], f[1], f[2], f[3]), pk_fp8x4(f[4], f[5], f[6], f[7]));
 }
 
-template <int MF, bool FP8>
-__global__ __launch_bounds__(256) void attn_flash_kernel(
+// NW waves of 16 * MF queries.  NW = 8, MF = 1 (two waves per SIMD, 128 queries per workgroup as with NW = 4, MF = 2): the softmax
+// VALU phase of one wave runs under the MFMA phase of its SIMD partner (one wave per SIMD runs them one after the other: PMC
+// of round 2, VALU active 50 %, MFMA busy 17 %); every K / V^T fragment read then feeds one MFMA instead of two.
+template <int MF, bool FP8, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_flash_kernel(
     const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
     const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
     int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     constexpr int LD8 = 72;                            // byte pitch of the fp8 tiles and of the fp8 P patch
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KT * LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[2][D * LDK];
-    __shared__ __attribute__((aligned(16))) bf16_t Ps[4][QW * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[NW][QW * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
     // XCD-aware mapping (1-D grid): the query tiles of one (batch, head) pair read the same K / V^T rows; they get
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     if (pair >= npairs) return;                        // uniform: the grid is padded to a multiple of 8 pairs
     const int qt = slot % nq;
     const int b = pair / nheads, h = pair % nheads;
-    const int qb = q_begin + qt * (4 * QW) + wave * QW;   // this wave's first query
+    const int qb = q_begin + qt * (NW * QW) + wave * QW;   // this wave's first query
     q += (long)b * q_bs + h * D;
     k += (long)b * k_bs + h * D;
     vt += (long)b * vt_bs + (long)h * D * ldvt;
@@ -196,9 +199,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     // before the loop: key tiles beyond it are never visited, tiles inside it run the unmasked code, only the boundary
     // tile compares; a workgroup whose queries are all padding writes zeros and leaves.
     const int Tk = klen ? (klen[b] < Tn ? klen[b] : Tn) : Tn;
-    if (klen && q_begin + qt * (4 * QW) >= Tk) {        // uniform per workgroup, before any barrier
-        for (int id = tid; id < 4 * QW * 8; id += 256) {
-            const int i = q_begin + qt * (4 * QW) + (id >> 3);
+    if (klen && q_begin + qt * (NW * QW) >= Tk) {        // uniform per workgroup, before any barrier
+        for (int id = tid; id < NW * QW * 8; id += 64 * NW) {
+            const int i = q_begin + qt * (NW * QW) + (id >> 3);
             if (i < Tn) *reinterpret_cast<uint4*>(out + (long)i * ldo + (id & 7) * 8) = make_uint4(0, 0, 0, 0);
         }
         return;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     // keys beyond the last query's chunk are invisible to the whole block
     int kend = Tk;
     if (chunk > 0) {
-        int qlast = q_begin + qt * (4 * QW) + 4 * QW - 1;
+        int qlast = q_begin + qt * (NW * QW) + NW * QW - 1;
         if (qlast > Tn - 1) qlast = Tn - 1;
         int e = (qlast / chunk + 1) * chunk;
         if (e < kend) kend = e;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     // unmasked code; only the tiles that reach into the block's own chunks compare
     int vis_all = Tk;
     if (chunk > 0) {
-        const int e = ((q_begin + qt * (4 * QW)) / chunk + 1) * chunk;
+        const int e = ((q_begin + qt * (NW * QW)) / chunk + 1) * chunk;
         if (e < vis_all) vis_all = e;
     }
     bf16_t* Pw = Ps[wave];
@@ -258,8 +261,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     uint4 kreg[2], vreg[2];
     auto load_tiles = [&](int j0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int id = tid + i * 256;                    // 512 chunks of 16 B per tile
+        for (int i = 0; i < 512 / (64 * NW); ++i) {
+            int id = tid + i * 64 * NW;                // 512 chunks of 16 B per tile
             int r = id >> 3, c = (id & 7) * 8;
             int key = j0 + r;
             kreg[i] = key < Tk ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int id = tid + i * 256;
+        for (int i = 0; i < 512 / (64 * NW); ++i) {
+            int id = tid + i * 64 * NW;
             int r = id >> 3, c = (id & 7) * 8;
             if constexpr (FP8) {
                 *reinterpret_cast<uint2*>(reinterpret_cast<char*>(Ks[buf]) + r * LD8 + c) = bf16x8_to_fp8(kreg[i]);
@@ -683,7 +686,7 @@ extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, con
         hipLaunchKernelGGL((attn_flash_kernel<1, false>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
                            (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     else
-        hipLaunchKernelGGL((attn_flash_kernel<2, false>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
+        hipLaunchKernelGGL((attn_flash_kernel<1, false, 8>), grid, dim3(512), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
                            (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     MMX_LAUNCH_CHECK();
     return MMX_OK;

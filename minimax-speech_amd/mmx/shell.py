@@ -60,6 +60,15 @@ class EngineHost(nn.Module):
                 m._invalidate()
         return self
 
+    def split_parity(self, on=True):
+        """The split build (mmx/_lib.py X2 / X3): bf16 weight stream, fp32 activations carried as bf16 terms inside the MFMA
+        products - token ids and waveform as the fp32 build's, at (nearly) the bf16 build's speed."""
+        for m in self.modules():
+            if isinstance(m, EngineHost):
+                m.compute_dtype = 2 if on else 1
+                m._invalidate()
+        return self
+
     def _device(self):
         p = next(self.parameters())
         if not p.is_cuda:
