@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-3 profile collection on the GPU box.  Kernel stats (rocprofv3 --kernel-trace --stats) of the default bench (bf16), of
+# the split build's bench, of the decode loop alone (both builds) and of an isolated batched CFM solve (both builds); PMC passes
+# (one counter set per pass, no trace domains next to --pmc) over the decode loop (HBM bytes of the projection kernels) and
+# over the CFM solve (HBM bytes, MFMA busy, LDS conflicts of the flow kernels).  Output under gpurun_out/$1; the summaries
+# judged are copied into profiles/ afterwards.
+out=gpurun_out/${1:-r3p}
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+kstats() {      # name, command...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$name -- "$@" > $out/$name.log 2>&1
+    find $out/kt_$name -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${name}_kernel_stats.csv
+    rm -rf $out/kt_$name
+    echo "kernel stats $name done" >> $out/progress.log
+}
+pmc() {         # name, counters, filter words, command...
+    local name=$1 ctr=$2 keep=$3; shift 3
+    rocprofv3 --pmc $ctr --output-format csv -d $out/pmc_$name -- "$@" > /dev/null 2>&1
+    python tools/pmc_by_kernel.py $out/pmc_$name $keep > $out/pmc_$name.txt 2>&1
+    rm -rf $out/pmc_$name
+    echo "pmc $name done" >> $out/progress.log
+}
+kstats bench python3 bench.py --steps 5 --warmup 2 --no-extras --no-cpu-baseline &&
+kstats bench_x python3 bench.py --dtype x --steps 3 --warmup 1 --no-extras --no-cpu-baseline &&
+kstats decode_bf16 python3 tools/decode_alone.py --dtype bf16 --steps 2 &&
+kstats decode_x python3 tools/decode_alone.py --dtype x --steps 2 &&
+kstats cfm8x896 python3 tools/prof_cfm.py 8 896 bf16 &&
+kstats cfm8x896_x python3 tools/prof_cfm.py 8 896 x &&
+kstats dac python3 tools/prof_dac.py &&
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    pmc decode_bf16_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/decode_alone.py --dtype bf16 --steps 1 || exit 1
+    pmc decode_x_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/decode_alone.py --dtype x --steps 1 || exit 1
+done
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16" "FETCH_SIZE" "WRITE_SIZE"; do
+    n=$(echo $c | cut -d" " -f1)
+    pmc cfm_$n "$c" "est_tail est_resnet attn_flash gemm_win rownorm" python3 tools/prof_cfm.py 8 896 bf16 || exit 1
+    pmc cfmx_$n "$c" "est_tail est_resnet attn_flash gemm_win rownorm" python3 tools/prof_cfm.py 8 896 x || exit 1
+done
+cat $out/pmc_*.txt | head -200

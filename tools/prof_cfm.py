@@ -6,7 +6,8 @@ import torch
 from mmx import shapes, synth
 from mmx.flow import FlowEngine
 n, T = int(sys.argv[1]), int(sys.argv[2])
-eng = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=1, use_graphs=False)
+dt = {"bf16": 1, "f32": 0, "x": 2}[sys.argv[3]] if len(sys.argv) > 3 else 1
+eng = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=dt, use_graphs=False)
 mus = [torch.randn(T, 80, device="cuda") for _ in range(n)]
 conds = [torch.zeros(T, 80, device="cuda") for _ in range(n)]
 spks = [torch.randn(80, device="cuda") for _ in range(n)]
