@@ -55,6 +55,27 @@ template <> struct Cvt<bf16_t> {
     static __device__ __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
 };
 
+// Cross-lane adds on the VALU (DPP) instead of the LDS pipe: hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-pipe round
+// trip of ~100 cycles), which sits on the dependent chain of every short reduction.  CTRL: quad_perm [1,0,3,2] = 0xB1 (xor 1),
+// quad_perm [2,3,0,1] = 0x4E (xor 2), row_half_mirror = 0x141 (lane i <-> 7 - i inside 8 lanes: the other quad once both quads
+// are reduced), row_mirror = 0x140 (lane i <-> 15 - i inside 16 lanes: the other half once both halves are reduced).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over aligned groups of 8 / 16 consecutive lanes, result in every lane of the group
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+    v = group8_sum(v);
+    v += dpp_f32<0x140>(v);
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

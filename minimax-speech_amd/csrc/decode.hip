@@ -124,11 +124,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     if (a.ssq_in) {
         const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
         const float4 q = *reinterpret_cast<const float4*>(a.ssq_in + row * SSQ_SLOTS + part * 4);
-        float sq = (q.x + q.y) + (q.z + q.w);
-        sq += __shfl_xor(sq, 1, 64);
-        sq += __shfl_xor(sq, 2, 64);
-        sq += __shfl_xor(sq, 4, 64);
-        sq += __shfl_xor(sq, 8, 64);
+        float sq = group16_sum((q.x + q.y) + (q.z + q.w));
         if (part == 0) rstd[row] = rsqrtf(sq / (float)a.K + a.eps);
     }
     // Epilogue work is spread over all 8 waves: unit u = (tile t, row tile m, register r) covers, per lane (g, l16), the
@@ -260,11 +256,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
             if constexpr (EPI == 2) {
                 if (ok && a.xs_out) store_split<NS>(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), vv * pre_gn[k]);
                 if (a.ssq_out) {                       // this tile's share of the row's sum of squares: over its 16 columns
-                    float q = ok ? vv * vv : 0.f;
-                    q += __shfl_xor(q, 1, 64);
-                    q += __shfl_xor(q, 2, 64);
-                    q += __shfl_xor(q, 4, 64);
-                    q += __shfl_xor(q, 8, 64);
+                    const float q = group16_sum(ok ? vv * vv : 0.f);
                     if (l16 == 0 && tile < ntiles) a.ssq_out[row * SSQ_SLOTS + tile] = q;
                 }
             }
@@ -300,11 +292,7 @@ __global__ __launch_bounds__(256) void decode_prep_kernel(const float* __restric
             if (h) h[(long)row * ldh + col] = v;
             store_split<NS>(xs, ps, plane_index(row, col, nkb), v * (gamma ? gamma[col] : 1.f));
         }
-        float q = v * v;
-        q += __shfl_xor(q, 1, 64);
-        q += __shfl_xor(q, 2, 64);
-        q += __shfl_xor(q, 4, 64);
-        q += __shfl_xor(q, 8, 64);
+        const float q = group16_sum(v * v);
         if ((t0 & 15) == 0) ssq[row * SSQ_SLOTS + tile] = q;           // tiles beyond K / 16 get 0
     }
 }

@@ -261,8 +261,8 @@ __device__ __forceinline__ void layernorm_rows(float (&v)[MFR][CW], float* stats
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < CW; ++c) s += v[i][c];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
+        s += dpp_f32<0xB1>(s);                         // the 4 lanes of a row (DPP quad sums, no LDS round trip)
+        s += dpp_f32<0x4E>(s);
         if ((lane & 3) == 0) stats[(i * 16 + rl) * NW + wave] = s;
     }
     __syncthreads();
@@ -274,8 +274,8 @@ __device__ __forceinline__ void layernorm_rows(float (&v)[MFR][CW], float* stats
         float q = 0.f;
 #pragma unroll
         for (int c = 0; c < CW; ++c) { const float d = v[i][c] - mean[i]; q += d * d; }
-        q += __shfl_xor(q, 1, 64);
-        q += __shfl_xor(q, 2, 64);
+        q += dpp_f32<0xB1>(q);
+        q += dpp_f32<0x4E>(q);
         if ((lane & 3) == 0) stats[(i * 16 + rl) * NW + wave] = q;
     }
     __syncthreads();

@@ -647,9 +647,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
         float sdot = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) sdot += qv[e] * kv[e];
-        sdot += __shfl_xor(sdot, 1, 64);
-        sdot += __shfl_xor(sdot, 2, 64);
-        sdot += __shfl_xor(sdot, 4, 64);
+        sdot = group8_sum(sdot);                       // the 8 threads of a key (DPP: no LDS round trip on the key chain)
         const float mn = fmaxf(m, sdot);
         const float al = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sdot - mn);
         l = l * al + pj;
