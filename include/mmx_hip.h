@@ -380,6 +380,9 @@ typedef struct MmxEstResnetParams {
  * other's MFMA stage; bf16 only). */
 int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, int cfg, hipStream_t stream);
 int mmx_est_resnet(const MmxEstResnetParams* p, int dtype, int bm, int cfg, hipStream_t stream);
+/* Measurement hook (not part of the product path): buf != NULL makes every later mmx_est_tail launch of this process write
+ * shader-clock stamps uint64 [workgroup][wave][64] at its stage boundaries (tools/tail_lab.py); NULL switches it off. */
+int mmx_debug_tail_stamps(void* buf);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,11 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+// measurement hook (NULL in the product path, set by mmx_debug_tail_stamps): est_tail_kernel writes shader-clock stamps
+// [workgroup][wave][64] at its stage boundaries (tools/tail_lab.py --stamps)
+__device__ unsigned long long* g_tail_stamps = nullptr;
+#define TSTAMP(i) do { if (st && lane == 0) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 template <typename T> struct FT;
 template <> struct FT<bf16_t> { static constexpr int E = 8, KB = 32; typedef short8_t frag_t; };
 template <> struct FT<float> { static constexpr int E = 4, KB = 16; typedef float4_t frag_t; };
@@ -340,7 +345,8 @@ __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lan
 template <typename T, int MF, int PF, int NW, int NS = 1>
 __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n1g)[64 / NW], const float (&n1b)[64 / NW],
                                        const MmxEstNext& nx, float eps, char* a1, float* patch, float* stats,
-                                       WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0) {
+                                       WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0,
+                                       unsigned long long* st = nullptr) {
     typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
     constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256, CW = 64 / NW, PPK = 512 / (64 * NW), NP = 3 * PPK;
     constexpr int P1 = tile_pitch(C, sizeof(T));
@@ -352,6 +358,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 #pragma unroll
     for (int i = 0; i < MF; ++i) store_tile<T, NS, CW>(a1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), plane, xv[i]);
     __syncthreads();
+    TSTAMP(32);
     const char* a_lane = a1 + l16 * P1 + g * 16;
     // bf16 build: Q | K as bf16 rows and V transposed.  Split build: the same two layouts as bf16 PLANES when the caller
     // gives vt_out (q_out bf16 [B][T][ldq >= 2048] = [hi Q | hi K | lo Q | lo K], vt_out [B][2][512][ldvt]: what
@@ -366,6 +373,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
         zero_acc(acc);
         const T* wn = p + 1 < NP ? qkv_pass<T, NW>(nx.wqkv, wave, lane, p + 1) : nullptr;
         stage_run<T, MF, 4, PF, NS>(ring, a_lane, P1, NK, qkv_pass<T, NW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, 4, acc, plane);
+        TSTAMP(33 + 2 * p);
         const int kind = p / PPK, cw = (wave * PPK + p % PPK) * 64;     // 64 columns at cw inside the 512-wide Q / K / V
         if (vt_path && kind == 2) {
             // C layout -> [column][frame] patch, one 16-frame fragment at a time: a lane holds 4 consecutive frames of
@@ -432,6 +440,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
                 if (t < Tn) storen_T<TI, 16>(out + (long)t * nx.ldq + col, v);
             }
         }
+        TSTAMP(34 + 2 * p);
     }
 }
 
@@ -458,6 +467,9 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
     float* patch = patch_all + wave * PATCH_FLOATS;
     const int b = blockIdx.y, t0 = p.t_begin + blockIdx.x * BM, Tn = p.T;
     const int col0 = wave * WC + (lane & 3) * CW;      // this lane's CW columns of a 256-wide row
+    unsigned long long* st = g_tail_stamps;
+    if (st) st += ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 64;
+    TSTAMP(0);
 
     const T* wo = reinterpret_cast<const T*>(p.wo) + (long)lane * E;
     const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
@@ -491,10 +503,13 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
         loadn<CW>(p.n3b + col0, n3b);
         if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
         else load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, PL0, tid, 64 * NW);
+        TSTAMP(1);
         __syncthreads();
+        TSTAMP(2);
         float4_t acc[MF][NFN];
         zero_acc(acc);
         stage_run<T, MF, NFN, PF, NS>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, 4, acc, PL0);
+        TSTAMP(3);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[CW];
@@ -502,6 +517,7 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
 #pragma unroll
             for (int c = 0; c < CW; ++c) x1[i][c] += v[c] + bo[c];
         }
+        TSTAMP(4);
     }
     // ---- LayerNorm (norm3) -> A1
     {
@@ -515,6 +531,7 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
         for (int i = 0; i < MF; ++i) store_tile<T, NS, CW>(a1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), PL1, hn[i]);
     }
     __syncthreads();                                   // A1 complete; every wave is done with the attention tile
+    TSTAMP(5);
     // ---- FF1 + GELU -> LDS chunk -> FF2 accumulate  (transformer.py:306-313, diffusers GELU = Linear + exact gelu)
     float4_t acc2[MF][NFN];
     zero_acc(acc2);
@@ -532,6 +549,7 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
             const T* wn = more ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
             stage_run<T, MF, 4, PF, NS>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
                                         more ? NK1 : NK2, more ? 4 : NFN, acc, PL1);
+            TSTAMP(6 + ch * 12 + h * 2);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[16];
@@ -540,8 +558,10 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
                 for (int c = 0; c < 16; ++c) v[c] = act_c<ACT_GELU, PRECISE>(v[c] + b1[c], 0.f);
                 store_tile<T, NS, 16>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
             }
+            TSTAMP(7 + ch * 12 + h * 2);
         }
         __syncthreads();                               // the chunk is complete
+        TSTAMP(14 + ch * 12);
         if (ch == 1) {                                 // operands of the closing epilogue and of the next LayerNorm
             loadn<CW>(p.b2 + col0, b2);
             if (p.next.wqkv) { loadn<CW>(p.next.n1g + col0, n1g); loadn<CW>(p.next.n1b + col0, n1b); }
@@ -554,7 +574,9 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
         }
         const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW>(p.next.wqkv, wave, lane, 0) : nullptr);
         stage_run<T, MF, NFN, PF, NS>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, 4, acc2, PL0);
+        TSTAMP(15 + ch * 12);
         __syncthreads();                               // every wave is done reading the chunk
+        TSTAMP(16 + ch * 12);
     }
     // ---- + bias + residual -> x (fp32 residual stream, in place)
     {
@@ -573,7 +595,9 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
             }
         }
     }
-    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1);
+    TSTAMP(31);
+    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
+    TSTAMP(63);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -728,6 +752,12 @@ int check_next(const MmxEstNext& nx, int dtype, int T_) {
 }
 
 }  // namespace
+
+extern "C" int mmx_debug_tail_stamps(void* buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamps), &p, sizeof(p));
+    return e == hipSuccess ? MMX_OK : -(int)e - 1000;
+}
 
 // cfg = pf + 16 * waves: pf = k-steps of weight fragments a wave keeps in flight (2 / 4 / 8, 0 = default for the tile),
 // waves = 4 or 8 per workgroup (0 = default)

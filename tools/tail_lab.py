@@ -43,15 +43,80 @@ def run(n, T, bm, waves, pf):
     return _event_time_graph(one, 2 * len(blocks))
 
 
-cfgs = ([(32, 8, 0), (32, 4, 0), (16, 8, 0), (16, 4, 0)] if split else
-        [(64, 4, 2), (64, 4, 4), (64, 8, 2), (32, 8, 2), (32, 8, 4), (32, 4, 4), (32, 4, 2), (16, 8, 4), (16, 4, 8)])
-for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
-    rows = 2 * n * T
-    line = []
-    for bm, waves, pf in cfgs:
-        try:
-            us = run(n, T, bm, waves, pf)
-            line.append(f"{bm}x{waves}w/pf{pf}: {us:6.1f} ({-(-T // bm) * 2 * n:4d} wg)")
-        except Exception as e:  # noqa: BLE001
-            line.append(f"{bm}x{waves}w/pf{pf}: {type(e).__name__}")
-    print(f"rows {rows:6d} | " + " | ".join(line), flush=True)
+def sweep():
+    cfgs = ([(32, 8, 0), (32, 4, 0), (16, 8, 0), (16, 4, 0)] if split else
+            [(64, 4, 2), (64, 4, 4), (64, 8, 2), (32, 8, 2), (32, 8, 4), (32, 4, 4), (32, 4, 2), (16, 8, 4), (16, 4, 8)])
+    for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
+        rows = 2 * n * T
+        line = []
+        for bm, waves, pf in cfgs:
+            try:
+                us = run(n, T, bm, waves, pf)
+                line.append(f"{bm}x{waves}w/pf{pf}: {us:6.1f} ({-(-T // bm) * 2 * n:4d} wg)")
+            except Exception as e:  # noqa: BLE001
+                line.append(f"{bm}x{waves}w/pf{pf}: {type(e).__name__}")
+        print(f"rows {rows:6d} | " + " | ".join(line), flush=True)
+
+
+def stamps(n=5, T=1000, bm=64, waves=4, pf=2):
+    """Stage-boundary shader-clock stamps of every wave of one launch (mmx_debug_tail_stamps): median over workgroups of
+    the time between consecutive stamps of wave 0..NW-1, in us (s_memtime ticks / 2100)."""
+    import ctypes as C
+    from mmx import _lib
+    lib = _lib.load()
+    B = 2 * n
+    nwg = -(-T // bm) * B
+    nw = waves or 4
+    buf = torch.zeros(nwg * nw * 64, dtype=torch.int64, device=fl.dev)
+    Tp = ops.round_up(T, 8)
+    ao = torch.randn(B, T, 512, device=fl.dev).to(fl.tdt)
+    x = torch.randn(B, T, fl.C, device=fl.dev)
+    if split:
+        qk = torch.empty(B, T, 2048, dtype=torch.bfloat16, device=fl.dev)
+        vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device=fl.dev)
+        ldq, vt_bs = 2048, 2 * 512 * Tp
+    else:
+        qk, vt = fl._new(B, T, 1024), torch.zeros(B, 512, Tp, dtype=fl.tdt, device=fl.dev)
+        ldq, vt_bs = 1024, 512 * Tp
+    for i in range(6):                                   # warm L2 / instruction cache; the last launch's stamps are read
+        w, wn = blocks[i], blocks[i + 1]
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
+                           vt_bs=vt_bs)
+        if i == 5:
+            assert lib.mmx_debug_tail_stamps(C.c_void_p(buf.data_ptr())) == 0
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves, pf=pf)
+    torch.cuda.synchronize()
+    assert lib.mmx_debug_tail_stamps(C.c_void_p(0)) == 0
+    s = buf.cpu().reshape(nwg, nw, 64).double()
+    names = {0: "entry", 1: "operand loads issued + tile copy", 2: "barrier", 3: "Wo MFMA", 4: "Wo epilogue", 5: "LN3 + A1 + barrier"}
+    for ch in range(2):
+        for h in range(4):
+            names[6 + ch * 12 + 2 * h] = f"ch{ch} FF1 pass {h} MFMA"
+            names[7 + ch * 12 + 2 * h] = f"ch{ch} FF1 pass {h} GELU epilogue"
+        names[14 + ch * 12] = f"ch{ch} chunk barrier"
+        names[15 + ch * 12] = f"ch{ch} FF2 MFMA"
+        names[16 + ch * 12] = f"ch{ch} barrier"
+    names[31] = "closing epilogue (x store)"
+    names[32] = "LN1 + A1 + barrier"
+    for q in range(12):
+        names[33 + 2 * q] = f"QKV pass {q} MFMA"
+        names[34 + 2 * q] = f"QKV pass {q} epilogue"
+    names[63] = "end"
+    used = [i for i in range(64) if (s[:, :, i] > 0).all()]
+    print(f"stamps: rows {2 * n * T}, {bm} rows x {nw} waves, pf {pf}, {nwg} workgroups; median over workgroups and waves, us (2.1 GHz ticks)")
+    tot = 0.0
+    for a, b in zip(used[:-1], used[1:]):
+        d = ((s[:, :, b] - s[:, :, a]) / 2100.0).flatten()   # s_memtime: shader clock, ~2.1 GHz (tools/decode_lab.py)
+        tot += d.median().item()
+        print(f"   {names.get(b, b):38s} {d.median().item():7.2f}   (min {d.min().item():6.2f}, max {d.max().item():6.2f})   cumulative {tot:7.2f}")
+
+
+if "--stamps" in sys.argv:
+    if split:
+        stamps(5, 1000, 32, 8, 0)
+    else:
+        stamps(5, 1000, 64, 4, 2)
+        stamps(5, 1000, 64, 8, 2)
+        stamps(5, 1000, 32, 8, 2)
+else:
+    sweep()
