@@ -107,9 +107,32 @@ __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(r, x);
 }
 
+// erf for the fused bf16 epilogues whose result is rounded to bf16: odd polynomial of degree 17 on |x| <= 3 (clamped
+// beyond: 1 - erf(3) = 2.2e-5), |error| <= 2.4e-5 - no transcendental (v_rcp / v_exp issue at quarter rate; the FF1
+// epilogue of the estimator's fused tail kernel is VALU bound: tools/tail_lab.py --stamps), all FMAs pack into
+// v_pk_fma_f32.  GELU from it: |error| <= 5.2e-5 absolute.
+__device__ __forceinline__ float erf_poly(float x) {
+    const float u = __builtin_fminf(__builtin_fmaxf(x, -3.0f), 3.0f);
+    const float t = u * u;
+    float p = 4.074212256e-08f;
+    p = p * t - 1.944823225e-06f;
+    p = p * t + 4.106053166e-05f;
+    p = p * t - 5.110369530e-04f;
+    p = p * t + 4.235427827e-03f;
+    p = p * t - 2.510286123e-02f;
+    p = p * t + 1.110793352e-01f;
+    p = p * t - 3.753148615e-01f;
+    p = p * t + 1.128268480e+00f;
+    return u * p;
+}
+
+// ACT_GELU_POLY: GELU through erf_poly (internal to the fused bf16 kernels, not an ABI activation code)
+constexpr int ACT_GELU_POLY = 100;
+
 template <int ACT, bool PRECISE>
 __device__ __forceinline__ float act_c(float v, float slope) {
     if constexpr (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == ACT_GELU_POLY) return 0.5f * v * (1.f + erf_poly(v * 0.70710678118654752f));
     else if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.f + (PRECISE ? erff(v * 0.70710678118654752f) : erf_fast(v * 0.70710678118654752f)));
     else if constexpr (ACT == ACT_SILU) return v / (1.f + (PRECISE ? expf(-v) : __expf(-v)));
     else if constexpr (ACT == ACT_MISH) {

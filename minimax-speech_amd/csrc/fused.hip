@@ -294,37 +294,67 @@ __device__ __forceinline__ void layernorm_rows(float (&v)[MFR][CW], float* stats
 
 // cooperative copy of `rows` rows x K elements (global row stride ld, first row index r0 of `nvalid` valid rows
 // starting at `src`; rows outside [0, nvalid) read zero) into an LDS tile with `pitch` bytes per row
+// Both copies issue their global loads in batches of U (addresses of rows outside the valid range are clamped and the
+// value is replaced by zero afterwards): one load -> wait -> LDS store round trip per 16-byte chunk made the 64 KB
+// attention tile of a 64-row workgroup a 6 us prologue (tools/tail_lab.py --stamps).
 template <typename T>
 __device__ __forceinline__ void load_tile(const T* __restrict__ src, long ld, int r0, int nvalid, int rows, int K,
                                           char* tile, int pitch, int tid, int nthreads) {
-    constexpr int E = FT<T>::E;
+    constexpr int E = FT<T>::E, U = 8;
     const int cpr = K / E;                             // 16-byte chunks per row
     const int total = rows * cpr;
-    for (int id = tid; id < total; id += nthreads) {
-        const int r = id / cpr, ch = id - r * cpr;
-        const int gr = r0 + r;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gr >= 0 && gr < nvalid) v = *reinterpret_cast<const uint4*>(src + (long)gr * ld + ch * E);
-        *reinterpret_cast<uint4*>(tile + r * pitch + ch * 16) = v;
+    for (int base = tid; base < total; base += U * nthreads) {
+        uint4 v[U];
+        int off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int id = base + u * nthreads;
+            const int idc = id < total ? id : total - 1;
+            const int r = idc / cpr, ch = idc - r * cpr;
+            const int gr = r0 + r;
+            const bool ok = gr >= 0 && gr < nvalid;
+            const int grc = gr < 0 ? 0 : (gr < nvalid ? gr : nvalid - 1);
+            v[u] = *reinterpret_cast<const uint4*>(src + (long)grc * ld + ch * E);
+            if (!ok) v[u] = make_uint4(0, 0, 0, 0);
+            off[u] = id < total ? r * pitch + ch * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (off[u] >= 0) *reinterpret_cast<uint4*>(tile + off[u]) = v[u];
     }
 }
 // split build: fp32 rows -> bf16 hi + lo planes (`plane` bytes apart), 4 values per 16-byte global chunk
 __device__ __forceinline__ void load_tile_split(const float* __restrict__ src, long ld, int r0, int nvalid, int rows, int K,
                                                 char* tile, int pitch, int plane, int tid, int nthreads) {
+    constexpr int U = 8;
     const int cpr = K / 4;
     const int total = rows * cpr;
-    for (int id = tid; id < total; id += nthreads) {
-        const int r = id / cpr, ch = id - r * cpr;
-        const int gr = r0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr >= 0 && gr < nvalid) v = *reinterpret_cast<const float4*>(src + (long)gr * ld + ch * 4);
-        uint2 hi, lo;
-        hi.x = pack_bf16x2(v.x, v.y);
-        hi.y = pack_bf16x2(v.z, v.w);
-        lo.x = pack_bf16x2(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
-        lo.y = pack_bf16x2(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
-        *reinterpret_cast<uint2*>(tile + r * pitch + ch * 8) = hi;
-        *reinterpret_cast<uint2*>(tile + plane + r * pitch + ch * 8) = lo;
+    for (int base = tid; base < total; base += U * nthreads) {
+        float4 v[U];
+        int off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int id = base + u * nthreads;
+            const int idc = id < total ? id : total - 1;
+            const int r = idc / cpr, ch = idc - r * cpr;
+            const int gr = r0 + r;
+            const bool ok = gr >= 0 && gr < nvalid;
+            const int grc = gr < 0 ? 0 : (gr < nvalid ? gr : nvalid - 1);
+            v[u] = *reinterpret_cast<const float4*>(src + (long)grc * ld + ch * 4);
+            if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            off[u] = id < total ? r * pitch + ch * 8 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (off[u] < 0) continue;
+            uint2 hi, lo;
+            hi.x = pack_bf16x2(v[u].x, v[u].y);
+            hi.y = pack_bf16x2(v[u].z, v[u].w);
+            lo.x = pack_bf16x2(v[u].x - __uint_as_float(hi.x << 16), v[u].y - __uint_as_float(hi.x & 0xffff0000u));
+            lo.y = pack_bf16x2(v[u].z - __uint_as_float(hi.y << 16), v[u].w - __uint_as_float(hi.y & 0xffff0000u));
+            *reinterpret_cast<uint2*>(tile + off[u]) = hi;
+            *reinterpret_cast<uint2*>(tile + plane + off[u]) = lo;
+        }
     }
 }
 
@@ -449,8 +479,10 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 // slices: the VALU-heavy epilogues (GELU, layout changes, LayerNorm) of one wave run under the MFMA stage of the other,
 // which a single wave per SIMD cannot do for itself (measured at 64 rows: 60 us = weight stream 23 + MFMA 17 + VALU ~20,
 // one after the other).
-template <typename T, int BM, int PF, int NW, int NS = 1>
-__global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
+// OCC = 2 (4-wave workgroups): registers capped at 256 so that TWO workgroups share a CU - no barrier ties them, so one
+// workgroup's VALU epilogues run beside the other's weight stream / MFMA stages.
+template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1>
+__global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams p) {
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PPC = CH / (64 * NW);
     constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
@@ -555,7 +587,7 @@ __global__ __launch_bounds__(64 * NW) void est_tail_kernel(MmxEstTailParams p) {
                 float v[16];
                 to_rows<4>(acc[i], patch, lane, v);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) v[c] = act_c<ACT_GELU, PRECISE>(v[c] + b1[c], 0.f);
+                for (int c = 0; c < 16; ++c) v[c] = act_c<(PRECISE ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
                 store_tile<T, NS, 16>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
             }
             TSTAMP(7 + ch * 12 + h * 2);
@@ -770,16 +802,22 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     MMX_CHECK_ARG(((uintptr_t)p.ao % 16) == 0 && ((uintptr_t)p.x % 16) == 0);
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % (dtype == MMX_X2 ? 4 : 8) == 0 && p.act_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
-    const int pf = cfg & 15, nw = cfg >> 4;
-#define TAILN(TT, BM, PF, NW, NS)                                                                         \
+    const int pf = cfg & 15, nw = (cfg >> 4) & 15, occ2 = (cfg >> 8) & 1;
+#define TAILO(TT, BM, PF, NW, NS, OCC)                                                                    \
     do {                                                                                                   \
         const size_t lds = tail_lds<TT, BM, NW, NS>();                                                     \
-        MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS>), lds);                                        \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_CHECK_ARG(lds * OCC <= 160 * 1024);                                                            \
+        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC>), lds);                                   \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
+#define TAILN(TT, BM, PF, NW, NS) TAILO(TT, BM, PF, NW, NS, 1)
 #define TAIL(TT, BM, PF, NW) TAILN(TT, BM, PF, NW, 1)
-    if (dtype == MMX_X2) {
+    if (occ2) {                                        // two workgroups per CU (4 waves each)
+        if (dtype == MMX_BF16 && bm == 32) { if (pf == 4) TAILO(bf16_t, 32, 4, 4, 1, 2); else TAILO(bf16_t, 32, 2, 4, 1, 2); }
+        else if (dtype == MMX_BF16 && bm == 16) TAILO(bf16_t, 16, 4, 4, 1, 2);
+        else if (dtype == MMX_X2 && bm == 16) { if (pf == 4) TAILO(bf16_t, 16, 4, 4, 2, 2); else TAILO(bf16_t, 16, 2, 4, 2, 2); }
+        else return MMX_EARG;
+    } else if (dtype == MMX_X2) {
         // split build: two bf16 planes per LDS tile, so the largest tile is 32 rows (137 KB with 8 waves)
         if (bm == 32) { if (nw == 4) TAILN(bf16_t, 32, 4, 4, 2); else TAILN(bf16_t, 32, 2, 8, 2); }
         else if (bm == 16) { if (nw == 8) TAILN(bf16_t, 16, 4, 8, 2); else TAILN(bf16_t, 16, 8, 4, 2); }
@@ -806,6 +844,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     } else return MMX_EARG;
 #undef TAIL
 #undef TAILN
+#undef TAILO
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

@@ -38,14 +38,15 @@ def run(n, T, bm, waves, pf):
         w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
         nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
                            vt_bs=vt_bs)
-        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves, pf=pf)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=waves >= 100)
 
     return _event_time_graph(one, 2 * len(blocks))
 
 
 def sweep():
-    cfgs = ([(32, 8, 0), (32, 4, 0), (16, 8, 0), (16, 4, 0)] if split else
-            [(64, 4, 2), (64, 4, 4), (64, 8, 2), (32, 8, 2), (32, 8, 4), (32, 4, 4), (32, 4, 2), (16, 8, 4), (16, 4, 8)])
+    # waves >= 100: the two-workgroups-per-CU variants (4 waves each)
+    cfgs = ([(32, 8, 0), (16, 8, 0), (16, 104, 4), (16, 104, 2)] if split else
+            [(64, 4, 2), (32, 8, 2), (32, 4, 2), (32, 104, 2), (32, 104, 4), (16, 8, 4), (16, 104, 4)])
     for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
         line = []
