@@ -70,8 +70,9 @@ __host__ __device__ constexpr int tile_pitch(int K, int esz) { return ((K * esz 
 // PF: k-steps the ring runs ahead.  One k-step of a wave is MF*NF MFMAs (16 cycles each), an L2 hit takes ~500-800
 // cycles: a 16-row tile (MF = 1) needs ~8 k-steps in flight, a 64-row tile 2.  Every stage's k-step count must be a
 // multiple of PF (checked on the host).
-// The ring is 4 n-fragments wide; a stage that owns fewer (nf = 2: 32 columns per wave in the 8-wave kernels) uses the
-// first nf slots, and head loads for the unused slots repeat fragment 0 (no branch around a load).
+// The ring is NF (4, or 2 in the narrow-pass 8-wave kernels) n-fragments wide; a stage that owns fewer (nf = 2: 32 columns
+// per wave in the 8-wave kernels) uses the first nf slots, and head loads for the unused slots repeat fragment 0 (no branch
+// around a load).
 template <typename T, int NF, int PF_>
 struct WRing {
     static constexpr int E = FT<T>::E, PF = PF_;
@@ -90,8 +91,8 @@ struct WRing {
 // taps = 3; Linear: taps = 1).  wb / ns / nk: packed weights of this stage for this wave (lane offset included),
 // elements between n-fragments, k-steps (even).  wbn / nsn: the next stage's (NULL: none).
 // NS / plane: the A tile is NS planes, `plane` bytes apart (split build); every plane is multiplied with the same B fragment.
-template <typename T, int MF, int NF, int PF, int NS = 1>
-__device__ __forceinline__ void stage_run(WRing<T, 4, PF>& ring, const char* a_lane, int pitch, int cin_steps,
+template <typename T, int MF, int NF, int PF, int NS = 1, int RW = 4>
+__device__ __forceinline__ void stage_run(WRing<T, RW, PF>& ring, const char* a_lane, int pitch, int cin_steps,
                                           const T* wb, long ns, int nk, const T* wbn, long nsn, int nkn, int nfn,
                                           float4_t (&acc)[MF][NF], int plane = 0) {
     constexpr int E = FT<T>::E, KB = FT<T>::KB;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void stage_run(WRing<T, 4, PF>& ring, const char* a_l
                 if (wbn) {                             // uniform per stage
                     const T* src = wbn + (long)(p < nkn ? p : nkn - 1) * 64 * E;
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) ring.w[p][jj] = *reinterpret_cast<const u32x4_t*>(src + (jj < nfn ? jj : 0) * nsn);
+                    for (int jj = 0; jj < RW; ++jj) ring.w[p][jj] = *reinterpret_cast<const u32x4_t*>(src + (jj < nfn ? jj : 0) * nsn);
                 }
             } else {
                 const T* src = wb + (long)(ks + p + PF) * 64 * E;
@@ -362,23 +363,24 @@ __device__ __forceinline__ void load_tile_split(const float* __restrict__ src, l
 // Shared tail of both kernels: x (row layout) -> LayerNorm(n1) -> A1 tile -> Q/K/V projection.
 // bf16: Q,K row-major [B][T][1024] and V TRANSPOSED vt[b][512][Tp] (what the flash kernel reads);
 // fp32: q|k|v row-major [B][T][1536] (the dense attention kernel reads strided heads).
-// Every wave takes 64-column passes: pass p of wave w is kind p / PPK (Q, K, V), columns kind*512 + (w*PPK + p % PPK)*64
-// of the packed [1536][256] projection, PPK = 512 / (64 * NW) passes per kind (2 with 4 waves, 1 with 8).
-template <typename T, int NW>
+// Every wave takes PC = 16 * PW-column passes (PW = 4: 64 columns; PW = 2, 8 waves: 32 columns - half the accumulator
+// registers, see est_tail_kernel): pass p of wave w is kind p / PPK (Q, K, V), columns kind*512 + (w*PPK + p % PPK)*PC of the
+// packed [1536][256] projection, PPK = 512 / (PC * NW) passes per kind.
+template <typename T, int NW, int PW = 4>
 __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lane, int p) {
-    constexpr int E = FT<T>::E, KB = FT<T>::KB, PPK = 512 / (64 * NW);
+    constexpr int E = FT<T>::E, KB = FT<T>::KB, PC = 16 * PW, PPK = 512 / (PC * NW);
     return reinterpret_cast<const T*>(wqkv) + (long)lane * E +
-           (long)(((p / PPK) * 512 + (wave * PPK + p % PPK) * 64) / 16) * ((long)(256 / KB) * 64 * E);
+           (long)(((p / PPK) * 512 + (wave * PPK + p % PPK) * PC) / 16) * ((long)(256 / KB) * 64 * E);
 }
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
-template <typename T, int MF, int PF, int NW, int NS = 1>
+template <typename T, int MF, int PF, int NW, int NS = 1, int PW = 4>
 __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n1g)[64 / NW], const float (&n1b)[64 / NW],
                                        const MmxEstNext& nx, float eps, char* a1, float* patch, float* stats,
-                                       WRing<T, 4, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0,
+                                       WRing<T, PW, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0,
                                        unsigned long long* st = nullptr) {
     typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
-    constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256, CW = 64 / NW, PPK = 512 / (64 * NW), NP = 3 * PPK;
+    constexpr int E = FT<T>::E, KB = FT<T>::KB, C = 256, CW = 64 / NW, PC = 16 * PW, PPK = 512 / (PC * NW), NP = 3 * PPK;
     constexpr int P1 = tile_pitch(C, sizeof(T));
     constexpr int NK = C / KB;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
@@ -399,24 +401,25 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
     const bool vt_path = VTC && (NS == 1 || planes);
     constexpr int PV = 16 * 2 + 16;                    // V^T patch pitch: [64 columns][16 frames] of bf16 inside the wave's patch
     for (int p = 0; p < NP; ++p) {
-        float4_t acc[MF][4];
+        float4_t acc[MF][PW];
         zero_acc(acc);
-        const T* wn = p + 1 < NP ? qkv_pass<T, NW>(nx.wqkv, wave, lane, p + 1) : nullptr;
-        stage_run<T, MF, 4, PF, NS>(ring, a_lane, P1, NK, qkv_pass<T, NW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, 4, acc, plane);
+        const T* wn = p + 1 < NP ? qkv_pass<T, NW, PW>(nx.wqkv, wave, lane, p + 1) : nullptr;
+        stage_run<T, MF, PW, PF, NS, PW>(ring, a_lane, P1, NK, qkv_pass<T, NW, PW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, PW, acc, plane);
         TSTAMP(33 + 2 * p);
-        const int kind = p / PPK, cw = (wave * PPK + p % PPK) * 64;     // 64 columns at cw inside the 512-wide Q / K / V
+        const int kind = p / PPK, cw = (wave * PPK + p % PPK) * PC;     // PC columns at cw inside the 512-wide Q / K / V
         if (vt_path && kind == 2) {
             // C layout -> [column][frame] patch, one 16-frame fragment at a time: a lane holds 4 consecutive frames of
-            // one column; then lane = column writes two 16-byte chunks of 8 frames (frames >= Tn as zeros: the pad of
-            // the transposed buffer stays finite).  Split build: once for the hi terms, once for the remainders.
+            // one column; then the 2 * PC 16-byte chunks of 8 frames (column = chunk >> 1) go out one or two per lane
+            // (frames >= Tn as zeros: the pad of the transposed buffer stays finite).  Split build: once for the hi
+            // terms, once for the remainders.
             char* vw = reinterpret_cast<char*>(patch);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)s2 * 512 * nx.ldvt + (long)(cw + lane) * nx.ldvt + t0;
+                bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)s2 * 512 * nx.ldvt + (long)cw * nx.ldvt + t0;
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < PW; ++j) {
                         uint2 pk;
                         pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
                         pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
@@ -429,8 +432,9 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int c8 = 0; c8 < 2; ++c8) {
-                        uint4 v = *reinterpret_cast<const uint4*>(vw + lane * PV + c8 * 16);
+                    for (int k2 = 0; k2 < PW / 2; ++k2) {
+                        const int chunk = lane + 64 * k2, colv = chunk >> 1, c8 = chunk & 1;
+                        uint4 v = *reinterpret_cast<const uint4*>(vw + colv * PV + c8 * 16);
                         const int t = t0 + i * 16 + c8 * 8;
                         if (t >= Tn) continue;
                         if (t + 8 > Tn) {
@@ -439,35 +443,35 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
                             for (int e = 0; e < 8; ++e)
                                 if (t + e >= Tn) h[e] = 0;
                         }
-                        *reinterpret_cast<uint4*>(dst + i * 16 + c8 * 8) = v;
+                        *reinterpret_cast<uint4*>(dst + (long)colv * nx.ldvt + i * 16 + c8 * 8) = v;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
             }
         } else if (planes) {
             bf16_t* out = reinterpret_cast<bf16_t*>(nx.q_out) + (long)b * nx.q_bs;
-            const int col = kind * 512 + cw + (lane & 3) * 16;
+            const int col = kind * 512 + cw + (lane & 3) * (4 * PW);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
-                float v[16], lo[16];
-                to_rows<4>(acc[i], patch, lane, v);
+                float v[4 * PW], lo[4 * PW];
+                to_rows<PW>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
                 if (t < Tn) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) lo[c] = v[c] - bf2f(f2bf(v[c]));
-                    storen_T<bf16_t, 16>(out + (long)t * nx.ldq + col, v);
-                    storen_T<bf16_t, 16>(out + (long)t * nx.ldq + 1024 + col, lo);
+                    for (int c = 0; c < 4 * PW; ++c) lo[c] = v[c] - bf2f(f2bf(v[c]));
+                    storen_T<bf16_t, 4 * PW>(out + (long)t * nx.ldq + col, v);
+                    storen_T<bf16_t, 4 * PW>(out + (long)t * nx.ldq + 1024 + col, lo);
                 }
             }
         } else {
             TI* out = reinterpret_cast<TI*>(nx.q_out) + (long)b * nx.q_bs;
-            const int col = kind * 512 + cw + (lane & 3) * 16;
+            const int col = kind * 512 + cw + (lane & 3) * (4 * PW);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
-                float v[16];
-                to_rows<4>(acc[i], patch, lane, v);
+                float v[4 * PW];
+                to_rows<PW>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
-                if (t < Tn) storen_T<TI, 16>(out + (long)t * nx.ldq + col, v);
+                if (t < Tn) storen_T<TI, 4 * PW>(out + (long)t * nx.ldq + col, v);
             }
         }
         TSTAMP(34 + 2 * p);
@@ -481,10 +485,16 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 // one after the other).
 // OCC = 2 (4-wave workgroups): registers capped at 256 so that TWO workgroups share a CU - no barrier ties them, so one
 // workgroup's VALU epilogues run beside the other's weight stream / MFMA stages.
-template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1>
+// PW = 2 (8 waves): FF1 and Q/K/V passes of 32 columns, every stage 2 fragments wide - the pass accumulator is 32 instead
+// of 64 registers per 64 rows, which is what lets the 64-row tile run two waves per SIMD inside 256 registers without
+// spilling (the 64-column-pass version spilled 400 bytes per lane), with a ring 4 k-steps deep: 8 waves x 8 KB of weight
+// fragments in flight per CU instead of 4 x 8 KB.  At depth 2 a fragment is requested two k-steps (0.25 us of MFMAs) before
+// its use, less than an L2 hit takes, so the one-wave-per-SIMD kernel waits in every k-step (tools/tail_lab.py --stamps).
+template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1, int PW = 4>
 __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams p) {
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
-    constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PPC = CH / (64 * NW);
+    constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PC = 16 * PW, PPC = CH / (PC * NW);
+    static_assert(NFN <= PW, "the ring is PW fragments wide");
     constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
     constexpr int PL0 = BM * P0, PL1 = BM * P1;        // bytes between the planes of a tile (split build)
     constexpr bool PRECISE = sizeof(T) == 4 || NS > 1;
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     const T* w2 = reinterpret_cast<const T*>(p.w2) + (long)lane * E;
     constexpr int NK0 = CI / KB, NK1 = C / KB, NK2 = CH / KB, NK2T = CF / KB;
     const long ns0 = (long)NK0 * 64 * E, ns1 = (long)NK1 * 64 * E, ns2 = (long)NK2T * 64 * E;
-    WRing<T, 4, PF> ring;
+    WRing<T, PW, PF> ring;
     const T* wo_w = wo + (long)(wave * NFN) * ns0;     // this wave's NFN n-fragments of the 256 output columns
     ring.prime(wo_w, ns0, NK0, NFN);
 
@@ -516,8 +526,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     // epilogue uses them.  A wave waits for a load with s_waitcnt vmcnt(N), which counts in issue order: a load issued
     // in the epilogue would wait for itself AND drain the weight ring that is running ahead for the next stage.
     // ---- attention output projection + bias + residual  (transformer.py:290-297: attn1 -> + hidden_states)
-    // FF1 pass q = ch*PPC + h: 64 columns at ch*512 + (wave*PPC + h)*64 of the 1024-wide intermediate
-    auto w1_pass = [&](int q) { return w1 + (long)(((q / PPC) * CH + (wave * PPC + q % PPC) * 64) / 16) * ns1; };
+    // FF1 pass q = ch*PPC + h: PC columns at ch*512 + (wave*PPC + h)*PC of the 1024-wide intermediate
+    auto w1_pass = [&](int q) { return w1 + (long)(((q / PPC) * CH + (wave * PPC + q % PPC) * PC) / 16) * ns1; };
     float x1[MF][CW], bo[CW], n3g[CW], n3b[CW];
     {
         const float* xr = p.x + (long)b * p.x_bs;
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
         TSTAMP(2);
         float4_t acc[MF][NFN];
         zero_acc(acc);
-        stage_run<T, MF, NFN, PF, NS>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, 4, acc, PL0);
+        stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, PW, acc, PL0);
         TSTAMP(3);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -572,23 +582,23 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     for (int ch = 0; ch < 2; ++ch) {
         for (int h = 0; h < PPC; ++h) {
             const int q = ch * PPC + h;
-            const int hc = (wave * PPC + h) * 64 + (lane & 3) * 16;   // column inside the chunk
-            float b1[16];
-            loadn<16>(p.b1 + ch * CH + hc, b1);
-            float4_t acc[MF][4];
+            const int hc = (wave * PPC + h) * PC + (lane & 3) * (4 * PW);   // column inside the chunk
+            float b1[4 * PW];
+            loadn<4 * PW>(p.b1 + ch * CH + hc, b1);
+            float4_t acc[MF][PW];
             zero_acc(acc);
             const bool more = h + 1 < PPC;
             const T* wn = more ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
-            stage_run<T, MF, 4, PF, NS>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
-                                        more ? NK1 : NK2, more ? 4 : NFN, acc, PL1);
+            stage_run<T, MF, PW, PF, NS, PW>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
+                                             more ? NK1 : NK2, more ? PW : NFN, acc, PL1);
             TSTAMP(6 + ch * 12 + h * 2);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
-                float v[16];
-                to_rows<4>(acc[i], patch, lane, v);
+                float v[4 * PW];
+                to_rows<PW>(acc[i], patch, lane, v);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) v[c] = act_c<(PRECISE ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
-                store_tile<T, NS, 16>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
+                for (int c = 0; c < 4 * PW; ++c) v[c] = act_c<(PRECISE ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
+                store_tile<T, NS, 4 * PW>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
             }
             TSTAMP(7 + ch * 12 + h * 2);
         }
@@ -604,8 +614,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
                 rm[i] = (rmk && t < Tn) ? rmk[t] : 1.f;
             }
         }
-        const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW>(p.next.wqkv, wave, lane, 0) : nullptr);
-        stage_run<T, MF, NFN, PF, NS>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, 4, acc2, PL0);
+        const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW, PW>(p.next.wqkv, wave, lane, 0) : nullptr);
+        stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, PW, acc2, PL0);
         TSTAMP(15 + ch * 12);
         __syncthreads();                               // every wave is done reading the chunk
         TSTAMP(16 + ch * 12);
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
         }
     }
     TSTAMP(31);
-    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
+    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS, PW>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
     TSTAMP(63);
 }
 
@@ -803,16 +813,23 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % (dtype == MMX_X2 ? 4 : 8) == 0 && p.act_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
     const int pf = cfg & 15, nw = (cfg >> 4) & 15, occ2 = (cfg >> 8) & 1;
-#define TAILO(TT, BM, PF, NW, NS, OCC)                                                                    \
+#define TAILP(TT, BM, PF, NW, NS, OCC, PW)                                                                \
     do {                                                                                                   \
         const size_t lds = tail_lds<TT, BM, NW, NS>();                                                     \
         MMX_CHECK_ARG(lds * OCC <= 160 * 1024);                                                            \
-        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC>), lds);                                   \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW>), lds);                               \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
+#define TAILO(TT, BM, PF, NW, NS, OCC) TAILP(TT, BM, PF, NW, NS, OCC, 4)
 #define TAILN(TT, BM, PF, NW, NS) TAILO(TT, BM, PF, NW, NS, 1)
 #define TAIL(TT, BM, PF, NW) TAILN(TT, BM, PF, NW, 1)
-    if (occ2) {                                        // two workgroups per CU (4 waves each)
+    const int narrow = (cfg >> 9) & 1;
+    if (narrow) {                                      // 8 waves, 32-column passes (PW = 2)
+        if (dtype == MMX_BF16 && bm == 64) { if (pf == 2) TAILP(bf16_t, 64, 2, 8, 1, 1, 2); else TAILP(bf16_t, 64, 4, 8, 1, 1, 2); }
+        else if (dtype == MMX_BF16 && bm == 32) { if (pf == 8) TAILP(bf16_t, 32, 8, 8, 1, 1, 2); else TAILP(bf16_t, 32, 4, 8, 1, 1, 2); }
+        else if (dtype == MMX_X2 && bm == 32) { if (pf == 2) TAILP(bf16_t, 32, 2, 8, 2, 1, 2); else TAILP(bf16_t, 32, 4, 8, 2, 1, 2); }
+        else return MMX_EARG;
+    } else if (occ2) {                                 // two workgroups per CU (4 waves each)
         if (dtype == MMX_BF16 && bm == 32) { if (pf == 4) TAILO(bf16_t, 32, 4, 4, 1, 2); else TAILO(bf16_t, 32, 2, 4, 1, 2); }
         else if (dtype == MMX_BF16 && bm == 16) TAILO(bf16_t, 16, 4, 4, 1, 2);
         else if (dtype == MMX_X2 && bm == 16) { if (pf == 4) TAILO(bf16_t, 16, 4, 4, 2, 2); else TAILO(bf16_t, 16, 2, 4, 2, 2); }
@@ -845,6 +862,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
 #undef TAIL
 #undef TAILN
 #undef TAILO
+#undef TAILP
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

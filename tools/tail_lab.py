@@ -38,15 +38,15 @@ def run(n, T, bm, waves, pf):
         w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
         nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
                            vt_bs=vt_bs)
-        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=waves >= 100)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=100 <= waves < 200, narrow=waves >= 200)
 
     return _event_time_graph(one, 2 * len(blocks))
 
 
 def sweep():
-    # waves >= 100: the two-workgroups-per-CU variants (4 waves each)
-    cfgs = ([(32, 8, 0), (16, 8, 0), (16, 104, 4), (16, 104, 2)] if split else
-            [(64, 4, 2), (32, 8, 2), (32, 4, 2), (32, 104, 2), (32, 104, 4), (16, 8, 4), (16, 104, 4)])
+    # waves 1xx: the two-workgroups-per-CU variants (4 waves each); 2xx: 8 waves with 32-column passes
+    cfgs = ([(32, 8, 0), (32, 208, 2), (32, 208, 4), (16, 8, 0), (16, 104, 2)] if split else
+            [(64, 4, 2), (64, 208, 2), (64, 208, 4), (32, 8, 2), (32, 208, 4), (32, 208, 8), (32, 104, 2), (16, 8, 4)])
     for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
         line = []
@@ -67,7 +67,7 @@ def stamps(n=5, T=1000, bm=64, waves=4, pf=2):
     lib = _lib.load()
     B = 2 * n
     nwg = -(-T // bm) * B
-    nw = waves or 4
+    nw = (waves % 100) or 4
     buf = torch.zeros(nwg * nw * 64, dtype=torch.int64, device=fl.dev)
     Tp = ops.round_up(T, 8)
     ao = torch.randn(B, T, 512, device=fl.dev).to(fl.tdt)
@@ -85,7 +85,7 @@ def stamps(n=5, T=1000, bm=64, waves=4, pf=2):
                            vt_bs=vt_bs)
         if i == 5:
             assert lib.mmx_debug_tail_stamps(C.c_void_p(buf.data_ptr())) == 0
-        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves, pf=pf)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=100 <= waves < 200, narrow=waves >= 200)
     torch.cuda.synchronize()
     assert lib.mmx_debug_tail_stamps(C.c_void_p(0)) == 0
     s = buf.cpu().reshape(nwg, nw, 64).double()
@@ -117,7 +117,7 @@ if "--stamps" in sys.argv:
         stamps(5, 1000, 32, 8, 0)
     else:
         stamps(5, 1000, 64, 4, 2)
-        stamps(5, 1000, 64, 8, 2)
+        stamps(5, 1000, 64, 208, 4)
         stamps(5, 1000, 32, 8, 2)
 else:
     sweep()
