@@ -167,6 +167,7 @@ __device__ __forceinline__ void zero_acc(float4_t (&acc)[MF][NF]) {
 // 16-row fragment and NF*4 consecutive columns (lane & 3)*NF*4 .. of the wave's NF*16-column slice, through the wave's
 // private fp32 patch (16 rows of NF*16 + 4 floats: conflict-free ds_write_b32).
 constexpr int PATCH_FLOATS = 16 * 68;                  // per wave: the widest slice is 64 columns
+constexpr int TAIL_PRM_FLOATS = 6 * 256 + 1024;        // est_tail_kernel's bias / LayerNorm vectors in LDS
 template <int NF>
 __device__ __forceinline__ void to_rows(const float4_t (&acc)[NF], float* patch, int lane, float (&v)[NF * 4]) {
     constexpr int LDC = NF * 16 + 4;
@@ -498,12 +499,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
     constexpr int PL0 = BM * P0, PL1 = BM * P1;        // bytes between the planes of a tile (split build)
     constexpr bool PRECISE = sizeof(T) == 4 || NS > 1;
+    constexpr bool PARK = PW == 2;
     typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* buf0 = smem;                                 // [NS][BM][512] attention output, then the FF intermediate chunk
     char* a1 = buf0 + NS * PL0;                        // [NS][BM][256] LayerNorm output (A operand of FF1 / QKV)
     float* patch_all = reinterpret_cast<float*>(a1 + NS * PL1);
     float* stats = patch_all + NW * PATCH_FLOATS;      // [BM][NW]
+    // the block's bias / LayerNorm vectors: bo | n3g | n3b | b2 | n1g | n1b (256 each) | b1 (1024).  Epilogues read them
+    // from here (lgkmcnt) instead of holding them in registers from before the preceding MFMA stage: a global load issued
+    // in an epilogue would wait behind the weight ring (vmcnt counts in issue order)
+    float* prm = stats + BM * NW;
+    constexpr int PRM_BO = 0, PRM_N3G = 256, PRM_N3B = 512, PRM_B2 = 768, PRM_N1G = 1024, PRM_N1B = 1280, PRM_B1 = 1536;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
     float* patch = patch_all + wave * PATCH_FLOATS;
@@ -522,14 +529,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     const T* wo_w = wo + (long)(wave * NFN) * ns0;     // this wave's NFN n-fragments of the 256 output columns
     ring.prime(wo_w, ns0, NK0, NFN);
 
-    // Epilogue operands (residual rows, biases, LayerNorm weights, row mask) are loaded BEFORE the MFMA stage whose
-    // epilogue uses them.  A wave waits for a load with s_waitcnt vmcnt(N), which counts in issue order: a load issued
-    // in the epilogue would wait for itself AND drain the weight ring that is running ahead for the next stage.
+    // Global epilogue operands (residual rows, row mask) are loaded BEFORE the MFMA stage whose epilogue uses them.  A wave
+    // waits for a load with s_waitcnt vmcnt(N), which counts in issue order: a load issued in the epilogue would wait for
+    // itself AND drain the weight ring that is running ahead for the next stage.  The small vectors come from LDS (prm).
     // ---- attention output projection + bias + residual  (transformer.py:290-297: attn1 -> + hidden_states)
     // FF1 pass q = ch*PPC + h: PC columns at ch*512 + (wave*PPC + h)*PC of the 1024-wide intermediate
     auto w1_pass = [&](int q) { return w1 + (long)(((q / PPC) * CH + (wave * PPC + q % PPC) * PC) / 16) * ns1; };
-    float x1[MF][CW], bo[CW], n3g[CW], n3b[CW];
+    float x1[MF][CW];
     {
+        for (int id = tid; id < TAIL_PRM_FLOATS / 4; id += 64 * NW) {
+            const int seg = id >> 6, o4 = (id & 63) * 4;            // 64 float4 per 256-float vector; b1 is segments 6..9
+            const float* src = seg == 0 ? p.bo : seg == 1 ? p.n3g : seg == 2 ? p.n3b : seg == 3 ? p.b2
+                             : seg == 4 ? (p.next.wqkv ? p.next.n1g : p.b2) : seg == 5 ? (p.next.wqkv ? p.next.n1b : p.b2) : p.b1 + (seg - 6) * 256;
+            *reinterpret_cast<float4_t*>(prm + id * 4) = *reinterpret_cast<const float4_t*>(src + o4);
+        }
         const float* xr = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -540,9 +553,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
                 for (int c = 0; c < CW; ++c) x1[i][c] = 0.f;
             }
         }
-        loadn<CW>(p.bo + col0, bo);
-        loadn<CW>(p.n3g + col0, n3g);
-        loadn<CW>(p.n3b + col0, n3b);
         if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
         else load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, PL0, tid, 64 * NW);
         TSTAMP(1);
@@ -552,17 +562,29 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
         zero_acc(acc);
         stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, PW, acc, PL0);
         TSTAMP(3);
+        float bo[CW];
+        loadn<CW>(prm + PRM_BO + col0, bo);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[CW];
             to_rows<NFN>(acc[i], patch, lane, v);
 #pragma unroll
             for (int c = 0; c < CW; ++c) x1[i][c] += v[c] + bo[c];
+            // PARK: the residual rows wait in HBM (x, in place) for the closing epilogue instead of in 8 * MF registers
+            // through both FF stages - the narrow-pass 8-wave kernels have 256 registers per wave
+            if (PARK && t0 + i * 16 + rl < Tn) storen<CW>(p.x + (long)b * p.x_bs + (long)(t0 + i * 16 + rl) * C + col0, x1[i]);
         }
         TSTAMP(4);
     }
     // ---- LayerNorm (norm3) -> A1
-    {
+    float n3g[CW], n3b[CW];
+    loadn<CW>(prm + PRM_N3G + col0, n3g);
+    loadn<CW>(prm + PRM_N3B + col0, n3b);
+    if constexpr (PARK) {
+        layernorm_rows<MF, CW, NW>(x1, stats, n3g, n3b, p.eps, wave, lane);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) store_tile<T, NS, CW>(a1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), PL1, x1[i]);
+    } else {
         float hn[MF][CW];
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -578,13 +600,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     float4_t acc2[MF][NFN];
     zero_acc(acc2);
     const T* w2_w = w2 + (long)(wave * NFN) * ns2;     // FF2: this wave's output columns, K walked per chunk
-    float b2[CW], n1g[CW], n1b[CW], rm[MF];
+    float rm[MF];
     for (int ch = 0; ch < 2; ++ch) {
         for (int h = 0; h < PPC; ++h) {
             const int q = ch * PPC + h;
             const int hc = (wave * PPC + h) * PC + (lane & 3) * (4 * PW);   // column inside the chunk
-            float b1[4 * PW];
-            loadn<4 * PW>(p.b1 + ch * CH + hc, b1);
             float4_t acc[MF][PW];
             zero_acc(acc);
             const bool more = h + 1 < PPC;
@@ -592,6 +612,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
             stage_run<T, MF, PW, PF, NS, PW>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
                                              more ? NK1 : NK2, more ? PW : NFN, acc, PL1);
             TSTAMP(6 + ch * 12 + h * 2);
+            float b1[4 * PW];
+            loadn<4 * PW>(prm + PRM_B1 + ch * CH + hc, b1);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[4 * PW];
@@ -604,14 +626,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
         }
         __syncthreads();                               // the chunk is complete
         TSTAMP(14 + ch * 12);
-        if (ch == 1) {                                 // operands of the closing epilogue and of the next LayerNorm
-            loadn<CW>(p.b2 + col0, b2);
-            if (p.next.wqkv) { loadn<CW>(p.next.n1g + col0, n1g); loadn<CW>(p.next.n1b + col0, n1b); }
+        if (ch == 1) {                                 // global operands of the closing epilogue
             const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 const int t = t0 + i * 16 + rl;
                 rm[i] = (rmk && t < Tn) ? rmk[t] : 1.f;
+                if constexpr (PARK) {                  // the parked residual rows (written by this lane, a barrier ago)
+                    loadn<CW>(p.x + (long)b * p.x_bs + (long)(t < Tn ? t : Tn - 1) * C + col0, x1[i]);
+                }
             }
         }
         const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW, PW>(p.next.wqkv, wave, lane, 0) : nullptr);
@@ -623,6 +646,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     // ---- + bias + residual -> x (fp32 residual stream, in place)
     {
         float* xw = p.x + (long)b * p.x_bs;
+        float b2[CW];
+        loadn<CW>(prm + PRM_B2 + col0, b2);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[CW];
@@ -638,7 +663,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
         }
     }
     TSTAMP(31);
-    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS, PW>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
+    if (p.next.wqkv) {
+        float n1g[CW], n1b[CW];
+        loadn<CW>(prm + PRM_N1G + col0, n1g);
+        loadn<CW>(prm + PRM_N1B + col0, n1b);
+        ln_qkv<T, MF, PF, NW, NS, PW>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
+    }
     TSTAMP(63);
 }
 
@@ -765,7 +795,8 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
 
 template <typename T, int BM, int NW, int NS = 1>
 size_t tail_lds() {
-    return NS * ((size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T))) + (size_t)NW * PATCH_FLOATS * 4 + (size_t)BM * NW * 4;
+    return NS * ((size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T))) + (size_t)NW * PATCH_FLOATS * 4 + (size_t)BM * NW * 4 +
+           (size_t)TAIL_PRM_FLOATS * 4;
 }
 template <typename T, int BM, int NW, int NS = 1>
 size_t resnet_lds(int cin) {
