@@ -565,17 +565,25 @@ class FlowEngine:
         return out
 
     # ------------------------------------------------------------------ estimator on the row-tile fused kernels
-    # measured time of ONE workgroup of the fused kernels by tile height (us, bf16): every workgroup streams the block's
-    # whole weight set from L2 at the CU's ~72 GB/s, so a launch takes (workgroups per CU, rounded up) x this
-    _WG_US = {16: 28.8, 32: 32.4, 64: 53.9}
+    # measured time (us, bf16) of ONE launch of est_tail_kernel with few workgroups, by tile height (tools/tail_lab.py: 16 rows
+    # x 8 waves, 32 and 64 rows x 8 waves with 32-column passes): every workgroup streams the block's 2 MB of weights from L2
+    # through its CU's memory pipe, so a workgroup takes this long whatever else runs; with more of the chip streaming the
+    # same weights it takes up to 45 % longer (256 workgroups: 34 / 42 / 65 us)
+    _WG_US = {16: 27.1, 32: 29.9, 64: 44.1}
+
+    @classmethod
+    def _launch_us(cls, bm, tiles):
+        """Model of one est_tail launch: full rounds of 256 workgroups, then the remainder."""
+        t = lambda n: cls._WG_US[bm] * (1.0 + 0.45 * (n / 256.0) ** 2)
+        full, rem = divmod(tiles, 256)
+        return full * t(256) + (t(rem) if rem else 0.0)
 
     def _tile_rows(self, B, T):
         """Rows per workgroup of the fused kernels: the tile height with the shortest launch on 256 CUs."""
         tiles = lambda bm: B * ((T + bm - 1) // bm)
         if self.dtype == BF16:
             cap = getattr(self, "max_tile_rows", 64)
-            cost = lambda bm: ((tiles(bm) + 255) // 256) * self._WG_US[bm]
-            bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (cost(b), -b))
+            bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (self._launch_us(b, tiles(b)), -b))
             bm = max(bm, getattr(self, "min_tile_rows", 16), 64 if self.polite else 16)
             return bm, bm
         if self.split:
