@@ -1,0 +1,20 @@
+#!/bin/bash
+# Scheduling sweep of the config-4 rank share (bench.py flags), one line per setting: value, ms per step, LM loop / tail times.
+#   bash tools/sweep_sched.sh OUTDIR [dtype]
+out=$1; dt=${2:-bf16}; mkdir -p $out
+run() {
+  name=$1; shift
+  MMX_TIMING=1 python bench.py --dtype $dt --steps 3 --warmup 2 --no-cpu-baseline --no-extras "$@" > $out/$name.json 2> $out/$name.err
+  v=$(python -c "import json,sys; d=json.loads(open('$out/$name.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])")
+  t=$(grep "LM loop done" $out/$name.err $out/$name.json | tail -1 | sed 's/.*LM loop done at/LM/; s/, decode steps.*//')
+  echo "$name: $v | $t" | tee -a $out/sweep.txt
+}
+run base
+run nopolite --no-polite
+run hold40 --hold-steps 40
+run hold90 --hold-steps 90
+run tail3 --tail-active 3
+run group6 --flow-group 6
+run group12 --flow-group 12
+run workers3 --flow-workers 3
+run poll4 --poll-every 4
