@@ -381,6 +381,34 @@ typedef struct MmxEstResnetParams {
  * other's MFMA stage; bf16 only). */
 int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, int cfg, hipStream_t stream);
 int mmx_est_resnet(const MmxEstResnetParams* p, int dtype, int bm, int cfg, hipStream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * DAC-VAE ResidualUnit as one kernel (dac-vae/model.py:107-143; :509-514: LeakyReLU(slope) after every Conv1d):
+ *     x_out = x + lrelu(conv1(snake_a2(lrelu(conv7, dilation dil (snake_a0(x))))))      [act_out = snake_alpha_next(x_out)]
+ * for the narrow decoder stages, C = 48 / 96 / 192; dtype MMX_BF16 or MMX_X2 (the fp32 build runs the unit as two
+ * mmx_gemm_win launches).  x / x_out: fp32 [B][T][C] residual stream (batch stride x_bs elements; x_out must not alias x:
+ * neighbouring tiles read each other's halo rows); act_out (optional): the next layer's input activation, bf16 (MMX_BF16) or
+ * fp32 (MMX_X2), same strides.  w7 / w1: mmx_pack_skinny packs of the weight matrices [C][7 * CP] (tap-major, each tap's
+ * C input channels zero-padded to CP = 32 * ceil(C / 32)) and [C][CP].  lens (optional, int32 [B]): rows >= lens[b] of batch
+ * member b are conv padding - read as zero, written as zero (utterances of different lengths decoded in one batch).
+ * bm: rows per workgroup, 0 = the library's default for (C, dtype). */
+typedef struct {
+    const float* x;
+    float* x_out;
+    void* act_out;
+    const void* w7;
+    const void* w1;
+    const float* b7;
+    const float* b1;
+    const float* a0;
+    const float* a2;
+    const float* alpha_next;
+    const int32_t* lens;
+    int64_t x_bs;
+    int32_t B, T, C, dil;
+    float slope;
+} MmxDacRuParams;
+int mmx_dac_ru(const MmxDacRuParams* p, int dtype, int bm, hipStream_t stream);
+
 /* Measurement hook (not part of the product path): buf != NULL makes every later mmx_est_tail launch of this process write
  * shader-clock stamps uint64 [workgroup][wave][64] at its stage boundaries (tools/tail_lab.py); NULL switches it off. */
 int mmx_debug_tail_stamps(void* buf);

@@ -94,17 +94,18 @@ struct WRing {
 template <typename T, int MF, int NF, int PF, int NS = 1, int RW = 4>
 __device__ __forceinline__ void stage_run(WRing<T, RW, PF>& ring, const char* a_lane, int pitch, int cin_steps,
                                           const T* wb, long ns, int nk, const T* wbn, long nsn, int nkn, int nfn,
-                                          float4_t (&acc)[MF][NF], int plane = 0) {
+                                          float4_t (&acc)[MF][NF], int plane = 0, int tap_pitch = 0) {
     constexpr int E = FT<T>::E, KB = FT<T>::KB;
     typedef typename FT<T>::frag_t frag_t;
+    if (tap_pitch == 0) tap_pitch = pitch;             // dilated convs (DAC): tap t reads t * dilation rows further down
     // A fragments come from LDS AD - 1 k-steps ahead of their use (a k-step is MF*NF MFMAs = 64 cycles at MF = 1,
     // 256 at MF = 4; the LDS latency is ~130 cycles)
-    constexpr int AD = (MF == 1 && PF >= 4) ? 4 : 2;
+    constexpr int AD = (PF % 2) ? PF : ((MF == 1 && PF >= 4) ? 4 : 2);
     static_assert(PF % AD == 0, "ring depths");
     frag_t a[AD][NS][MF];
     int rt = 0, rc = 0, rs = 0;                        // tap / k-step inside the tap / k-step of the next A read
     auto read_a = [&](frag_t (&dst)[NS][MF]) {
-        const char* ap = a_lane + rt * pitch + rc * (KB * (int)sizeof(T));
+        const char* ap = a_lane + rt * tap_pitch + rc * (KB * (int)sizeof(T));
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
@@ -793,6 +794,212 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
     if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS>(h2, gg, be, p.next, p.eps, h1, patch, stats, ring, b, t0, Tn, wave, lane, PLH);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// DAC-VAE ResidualUnit (dac-vae/model.py:107-143 with :509-514: every Conv1d is followed by LeakyReLU(0.1)) as ONE kernel
+// for the narrow stages (C = 48 / 96 / 192 channels, 240 000 .. 40 000 rows per 10 s of audio):
+//
+//     x_out = x + lrelu(conv1(snake_a2(lrelu(conv7_dil(snake_a0(x))))))          [act_out = snake_next(x_out)]
+//
+// As two windowed GEMMs (csrc/gemm.hip) a unit moves 16 bytes per element through HBM (activation in, intermediate out
+// and in, residual in, residual + next activation out); here the fp32 residual stream is read once (tile + 3 * dilation
+// rows of halo each side) and written once.  A workgroup takes BM rows: snake(x) of rows t0 - 3d .. t0 + BM + 3d goes into
+// an LDS tile (bf16, or hi + lo planes in the split build), the k7 conv walks it as 7 taps d rows apart, its output
+// (+ bias, LeakyReLU, Snake) becomes a second LDS tile, the 1x1 conv reads that, and the epilogue adds the residual.
+// Weights are packed in MFMA B-fragment order and streamed from L2 through the register ring of the estimator kernels;
+// 4 waves as WR row groups x WC column groups of 48 columns (3 n-fragments) each: C = 192 -> 1 x 4 (every weight
+// fragment streamed once per workgroup), 96 -> 2 x 2, 48 -> 4 x 1.  CP = channels padded to a multiple of 32 (48 -> 64,
+// zero columns in both tiles, zero weight columns).
+// LDS row pitch of a [rows][cp] bf16 tile: the smallest odd multiple of 32 bytes that holds a row (conflict-free
+// ds_read_b128 fragment reads, like the 96 / 160-byte pitches of csrc/gemm.hip)
+__host__ __device__ constexpr int dac_pitch(int cp) { return (((cp * 2 + 31) / 32) | 1) * 32; }
+constexpr int DAC_PATCH_FLOATS = 16 * 52;              // per wave: 48 columns + 4
+
+template <int C, int BM, int WR, int WC, int NS, int PF>
+__global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
+    typedef bf16_t T;
+    constexpr int E = 8, KB = 32, NF = 3, CP = (C + 31) / 32 * 32, PA = dac_pitch(CP);
+    constexpr int BMW = BM / WR, MF = BMW / 16;
+    constexpr int NK7 = 7 * CP / KB, NK1 = CP / KB;
+    constexpr bool PRECISE = NS > 1;
+    static_assert(WR * WC == 4 && WC * NF * 16 == C && NK7 % PF == 0 && NK1 % PF == 0, "wave grid / ring depth");
+    typedef std::conditional_t<NS == 1, bf16_t, float> TA;   // activation type in HBM
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d = p.dil, halo = 3 * d, rows_in = BM + 2 * halo;
+    const int PLA = rows_in * PA, PLM = BM * PA;       // bytes between the planes of a tile (split build)
+    char* ain = smem;                                  // [NS][BM + 6d][CP] snake_a0(x), rows t0 - 3d ..
+    char* mid = ain + NS * PLA;                        // [NS][BM][CP]
+    float* patch_all = reinterpret_cast<float*>(mid + NS * PLM);
+    float* prm = patch_all + 4 * DAC_PATCH_FLOATS;     // a0 | a2 | b7 | b1 | alpha_next, CP floats each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
+    const int wr = wave / WC, wc = wave % WC;
+    float* patch = patch_all + wave * DAC_PATCH_FLOATS;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM;
+    const int len = p.lens ? p.lens[b] : p.T;          // rows >= len are zero (conv padding of a shorter batch member)
+    const int lc = len > 0 ? len : 1;                  // clamp bound for addresses
+    const float* xb = p.x + (long)b * p.x_bs;
+
+    const T* w7 = reinterpret_cast<const T*>(p.w7) + (long)lane * E;
+    const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
+    const long ns7 = (long)NK7 * 64 * E, ns1 = (long)NK1 * 64 * E;
+    const T* w7_w = w7 + (long)(wc * NF) * ns7;
+    const T* w1_w = w1 + (long)(wc * NF) * ns1;
+    WRing<T, NF, PF> ring;
+    ring.prime(w7_w, ns7, NK7, NF);
+
+    for (int id = tid; id < 5 * CP; id += 256) {
+        const int v = id / CP, c = id - v * CP;
+        const float* src = v == 0 ? p.a0 : v == 1 ? p.a2 : v == 2 ? p.b7 : v == 3 ? p.b1 : p.alpha_next;
+        prm[id] = (c < C && src) ? src[c] : 0.f;
+    }
+    // ---- snake_a0(x) of the tile and its halo -> ain.  16-byte chunks of 4 channels; loads in batches (no branch around a
+    //      load: rows outside [0, len) are clamped and zeroed), alpha straight from global (L1 hits)
+    {
+        constexpr int CPR = CP / 4, U = 8;
+        const int total = rows_in * CPR;
+        for (int base = tid; base < total; base += U * 256) {
+            float4 v[U], al[U];
+            int off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = base + u * 256;
+                const int idc = id < total ? id : total - 1;
+                const int r = idc / CPR, ch = idc - r * CPR;
+                const int t = t0 - halo + r;
+                const bool ok = t >= 0 && t < len && ch * 4 < C;
+                const int tc = t < 0 ? 0 : (t < lc ? t : lc - 1);
+                const int cc = ch * 4 < C ? ch * 4 : 0;
+                v[u] = *reinterpret_cast<const float4*>(xb + (long)tc * C + cc);
+                al[u] = *reinterpret_cast<const float4*>(p.a0 + cc);
+                if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                off[u] = id < total ? r * PA + ch * 8 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (off[u] < 0) continue;
+                float o[4] = {snake_apply<PRECISE>(v[u].x, al[u].x), snake_apply<PRECISE>(v[u].y, al[u].y),
+                              snake_apply<PRECISE>(v[u].z, al[u].z), snake_apply<PRECISE>(v[u].w, al[u].w)};
+                uint2 hi;
+                hi.x = pack_bf16x2(o[0], o[1]);
+                hi.y = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<uint2*>(ain + off[u]) = hi;
+                if constexpr (NS > 1) {
+                    uint2 lo;
+                    lo.x = pack_bf16x2(o[0] - __uint_as_float(hi.x << 16), o[1] - __uint_as_float(hi.x & 0xffff0000u));
+                    lo.y = pack_bf16x2(o[2] - __uint_as_float(hi.y << 16), o[3] - __uint_as_float(hi.y & 0xffff0000u));
+                    *reinterpret_cast<uint2*>(ain + PLA + off[u]) = lo;
+                }
+            }
+        }
+        if constexpr (CP > C) {                        // zero the padded columns of mid (ain's were written as zeros above)
+            for (int id = tid; id < BM * (CP - C) / 4; id += 256) {
+                const int r = id / ((CP - C) / 4), ch = id % ((CP - C) / 4);
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) *reinterpret_cast<uint2*>(mid + s2 * PLM + r * PA + (C + ch * 4) * 2) = make_uint2(0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- conv k7, dilation d: rows wr*BMW .., columns wc*48 ..
+    {
+        float4_t acc[MF][NF];
+        zero_acc(acc);
+        stage_run<T, MF, NF, PF, NS, NF>(ring, ain + (wr * BMW + l16) * PA + g * 16, PA, CP / KB, w7_w, ns7, NK7, w1_w, ns1, NK1, NF, acc, PLA, d * PA);
+        // + bias -> LeakyReLU -> Snake(a2) -> mid (row layout through the wave's patch: 12 consecutive columns per lane)
+        const int col = wc * 48 + (lane & 3) * 12;
+        float b7[12], a2[12];
+        loadn<12>(prm + 2 * CP + col, b7);
+        loadn<12>(prm + 1 * CP + col, a2);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            float v[12];
+            to_rows<NF>(acc[i], patch, lane, v);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                float y = v[c] + b7[c];
+                y = y > 0.f ? y : y * p.slope;
+                v[c] = snake_apply<PRECISE>(y, a2[c]);
+            }
+            char* dst = mid + (wr * BMW + i * 16 + rl) * PA + col * 2;
+            uint2 h0, h1, h2;
+            h0.x = pack_bf16x2(v[0], v[1]); h0.y = pack_bf16x2(v[2], v[3]);
+            h1.x = pack_bf16x2(v[4], v[5]); h1.y = pack_bf16x2(v[6], v[7]);
+            h2.x = pack_bf16x2(v[8], v[9]); h2.y = pack_bf16x2(v[10], v[11]);
+            *reinterpret_cast<uint2*>(dst) = h0;
+            *reinterpret_cast<uint2*>(dst + 8) = h1;
+            *reinterpret_cast<uint2*>(dst + 16) = h2;
+            if constexpr (NS > 1) {
+                const unsigned w[6] = {h0.x, h0.y, h1.x, h1.y, h2.x, h2.y};
+                unsigned l[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    l[e] = pack_bf16x2(v[2 * e] - __uint_as_float(w[e] << 16), v[2 * e + 1] - __uint_as_float(w[e] & 0xffff0000u));
+                *reinterpret_cast<uint2*>(dst + PLM) = make_uint2(l[0], l[1]);
+                *reinterpret_cast<uint2*>(dst + PLM + 8) = make_uint2(l[2], l[3]);
+                *reinterpret_cast<uint2*>(dst + PLM + 16) = make_uint2(l[4], l[5]);
+            }
+        }
+    }
+    // residual rows of the closing epilogue (issued before the 1x1 stage: see est_tail_kernel on vmcnt order)
+    const int col = wc * 48 + (lane & 3) * 12;
+    float xr[MF][12];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int t = t0 + wr * BMW + i * 16 + rl;
+        loadn<12>(xb + (long)(t < lc ? t : lc - 1) * C + col, xr[i]);
+    }
+    __syncthreads();
+    // ---- conv k1 + bias -> LeakyReLU -> + x -> x_out [-> Snake(alpha_next) -> act_out]
+    {
+        float4_t acc[MF][NF];
+        zero_acc(acc);
+        stage_run<T, MF, NF, PF, NS, NF>(ring, mid + (wr * BMW + l16) * PA + g * 16, PA, NK1, w1_w, ns1, NK1, (const T*)nullptr, 0, 0, NF, acc, PLM);
+        float b1[12], an[12];
+        loadn<12>(prm + 3 * CP + col, b1);
+        loadn<12>(prm + 4 * CP + col, an);
+        float* xo = p.x_out + (long)b * p.x_bs;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            float v[12];
+            to_rows<NF>(acc[i], patch, lane, v);
+            const int t = t0 + wr * BMW + i * 16 + rl;
+            const bool live = t < len;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                float y = v[c] + b1[c];
+                y = y > 0.f ? y : y * p.slope;
+                v[c] = live ? y + xr[i][c] : 0.f;
+            }
+            if (t < p.T) {
+                storen<12>(xo + (long)t * C + col, v);
+                if (p.act_out) {
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) v[c] = snake_apply<PRECISE>(v[c], an[c]);
+                    TA* ao = reinterpret_cast<TA*>(p.act_out) + (long)b * p.x_bs + (long)t * C + col;
+                    if constexpr (NS == 1) {
+                        uint2 h0, h1, h2;
+                        h0.x = pack_bf16x2(v[0], v[1]); h0.y = pack_bf16x2(v[2], v[3]);
+                        h1.x = pack_bf16x2(v[4], v[5]); h1.y = pack_bf16x2(v[6], v[7]);
+                        h2.x = pack_bf16x2(v[8], v[9]); h2.y = pack_bf16x2(v[10], v[11]);
+                        *reinterpret_cast<uint2*>(ao) = h0;
+                        *reinterpret_cast<uint2*>(ao + 4) = h1;
+                        *reinterpret_cast<uint2*>(ao + 8) = h2;
+                    } else {
+                        storen<12>(reinterpret_cast<float*>(ao), v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int C, int BM, int NS>
+size_t dac_ru_lds(int dil) {
+    constexpr int CP = (C + 31) / 32 * 32, PA = dac_pitch(CP);
+    return (size_t)NS * ((size_t)(BM + 6 * dil) * PA + (size_t)BM * PA) + 4 * DAC_PATCH_FLOATS * 4 + 5 * CP * 4;
+}
+
 template <typename T, int BM, int NW, int NS = 1>
 size_t tail_lds() {
     return NS * ((size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T))) + (size_t)NW * PATCH_FLOATS * 4 + (size_t)BM * NW * 4 +
@@ -966,6 +1173,36 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     } else return MMX_EARG;
 #undef RESN
 #undef RESNN
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+extern "C" int mmx_dac_ru(const MmxDacRuParams* pp, int dtype, int bm, hipStream_t stream) {
+    MMX_CHECK_ARG(pp != nullptr);
+    const MmxDacRuParams& p = *pp;
+    MMX_CHECK_ARG(p.x && p.x_out && p.x != p.x_out && p.w7 && p.w1 && p.b7 && p.b1 && p.a0 && p.a2 && p.B > 0 && p.T > 0);
+    MMX_CHECK_ARG(p.dil >= 1 && p.dil <= 9 && (p.C == 48 || p.C == 96 || p.C == 192) && p.x_bs % 4 == 0 && p.x_bs >= (int64_t)p.T * p.C);
+    MMX_CHECK_ARG(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.x_out % 16) == 0 && ((uintptr_t)p.act_out % 16) == 0 && ((uintptr_t)p.a0 % 16) == 0);
+    MMX_CHECK_ARG(!p.act_out || p.alpha_next);
+    MMX_CHECK_ARG(dtype == MMX_BF16 || dtype == MMX_X2);
+#define DACRU(C_, BM_, WR_, WC_, NS_, PF_)                                                                 \
+    do {                                                                                                   \
+        const size_t lds = dac_ru_lds<C_, BM_, NS_>(p.dil);                                                \
+        MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
+        MMX_LDS_OPT_IN((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_>), lds);                                 \
+        hipLaunchKernelGGL((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_>), dim3((p.T + BM_ - 1) / BM_, p.B), dim3(256), lds, stream, p); \
+    } while (0)
+    // tile heights: the tallest the two LDS tiles (and, in the split build, their second planes) leave room for
+    if (dtype == MMX_BF16) {
+        if (p.C == 48) { if (bm == 0 || bm == 256) DACRU(48, 256, 4, 1, 1, 2); else if (bm == 128) DACRU(48, 128, 4, 1, 1, 2); else return MMX_EARG; }
+        else if (p.C == 96) { if (bm == 0 || bm == 256) DACRU(96, 256, 2, 2, 1, 3); else if (bm == 128) DACRU(96, 128, 2, 2, 1, 3); else return MMX_EARG; }
+        else { if (bm == 0 || bm == 128) DACRU(192, 128, 1, 4, 1, 2); else if (bm == 64) DACRU(192, 64, 1, 4, 1, 2); else return MMX_EARG; }
+    } else {
+        if (p.C == 48) { if (bm == 0 || bm == 128) DACRU(48, 128, 4, 1, 2, 2); else if (bm == 64) DACRU(48, 64, 4, 1, 2, 2); else return MMX_EARG; }
+        else if (p.C == 96) { if (bm == 0 || bm == 128) DACRU(96, 128, 2, 2, 2, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 2, 3); else return MMX_EARG; }
+        else { if (bm == 0 || bm == 32) DACRU(192, 32, 1, 4, 2, 2); else if (bm == 16) DACRU(192, 16, 1, 4, 2, 2); else return MMX_EARG; }
+    }
+#undef DACRU
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")
 SYMBOLS = [
     "mmx_abi_version", "mmx_gemm_win", "mmx_gemm_win_tile", "mmx_rownorm", "mmx_groupnorm", "mmx_act_rows", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
     "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_attn_flash_fp8", "mmx_attn_flash_x", "mmx_attn_flash_xs", "mmx_conv_cout1_tanh", "mmx_conv_cin1", "mmx_vae_sample",
-    "mmx_est_tail", "mmx_est_resnet", "mmx_debug_tail_stamps", "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_skinny2", "mmx_decode_prep", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_decode_attn", "mmx_swiglu", "mmx_sample_step",
+    "mmx_est_tail", "mmx_est_resnet", "mmx_debug_tail_stamps", "mmx_dac_ru", "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_skinny2", "mmx_decode_prep", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_decode_attn", "mmx_swiglu", "mmx_sample_step",
 ]
 
 
@@ -60,6 +60,11 @@ class EstResnetParams(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("a_in", "x", "w1", "w2", "wr", "b1", "g1", "be1", "b2", "g2", "be2", "br", "tv", "rowmask")] + \
                [(k, C.c_int64) for k in ("a_bs", "x_bs", "tv_bs", "rm_bs")] + \
                [(k, C.c_int32) for k in ("lda", "cin", "B", "T", "t_begin")] + [("eps", C.c_float), ("next", EstNext)]
+
+
+class DacRuParams(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x", "x_out", "act_out", "w7", "w1", "b7", "b1", "a0", "a2", "alpha_next", "lens")] + \
+               [("x_bs", C.c_int64)] + [(k, C.c_int32) for k in ("B", "T", "C", "dil")] + [("slope", C.c_float)]
 
 
 def fill_struct(st, **kw):

@@ -15,13 +15,17 @@ from typing import Dict, List
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT
+from ._lib import BF16, F32, TORCH_DT, X2
 
 
 class DacDecoderEngine:
+    FUSED_RU_MAX_C = 192          # ResidualUnits of at most this many channels run as ONE kernel (mmx_dac_ru: 48 / 96 / 192)
+
     def __init__(self, sd: Dict[str, torch.Tensor], rates: List[int], dtype=BF16, device="cuda", use_tanh=True,
-                 with_pre=True):
+                 with_pre=True, fuse_ru=True):
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        # the fused ResidualUnit kernel exists for the bf16 and split builds; the fp32 build keeps two GEMM launches per unit
+        self.fuse_ru = bool(fuse_ru) and dtype in (BF16, X2)
         self.rates = list(rates)
         self.hop = int(math.prod(rates))
         self.use_tanh = use_tanh
@@ -45,11 +49,16 @@ class DacDecoderEngine:
             wt = wn(q + ".1")                                   # [Cin, Cout, 2s]
             blk = dict(stride=s, cin=wt.shape[0], cout=wt.shape[1], alpha_in=alpha(q + ".0.alpha"),
                        wt=ops.pack_convtranspose1d(wt, s, dtype), bt=bias(q + ".1"), rus=[])
+            blk["fused"] = self.fuse_ru and blk["cout"] in (48, 96, 192) and blk["cout"] <= self.FUSED_RU_MAX_C
             for j, d in enumerate((1, 3, 9)):
                 r = f"{q}.{2 + j}.block"
-                blk["rus"].append(dict(dil=d, a0=alpha(r + ".0.alpha"), w7=ops.pack_conv1d(wn(r + ".1.0"), dtype),
-                                       b7=bias(r + ".1.0"), a2=alpha(r + ".2.alpha"),
-                                       w1=ops.pack_conv1d(wn(r + ".3.0"), dtype), b1=bias(r + ".3.0")))
+                w7, w1 = wn(r + ".1.0"), wn(r + ".3.0")
+                ru = dict(dil=d, a0=alpha(r + ".0.alpha"), b7=bias(r + ".1.0"), a2=alpha(r + ".2.alpha"), b1=bias(r + ".3.0"))
+                if blk["fused"]:
+                    ru["w7_p"], ru["w1_p"] = ops.pack_dac_ru(w7, w1, dtype)
+                else:
+                    ru["w7"], ru["w1"] = ops.pack_conv1d(w7, dtype), ops.pack_conv1d(w1, dtype)
+                blk["rus"].append(ru)
             self.blocks.append(blk)
         self.alpha_final = alpha(f"{p}.{n + 1}.alpha")
         wf = wn(f"{p}.{n + 2}.0")                                # [1, C, 7]
@@ -101,6 +110,19 @@ class DacDecoderEngine:
             s, cin, cout = blk["stride"], blk["cin"], blk["cout"]
             T2 = T * s
             x = new(T2, cout, torch.float32)
+            if blk["fused"]:
+                # one kernel per ResidualUnit: the fp32 residual stream is all that passes between them; the last unit also
+                # writes the next layer's input activation
+                ops.convtranspose1d(a, blk["wt"], T=T, Cin=cin, Cout=cout, stride=s, dtype=dt, batch=B, bias=blk["bt"], out_f32=x)
+                T = T2
+                nxt = self.blocks[bi + 1]["alpha_in"] if bi + 1 < len(self.blocks) else self.alpha_final
+                for j, ru in enumerate(blk["rus"]):
+                    last = j == 2
+                    x2 = new(T, cout, torch.float32)
+                    a = new(T, cout) if last else None
+                    ops.dac_ru(x, x2, ru, B=B, T=T, C_=cout, dil=ru["dil"], dtype=dt, act_out=a, alpha_next=(nxt if last else None))
+                    x = x2
+                continue
             a2 = new(T2, cout)
             ops.convtranspose1d(a, blk["wt"], T=T, Cin=cin, Cout=cout, stride=s, dtype=dt, batch=B, bias=blk["bt"],
                                 alpha=blk["rus"][0]["a0"], out_f32=x, out_act=a2)

@@ -193,6 +193,28 @@ def est_resnet(a_in, lda, cin, x, r, tv, tv_bs, *, B, T, dtype, bm, rowmask=None
     check(load().mmx_est_resnet(C.byref(p), C.c_int(dtype), C.c_int(bm), C.c_int(pf + 16 * waves), stream()), "mmx_est_resnet")
 
 
+# ----------------------------------------------------------------------------- fused DAC ResidualUnit
+def pack_dac_ru(w7: torch.Tensor, w1: torch.Tensor, dtype):
+    """ResidualUnit conv weights [C, C, 7] and [C, C, 1] (weight norm folded) -> fragment-ordered packs for mmx_dac_ru:
+    [C][7 * CP] tap-major with each tap's input channels zero-padded to CP = 32 * ceil(C / 32), and [C][CP]."""
+    C_ = w7.shape[0]
+    CP = (C_ + 31) // 32 * 32
+    wd = L.WEIGHT_DT[dtype]
+    a = torch.zeros(C_, 7, CP, dtype=torch.float32, device=w7.device)
+    a[:, :, :C_] = w7.permute(0, 2, 1)
+    b = torch.zeros(C_, CP, dtype=torch.float32, device=w7.device)
+    b[:, :C_] = w1[:, :, 0]
+    return (pack_skinny(a.reshape(C_, 7 * CP).to(wd).contiguous(), dtype=dtype), pack_skinny(b.to(wd).contiguous(), dtype=dtype))
+
+
+def dac_ru(x, x_out, ru, *, B, T, C_, dil, dtype, act_out=None, alpha_next=None, lens=None, bm=0, slope=0.1, x_bs=None):
+    """ru: dict with w7_p / w1_p (pack_dac_ru), b7 / b1 / a0 / a2 (mmx/dac.py).  include/mmx_hip.h: mmx_dac_ru."""
+    p = L.fill_struct(L.DacRuParams(), x=x, x_out=x_out, act_out=act_out, w7=ru["w7_p"], w1=ru["w1_p"], b7=ru["b7"], b1=ru["b1"],
+                      a0=ru["a0"], a2=ru["a2"], alpha_next=alpha_next, lens=lens, x_bs=(T * C_ if x_bs is None else x_bs),
+                      B=B, T=T, C=C_, dil=dil, slope=slope)
+    check(load().mmx_dac_ru(C.byref(p), C.c_int(dtype), C.c_int(bm), stream()), "mmx_dac_ru")
+
+
 # ----------------------------------------------------------------------------- attention
 def attn_dense(q, k, v, out, *, B, H, Tq, Tk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, dtype,
                keymask=None, chunk=0, pos=None, ldp=0, pos_u=None, pos_v=None, head_stride=0, q_begin=0, km_bs=None):
