@@ -830,7 +830,12 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
     char* ain = smem;                                  // [NS][BM + 6d][CP] snake_a0(x), rows t0 - 3d ..
     char* mid = ain + NS * PLA;                        // [NS][BM][CP]
     float* patch_all = reinterpret_cast<float*>(mid + NS * PLM);
-    float* prm = patch_all + 4 * DAC_PATCH_FLOATS;     // a0 | a2 | b7 | b1 | alpha_next, CP floats each
+    float* prm = patch_all + 4 * DAC_PATCH_FLOATS;     // a0 | a2 | b7 | b1 | alpha_next | 1/(a0+1e-9) | 1/(a2+..) | 1/(alpha_next+..)
+    // Snake with the reciprocal taken once per channel: the same operations as snake_apply (layers.py:22), in the same order
+    auto snk = [](float x, float alpha, float inv) {
+        const float sn = PRECISE ? sinf(alpha * x) : __sinf(alpha * x);
+        return x + inv * (sn * sn);
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
     const int wr = wave / WC, wc = wave % WC;
@@ -848,19 +853,21 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
     WRing<T, NF, PF> ring;
     ring.prime(w7_w, ns7, NK7, NF);
 
-    for (int id = tid; id < 5 * CP; id += 256) {
+    for (int id = tid; id < 8 * CP; id += 256) {
         const int v = id / CP, c = id - v * CP;
-        const float* src = v == 0 ? p.a0 : v == 1 ? p.a2 : v == 2 ? p.b7 : v == 3 ? p.b1 : p.alpha_next;
-        prm[id] = (c < C && src) ? src[c] : 0.f;
+        const float* src = v == 0 ? p.a0 : v == 1 ? p.a2 : v == 2 ? p.b7 : v == 3 ? p.b1 : v == 4 ? p.alpha_next : v == 5 ? p.a0 : v == 6 ? p.a2 : p.alpha_next;
+        const float val = (c < C && src) ? src[c] : 0.f;
+        prm[id] = v < 5 ? val : 1.0f / (val + 1e-9f);
     }
-    // ---- snake_a0(x) of the tile and its halo -> ain.  16-byte chunks of 4 channels; loads in batches (no branch around a
-    //      load: rows outside [0, len) are clamped and zeroed), alpha straight from global (L1 hits)
+    __syncthreads();
+    // ---- snake_a0(x) of the tile and its halo -> ain.  16-byte chunks of 4 channels; loads in batches of U (no branch around
+    //      a load: rows outside [0, len) are clamped and zeroed) - every batch is one HBM round trip for the whole workgroup
     {
-        constexpr int CPR = CP / 4, U = 8;
+        constexpr int CPR = CP / 4, U = 16;
         const int total = rows_in * CPR;
         for (int base = tid; base < total; base += U * 256) {
-            float4 v[U], al[U];
-            int off[U];
+            float4 v[U];
+            int off[U], cch[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int id = base + u * 256;
@@ -871,15 +878,16 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
                 const int tc = t < 0 ? 0 : (t < lc ? t : lc - 1);
                 const int cc = ch * 4 < C ? ch * 4 : 0;
                 v[u] = *reinterpret_cast<const float4*>(xb + (long)tc * C + cc);
-                al[u] = *reinterpret_cast<const float4*>(p.a0 + cc);
                 if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 off[u] = id < total ? r * PA + ch * 8 : -1;
+                cch[u] = ch * 4;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (off[u] < 0) continue;
-                float o[4] = {snake_apply<PRECISE>(v[u].x, al[u].x), snake_apply<PRECISE>(v[u].y, al[u].y),
-                              snake_apply<PRECISE>(v[u].z, al[u].z), snake_apply<PRECISE>(v[u].w, al[u].w)};
+                const float4_t al = *reinterpret_cast<const float4_t*>(prm + cch[u]);     // a0 (zero in the padded columns)
+                const float4_t iv = *reinterpret_cast<const float4_t*>(prm + 5 * CP + cch[u]);
+                float o[4] = {snk(v[u].x, al[0], iv[0]), snk(v[u].y, al[1], iv[1]), snk(v[u].z, al[2], iv[2]), snk(v[u].w, al[3], iv[3])};
                 uint2 hi;
                 hi.x = pack_bf16x2(o[0], o[1]);
                 hi.y = pack_bf16x2(o[2], o[3]);
@@ -908,9 +916,10 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
         stage_run<T, MF, NF, PF, NS, NF>(ring, ain + (wr * BMW + l16) * PA + g * 16, PA, CP / KB, w7_w, ns7, NK7, w1_w, ns1, NK1, NF, acc, PLA, d * PA);
         // + bias -> LeakyReLU -> Snake(a2) -> mid (row layout through the wave's patch: 12 consecutive columns per lane)
         const int col = wc * 48 + (lane & 3) * 12;
-        float b7[12], a2[12];
+        float b7[12], a2[12], i2[12];
         loadn<12>(prm + 2 * CP + col, b7);
         loadn<12>(prm + 1 * CP + col, a2);
+        loadn<12>(prm + 6 * CP + col, i2);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[12];
@@ -919,7 +928,7 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
             for (int c = 0; c < 12; ++c) {
                 float y = v[c] + b7[c];
                 y = y > 0.f ? y : y * p.slope;
-                v[c] = snake_apply<PRECISE>(y, a2[c]);
+                v[c] = snk(y, a2[c], i2[c]);
             }
             char* dst = mid + (wr * BMW + i * 16 + rl) * PA + col * 2;
             uint2 h0, h1, h2;
@@ -955,9 +964,10 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
         float4_t acc[MF][NF];
         zero_acc(acc);
         stage_run<T, MF, NF, PF, NS, NF>(ring, mid + (wr * BMW + l16) * PA + g * 16, PA, NK1, w1_w, ns1, NK1, (const T*)nullptr, 0, 0, NF, acc, PLM);
-        float b1[12], an[12];
+        float b1[12], an[12], in[12];
         loadn<12>(prm + 3 * CP + col, b1);
         loadn<12>(prm + 4 * CP + col, an);
+        loadn<12>(prm + 7 * CP + col, in);
         float* xo = p.x_out + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -975,7 +985,7 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
                 storen<12>(xo + (long)t * C + col, v);
                 if (p.act_out) {
 #pragma unroll
-                    for (int c = 0; c < 12; ++c) v[c] = snake_apply<PRECISE>(v[c], an[c]);
+                    for (int c = 0; c < 12; ++c) v[c] = snk(v[c], an[c], in[c]);
                     TA* ao = reinterpret_cast<TA*>(p.act_out) + (long)b * p.x_bs + (long)t * C + col;
                     if constexpr (NS == 1) {
                         uint2 h0, h1, h2;
@@ -997,7 +1007,7 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
 template <int C, int BM, int NS>
 size_t dac_ru_lds(int dil) {
     constexpr int CP = (C + 31) / 32 * 32, PA = dac_pitch(CP);
-    return (size_t)NS * ((size_t)(BM + 6 * dil) * PA + (size_t)BM * PA) + 4 * DAC_PATCH_FLOATS * 4 + 5 * CP * 4;
+    return (size_t)NS * ((size_t)(BM + 6 * dil) * PA + (size_t)BM * PA) + 4 * DAC_PATCH_FLOATS * 4 + 8 * CP * 4;
 }
 
 template <typename T, int BM, int NW, int NS = 1>
@@ -1192,14 +1202,15 @@ extern "C" int mmx_dac_ru(const MmxDacRuParams* pp, int dtype, int bm, hipStream
         MMX_LDS_OPT_IN((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_>), lds);                                 \
         hipLaunchKernelGGL((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_>), dim3((p.T + BM_ - 1) / BM_, p.B), dim3(256), lds, stream, p); \
     } while (0)
-    // tile heights: the tallest the two LDS tiles (and, in the split build, their second planes) leave room for
+    // tile heights: default = the measured best of tools/dac_lab.py for (C, dtype); smaller tiles let two workgroups share a
+    // CU (LDS, 256 registers), which overlaps one's load / epilogue phases with the other's MFMA stages
     if (dtype == MMX_BF16) {
-        if (p.C == 48) { if (bm == 0 || bm == 256) DACRU(48, 256, 4, 1, 1, 2); else if (bm == 128) DACRU(48, 128, 4, 1, 1, 2); else return MMX_EARG; }
-        else if (p.C == 96) { if (bm == 0 || bm == 256) DACRU(96, 256, 2, 2, 1, 3); else if (bm == 128) DACRU(96, 128, 2, 2, 1, 3); else return MMX_EARG; }
-        else { if (bm == 0 || bm == 128) DACRU(192, 128, 1, 4, 1, 2); else if (bm == 64) DACRU(192, 64, 1, 4, 1, 2); else return MMX_EARG; }
+        if (p.C == 48) { if (bm == 0 || bm == 256) DACRU(48, 256, 4, 1, 1, 2); else if (bm == 128) DACRU(48, 128, 4, 1, 1, 2); else if (bm == 64) DACRU(48, 64, 4, 1, 1, 2); else return MMX_EARG; }
+        else if (p.C == 96) { if (bm == 0 || bm == 256) DACRU(96, 256, 2, 2, 1, 3); else if (bm == 128) DACRU(96, 128, 2, 2, 1, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 1, 3); else return MMX_EARG; }
+        else { if (bm == 0 || bm == 128) DACRU(192, 128, 1, 4, 1, 2); else if (bm == 64) DACRU(192, 64, 1, 4, 1, 2); else if (bm == 32) DACRU(192, 32, 1, 4, 1, 2); else return MMX_EARG; }
     } else {
         if (p.C == 48) { if (bm == 0 || bm == 128) DACRU(48, 128, 4, 1, 2, 2); else if (bm == 64) DACRU(48, 64, 4, 1, 2, 2); else return MMX_EARG; }
-        else if (p.C == 96) { if (bm == 0 || bm == 128) DACRU(96, 128, 2, 2, 2, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 2, 3); else return MMX_EARG; }
+        else if (p.C == 96) { if (bm == 0 || bm == 128) DACRU(96, 128, 2, 2, 2, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 2, 3); else if (bm == 32) DACRU(96, 32, 2, 2, 2, 3); else return MMX_EARG; }
         else { if (bm == 0 || bm == 32) DACRU(192, 32, 1, 4, 2, 2); else if (bm == 16) DACRU(192, 16, 1, 4, 2, 2); else return MMX_EARG; }
     }
 #undef DACRU
