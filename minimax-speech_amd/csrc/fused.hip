@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
     float* prm = patch_all + 4 * DAC_PATCH_FLOATS;     // a0 | a2 | b7 | b1 | alpha_next | 1/(a0+1e-9) | 1/(a2+..) | 1/(alpha_next+..)
     // Snake with the reciprocal taken once per channel: the same operations as snake_apply (layers.py:22), in the same order
     auto snk = [](float x, float alpha, float inv) {
-        const float sn = PRECISE ? sinf(alpha * x) : __sinf(alpha * x);
+        const float sn = PRECISE ? sin_cw(alpha * x) : __sinf(alpha * x);
         return x + inv * (sn * sn);
     };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1205,9 +1205,9 @@ extern "C" int mmx_dac_ru(const MmxDacRuParams* pp, int dtype, int bm, hipStream
     // tile heights: default = the measured best of tools/dac_lab.py for (C, dtype); smaller tiles let two workgroups share a
     // CU (LDS, 256 registers), which overlaps one's load / epilogue phases with the other's MFMA stages
     if (dtype == MMX_BF16) {
-        if (p.C == 48) { if (bm == 0 || bm == 256) DACRU(48, 256, 4, 1, 1, 2); else if (bm == 128) DACRU(48, 128, 4, 1, 1, 2); else if (bm == 64) DACRU(48, 64, 4, 1, 1, 2); else return MMX_EARG; }
+        if (p.C == 48) { if (bm == 256) DACRU(48, 256, 4, 1, 1, 2); else if (bm == 0 || bm == 128) DACRU(48, 128, 4, 1, 1, 2); else if (bm == 64) DACRU(48, 64, 4, 1, 1, 2); else return MMX_EARG; }
         else if (p.C == 96) { if (bm == 0 || bm == 256) DACRU(96, 256, 2, 2, 1, 3); else if (bm == 128) DACRU(96, 128, 2, 2, 1, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 1, 3); else return MMX_EARG; }
-        else { if (bm == 0 || bm == 128) DACRU(192, 128, 1, 4, 1, 2); else if (bm == 64) DACRU(192, 64, 1, 4, 1, 2); else if (bm == 32) DACRU(192, 32, 1, 4, 1, 2); else return MMX_EARG; }
+        else { if (bm == 0) bm = p.dil > 3 ? 32 : 64; if (bm == 128) DACRU(192, 128, 1, 4, 1, 2); else if (bm == 64) DACRU(192, 64, 1, 4, 1, 2); else if (bm == 32) DACRU(192, 32, 1, 4, 1, 2); else return MMX_EARG; }
     } else {
         if (p.C == 48) { if (bm == 0 || bm == 128) DACRU(48, 128, 4, 1, 2, 2); else if (bm == 64) DACRU(48, 64, 4, 1, 2, 2); else return MMX_EARG; }
         else if (p.C == 96) { if (bm == 0 || bm == 128) DACRU(96, 128, 2, 2, 2, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 2, 3); else if (bm == 32) DACRU(96, 32, 2, 2, 2, 3); else return MMX_EARG; }
