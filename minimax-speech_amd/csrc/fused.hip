@@ -1209,8 +1209,8 @@ extern "C" int mmx_dac_ru(const MmxDacRuParams* pp, int dtype, int bm, hipStream
         else if (p.C == 96) { if (bm == 0 || bm == 256) DACRU(96, 256, 2, 2, 1, 3); else if (bm == 128) DACRU(96, 128, 2, 2, 1, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 1, 3); else return MMX_EARG; }
         else { if (bm == 0) bm = p.dil > 3 ? 32 : 64; if (bm == 128) DACRU(192, 128, 1, 4, 1, 2); else if (bm == 64) DACRU(192, 64, 1, 4, 1, 2); else if (bm == 32) DACRU(192, 32, 1, 4, 1, 2); else return MMX_EARG; }
     } else {
-        if (p.C == 48) { if (bm == 0 || bm == 128) DACRU(48, 128, 4, 1, 2, 2); else if (bm == 64) DACRU(48, 64, 4, 1, 2, 2); else return MMX_EARG; }
-        else if (p.C == 96) { if (bm == 0 || bm == 128) DACRU(96, 128, 2, 2, 2, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 2, 3); else if (bm == 32) DACRU(96, 32, 2, 2, 2, 3); else return MMX_EARG; }
+        if (p.C == 48) { if (bm == 128) DACRU(48, 128, 4, 1, 2, 2); else if (bm == 0 || bm == 64) DACRU(48, 64, 4, 1, 2, 2); else return MMX_EARG; }
+        else if (p.C == 96) { if (bm == 0) bm = p.dil > 3 ? 128 : 64; if (bm == 128) DACRU(96, 128, 2, 2, 2, 3); else if (bm == 64) DACRU(96, 64, 2, 2, 2, 3); else if (bm == 32) DACRU(96, 32, 2, 2, 2, 3); else return MMX_EARG; }
         else { if (bm == 0 || bm == 32) DACRU(192, 32, 1, 4, 2, 2); else if (bm == 16) DACRU(192, 16, 1, 4, 2, 2); else return MMX_EARG; }
     }
 #undef DACRU
