@@ -299,12 +299,15 @@ def _time_steps(fn, build, warmup, steps):
 
 
 ATTN = "bf16"
+GROUP_FAN = None
 
 
 def make_engine(dt, device, max_batch, max_ctx):
     """The engine under test (full-size synthetic weights).  A function of its own so that the 2-rank CPU rehearsal of
     this script's launch / shard / barrier / gather contract can substitute a stub (tests/test_cpu_host.py)."""
     from mmx.pipeline import TtsEngine
+    if GROUP_FAN is not None:
+        TtsEngine.group_fan = GROUP_FAN
     return TtsEngine(*build_weights(0), dtype=dt, device=device, max_batch=max_batch, max_ctx=max_ctx, attn=ATTN)
 
 
@@ -323,6 +326,7 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
+    ap.add_argument("--group-fan", type=int, default=None, help="auxiliary streams per flow group for its per-utterance stages (TtsEngine.group_fan)")
     ap.add_argument("--pad-ratio", type=float, default=2.0, help="max length ratio inside one flow group")
     ap.add_argument("--flow-workers", type=int, default=2, help="host threads / streams solving flow groups concurrently")
     ap.add_argument("--poll-every", type=int, default=8, help="decode steps between two polls of the finished flags")
@@ -333,8 +337,8 @@ def main():
     ap.add_argument("--tail-active", type=int, default=0, help="with at most this many sequences still decoding, finished utterances go to an idle flow worker at once")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
-    global ATTN
-    ATTN = a.attn
+    global ATTN, GROUP_FAN
+    ATTN, GROUP_FAN = a.attn, a.group_fan
     if a.gqa_min_batch is not None:
         from mmx.llm import LlmEngine
         LlmEngine.gqa_min_batch = a.gqa_min_batch

@@ -49,6 +49,16 @@ class TtsEngine:
         self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device)
         self.hop = self.dac.hop
 
+    group_fan = 3      # auxiliary streams per flow group for its per-utterance stages (conformer encoder, DAC decode); 1 = off
+
+    def _aux_streams(self, cur, n):
+        """n auxiliary streams belonging to the stream `cur` (one set per flow worker stream; created once)."""
+        pool = self.__dict__.setdefault("_aux", {})
+        key = cur.cuda_stream
+        if key not in pool or len(pool[key]) < n:
+            pool[key] = [torch.cuda.Stream(device=self.dev, priority=0) for _ in range(n)]
+        return pool[key][:n]
+
     def close(self):
         """Destroys every recorded hipGraph of the engines on the calling thread (deterministic teardown: nothing is left
         for Python's cyclic collector to finalise later on whatever thread it happens to run)."""
@@ -273,17 +283,58 @@ class TtsEngine:
                 torch.cuda.current_stream().synchronize()
                 marks.append(time.perf_counter())
 
+        # The conformer encoder and the DAC decode are per utterance: chains of ~100 / ~30 launches, most of them too small to
+        # fill the chip.  The utterances of a group are independent there, so each goes to one of `fan` auxiliary streams
+        # (forked from / joined into the group's stream with events); the batched ODE solve between them stays on the group's
+        # stream.  fan = 1: everything on the group's stream.
+        cur = torch.cuda.current_stream()
+        fan = min(self.group_fan, len(grp))
+        aux = self._aux_streams(cur, fan) if fan > 1 else []
+
+        def fanned(jobs):
+            """jobs: callables, one per utterance; run on the auxiliary streams round robin, joined before returning."""
+            if not aux:
+                return [j() for j in jobs]
+            ev0 = torch.cuda.Event()
+            ev0.record(cur)
+            out = []
+            for i, j in enumerate(jobs):
+                st = aux[i % fan]
+                st.wait_event(ev0)
+                with torch.cuda.stream(st):
+                    out.append(j())
+            for st in aux:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                cur.wait_event(ev)
+            for o in out:                                    # results live on after this call, on other streams
+                for t in (o if isinstance(o, tuple) else (o,)):
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(cur)
+            return out
+
         mark()
-        conds = [flow.conditions(toks[b].reshape(1, -1), pr(b)[0], pr(b)[1], embs[b]) for b in grp]
+        conds = fanned([(lambda b=b: flow.conditions(toks[b].reshape(1, -1), pr(b)[0], pr(b)[1], embs[b])) for b in grp])
         mark()
         xs = flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
         mark()
-        for b, lat, c in zip(grp, xs, conds):
+
+        def dac_job(b, lat, c):
             lat = lat[c[3]:]                                 # the prompt's frames are not rendered (flow.py:509)
             T2 = lat.shape[0]
             zt = torch.empty(1, T2, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
             ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
-            wavs[b] = self.dac.decode_time_major(zt, 1, T2)
+            return self.dac.decode_time_major(zt, 1, T2)
+
+        for b, w in zip(grp, fanned([(lambda b=b, lat=lat, c=c: dac_job(b, lat, c)) for b, lat, c in zip(grp, xs, conds)])):
+            wavs[b] = w
+        if aux:
+            # blocks the auxiliary streams allocated (and this function's temporaries freed there) go back to THEIR pools:
+            # nothing on them may be reused before the group's stream has finished reading it
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            for st in aux:
+                st.wait_event(ev)
         mark()
         if trace:
             e, c, d = ((marks[i + 1] - marks[i]) * 1e3 for i in range(3))

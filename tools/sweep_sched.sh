@@ -9,6 +9,13 @@ run() {
   t=$(grep "LM loop done" $out/$name.err $out/$name.json | tail -1 | sed 's/.*LM loop done at/LM/; s/, decode steps.*//')
   echo "$name: $v | $t" | tee -a $out/sweep.txt
 }
+if [ "$3" = "fan" ]; then
+  run fan3
+  run fan1 --group-fan 1
+  run fan2 --group-fan 2
+  run fan4 --group-fan 4
+  exit 0
+fi
 run base
 run nopolite --no-polite
 run hold40 --hold-steps 40
