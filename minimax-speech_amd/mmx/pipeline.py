@@ -49,7 +49,10 @@ class TtsEngine:
         self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device)
         self.hop = self.dac.hop
 
-    group_fan = 3      # auxiliary streams per flow group for its per-utterance stages (conformer encoder, DAC decode); 1 = off
+    # auxiliary streams per flow group for its per-utterance stages (conformer encoder, DAC decode); 1 = off.  Off by default:
+    # measured on the config-4 rank share, 2 / 3 / 4 streams cost 15 % / 13 % / 32 % of the step (more queues beside the decode
+    # loop slow its launches more than the per-utterance stages gain); useful only without a decode loop alongside
+    group_fan = 1
 
     def _aux_streams(self, cur, n):
         """n auxiliary streams belonging to the stream `cur` (one set per flow worker stream; created once)."""

@@ -9,6 +9,13 @@ run() {
   t=$(grep "LM loop done" $out/$name.err $out/$name.json | tail -1 | sed 's/.*LM loop done at/LM/; s/, decode steps.*//')
   echo "$name: $v | $t" | tee -a $out/sweep.txt
 }
+if [ "$3" = "w1" ]; then
+  run base
+  run workers1 --flow-workers 1
+  run workers1_np --flow-workers 1 --no-polite
+  run workers1_h30 --flow-workers 1 --hold-steps 30
+  exit 0
+fi
 if [ "$3" = "fan" ]; then
   run fan3
   run fan1 --group-fan 1
