@@ -1,9 +1,10 @@
 #!/bin/bash
 # Round-3 profile collection on the GPU box.  Kernel stats (rocprofv3 --kernel-trace --stats) of the default bench (bf16), of
-# the split build's bench, of the decode loop alone (both builds) and of an isolated batched CFM solve (both builds); PMC passes
-# (one counter set per pass, no trace domains next to --pmc) over the decode loop (HBM bytes of the projection kernels) and
-# over the CFM solve (HBM bytes, MFMA busy, LDS conflicts of the flow kernels).  Output under gpurun_out/$1; the summaries
-# judged are copied into profiles/ afterwards.
+# the split build's bench, of the decode loop alone (both builds), of an isolated batched CFM solve (both builds) and of the DAC
+# decoder; PMC passes (one counter set per pass, no trace domains next to --pmc) over eager decode steps (HBM bytes of the
+# projection / attention kernels; counters are not collected for kernels replayed from a hipGraph), over the CFM solve (HBM
+# bytes, MFMA busy, LDS conflicts of the flow kernels) and over the DAC decoder (HBM bytes).  Output under gpurun_out/$1; the
+# summaries judged are copied into profiles/ afterwards.
 out=gpurun_out/${1:-r3p}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -29,8 +30,9 @@ kstats cfm8x896 python3 tools/prof_cfm.py 8 896 bf16 &&
 kstats cfm8x896_x python3 tools/prof_cfm.py 8 896 x &&
 kstats dac python3 tools/prof_dac.py &&
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
-    pmc decode_bf16_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/decode_alone.py --dtype bf16 --steps 1 || exit 1
-    pmc decode_x_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/decode_alone.py --dtype x --steps 1 || exit 1
+    pmc decode_bf16_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/prof_decode.py bf16 8 || exit 1
+    pmc decode_x_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/prof_decode.py x 8 || exit 1
+    pmc dac_$c "$c" "gemm_win dac_ru conv_cout1" python3 tools/prof_dac.py || exit 1
 done
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16" "FETCH_SIZE" "WRITE_SIZE"; do
@@ -38,4 +40,4 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
     pmc cfm_$n "$c" "est_tail est_resnet attn_flash gemm_win rownorm" python3 tools/prof_cfm.py 8 896 bf16 || exit 1
     pmc cfmx_$n "$c" "est_tail est_resnet attn_flash gemm_win rownorm" python3 tools/prof_cfm.py 8 896 x || exit 1
 done
-cat $out/pmc_*.txt | head -200
+ls $out
