@@ -459,6 +459,251 @@ __global__ __launch_bounds__(64 * NW) void attn_flash_kernel(
 }
 
 
+// ------------------------------------------------------------------------------------------ flash with the ESPnet rel-pos term
+// Conformer encoder attention (speech/cosyvoice/transformer/attention.py:215-330, RelPositionMultiHeadedAttention) on the
+// MFMA, bf16 build:   score(i, j) = ((q_i + u) . k_j + (q_i + v) . p[T - 1 - i + j]) * scale,   p = linear_pos(pos_emb), 2T - 1 rows
+// (rel_shift folded into the index, as attn_dense_kernel does).  Same transposed flash scheme as attn_flash_kernel, 16
+// queries per wave: per 64-key tile the positions a wave needs are the 79 rows p[mbase ..], mbase = T - 1 - (qb + 15) + j0,
+// so BD^T = P_window (Q + v)^T is five more 16x16x32 MFMA pairs (A = the window rows, read from global two tiles ahead into
+// registers, B = the q + v fragment); lane (query l16) then needs BD^T[jj + 15 - l16] for its keys jj - a per-lane shift
+// of the row index, done through the wave's LDS patch (float4 writes [query][80 positions], four dword reads per key
+// fragment).  The patch is reused for P afterwards.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
+    const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
+    const bf16_t* __restrict__ vt, long ldvt, long vt_bs, const bf16_t* __restrict__ pos, long ldp,
+    const float* __restrict__ pos_u, const float* __restrict__ pos_v, bf16_t* __restrict__ out, long ldo, long o_bs,
+    int Tn, float scale, int chunk, int nq, int nheads, int npairs) {
+    constexpr int D = 64, KT = 64, LDK = 80, LD = 72, BW = 84;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KT * LDK];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][D * LDK];
+    __shared__ __attribute__((aligned(16))) float Bp[NW][16 * BW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / nq) * 8 + xcd;
+    if (pair >= npairs) return;
+    const int qt = slot % nq;
+    const int b = pair / nheads, h = pair % nheads;
+    const int qb = qt * (NW * 16) + wave * 16;
+    q += (long)b * q_bs + h * D;
+    k += (long)b * k_bs + h * D;
+    vt += (long)b * vt_bs + (long)h * D * ldvt;
+    out += (long)b * o_bs + h * D;
+    pos += h * D;
+    const float sc2 = scale * 1.44269504088896341f;
+
+    short8_t aqu[2], aqv[2];                           // lane (q = l16, k-group g): (q + u), (q + v) [ks*32 + 8g .. +7]
+    {
+        int row = qb + l16;
+        row = row < Tn ? row : Tn - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(q + (long)row * ldq + ks * 32 + 8 * g);
+            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+            const float* pu = pos_u + h * D + ks * 32 + 8 * g;
+            const float* pv = pos_v + h * D + ks * 32 + 8 * g;
+            unsigned ou[4], ov[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = __uint_as_float(w[e] << 16), x1 = __uint_as_float(w[e] & 0xffff0000u);
+                ou[e] = pack_bf16x2(x0 + pu[2 * e], x1 + pu[2 * e + 1]);
+                ov[e] = pack_bf16x2(x0 + pv[2 * e], x1 + pv[2 * e + 1]);
+            }
+            aqu[ks] = __builtin_bit_cast(short8_t, make_uint4(ou[0], ou[1], ou[2], ou[3]));
+            aqv[ks] = __builtin_bit_cast(short8_t, make_uint4(ov[0], ov[1], ov[2], ov[3]));
+        }
+    }
+    float4_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    int lim = Tn;
+    if (chunk > 0) { const int c2 = ((qb + l16) / chunk + 1) * chunk; lim = c2 < lim ? c2 : lim; }
+    int kend = Tn;
+    if (chunk > 0) {
+        int qlast = qt * (NW * 16) + NW * 16 - 1;
+        if (qlast > Tn - 1) qlast = Tn - 1;
+        const int e = (qlast / chunk + 1) * chunk;
+        if (e < kend) kend = e;
+    }
+    const int ntile = (kend + KT - 1) / KT;
+    int vis_all = Tn;
+    if (chunk > 0) {
+        const int e = ((qt * (NW * 16)) / chunk + 1) * chunk;
+        if (e < vis_all) vis_all = e;
+    }
+    float* Bw = Bp[wave];
+    bf16_t* Pw = reinterpret_cast<bf16_t*>(Bw);
+
+    uint4 kreg[512 / (64 * NW)], vreg[512 / (64 * NW)];
+    auto load_tiles = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < 512 / (64 * NW); ++i) {
+            const int id = tid + i * 64 * NW;
+            const int r = id >> 3, c = (id & 7) * 8;
+            const int key = j0 + r;
+            kreg[i] = key < Tn ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
+            vreg[i] = (j0 + c < Tn) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 512 / (64 * NW); ++i) {
+            const int id = tid + i * 64 * NW;
+            const int r = id >> 3, c = (id & 7) * 8;
+            *reinterpret_cast<uint4*>(Ks[buf] + r * LDK + c) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs[buf] + r * LDK + c) = vreg[i];
+        }
+    };
+    // the position window of tile j0: rows mbase + f*16 + l16 (clamped: rows outside [0, 2T-2] only meet masked pairs)
+    short8_t pw[5][2];
+    const int prow_max = 2 * Tn - 2;
+    auto load_window = [&](int j0) {
+        const int mbase = Tn - 1 - (qb + 15) + j0;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            int row = mbase + f * 16 + l16;
+            row = row < 0 ? 0 : (row > prow_max ? prow_max : row);
+            const bf16_t* pp = pos + (long)row * ldp + 8 * g;
+            pw[f][0] = *reinterpret_cast<const short8_t*>(pp);
+            pw[f][1] = *reinterpret_cast<const short8_t*>(pp + 32);
+        }
+    };
+    load_tiles(0);
+    store_tiles(0);
+    if (ntile > 1) load_tiles(KT);
+    load_window(0);
+    for (int jt = 0; jt < ntile; ++jt) {
+        const int j0 = jt * KT, buf = jt & 1;
+        __syncthreads();
+        if (jt + 1 < ntile) store_tiles(buf ^ 1);
+        if (jt + 2 < ntile) load_tiles(j0 + 2 * KT);
+        // BD^T: rows = window positions f*16 + 4g + r, column = query l16
+        float4_t bd[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            bd[f] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bd[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw[f][ks], aqv[ks], bd[f], 0, 0, 0);
+        }
+        if (jt + 1 < ntile) load_window(j0 + KT);       // lands under the rest of this tile
+#pragma unroll
+        for (int f = 0; f < 5; ++f) *reinterpret_cast<float4_t*>(Bw + l16 * BW + f * 16 + 4 * g) = bd[f];
+        // AC^T = K (Q + u)^T
+        float4_t s[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            s[nf] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const short8_t bk = *reinterpret_cast<const short8_t*>(Ks[buf] + (nf * 16 + l16) * LDK + ks * 32 + 8 * g);
+                s[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, aqu[ks], s[nf], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const float* src = Bw + l16 * BW + 15 - l16 + 4 * g;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[nf][r] += src[nf * 16 + r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();               // every lane has read the window before P overwrites the patch
+        const bool need_mask = j0 + KT > vis_all;      // uniform per tile (vis_all <= Tn)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = s[nf][r];
+                if (need_mask) {
+                    const int j = j0 + nf * 16 + 4 * g + r;
+                    x = j < lim ? x : -INFINITY;
+                    s[nf][r] = x;
+                }
+                mx = fmaxf(mx, x);
+            }
+        mx *= sc2;
+        float m_use = m_run;
+        const bool grow = (mx - m_run) > 6.0f || m_run == -INFINITY;
+        if (__any(grow)) {
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+            l_run *= alpha;
+#pragma unroll
+            for (int df = 0; df < 4; ++df)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[df][r] *= alpha;
+            m_run = m_new;
+            m_use = m_safe;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][0], sc2, -m_use));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][1], sc2, -m_use));
+            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][2], sc2, -m_use));
+            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nf][3], sc2, -m_use));
+            rs += (p0 + p1) + (p2 + p3);
+            uint2 pk;
+            pk.x = pack_bf16x2(p0, p1);
+            pk.y = pack_bf16x2(p2, p3);
+            *reinterpret_cast<uint2*>(Pw + l16 * LD + nf * 16 + 4 * g) = pk;
+        }
+        l_run += rs;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        short8_t ap[2];
+        ap[0] = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 8 * g);
+        ap[1] = *reinterpret_cast<const short8_t*>(Pw + l16 * LD + 32 + 8 * g);
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const short8_t bv = *reinterpret_cast<const short8_t*>(Vs[buf] + (df * 16 + l16) * LDK + ks * 32 + 8 * g);
+                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, ap[ks], o[df], 0, 0, 0);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();               // the patch is rewritten in the next tile
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const int i = qb + l16;
+    if (i < Tn) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[df][0] * inv, o[df][1] * inv);
+            pk.y = pack_bf16x2(o[df][2] * inv, o[df][3] * inv);
+            *reinterpret_cast<uint2*>(out + (long)i * ldo + df * 16 + 4 * g) = pk;
+        }
+    }
+}
+
+extern "C" int mmx_attn_relpos_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
+                                    const void* vt, int64_t ldvt, int64_t vt_bs, const void* pos, int64_t ldp,
+                                    const float* pos_u, const float* pos_v, void* out, int64_t ldo, int64_t o_bs,
+                                    int B, int H, int T_, float scale, int chunk, hipStream_t stream) {
+    MMX_CHECK_ARG(q && k && vt && pos && pos_u && pos_v && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0);
+    MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldp % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
+    MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8 && ldo % 4 == 0 && o_bs % 4 == 0);
+    MMX_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)pos % 16) == 0 && ((uintptr_t)out % 8) == 0);
+    const int npairs = H * B, nq = (T_ + 63) / 64;
+    hipLaunchKernelGGL((attn_relpos_kernel<4>), dim3(8 * ((npairs + 7) / 8) * nq), dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs,
+                       (const bf16_t*)k, ldk, k_bs, (const bf16_t*)vt, ldvt, vt_bs, (const bf16_t*)pos, ldp, pos_u, pos_v, (bf16_t*)out, ldo,
+                       o_bs, T_, scale, chunk, nq, H, npairs);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
+
 // ------------------------------------------------------------------------------------------ flash, keys split over waves
 // Few queries against many keys (a streaming hop: ~64 new frames x up to 3 000 cached keys per (batch, head) pair): the
 // kernel above gives such a launch 32 workgroups that each walk every key tile in turn (47 tiles, 42 us per launch, 30 %

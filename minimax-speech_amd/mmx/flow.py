@@ -204,6 +204,9 @@ class FlowEngine:
                 w1=lin(p + ".feed_forward.w_1.weight"), b1=f(p + ".feed_forward.w_1.bias"),
                 w2=lin(p + ".feed_forward.w_2.weight"), b2=f(p + ".feed_forward.w_2.bias"))
 
+        # bf16 build: rel-pos attention on the MFMA (mmx_attn_relpos_bf16) - Q | K rows from one GEMM, V^T from a second one
+        # with the weights as its A operand (the layout the flash kernels read); other builds: mmx_attn_dense (fp32 VALU)
+        self.enc_mfma = dt == BF16 and getattr(self, "enc_attn", "mfma") == "mfma"
         self.enc = dict(embed=embed(e + ".embed"), up_embed=embed(e + ".up_embed"),
                         pl_w1=cv(e + ".pre_lookahead_layer.conv1.weight"), pl_b1=f(e + ".pre_lookahead_layer.conv1.bias"),
                         pl_w2=cv(e + ".pre_lookahead_layer.conv2.weight"), pl_b2=f(e + ".pre_lookahead_layer.conv2.bias"),
@@ -293,14 +296,24 @@ class FlowEngine:
         dt = self.dtype
         hn = self._new(T, 512)
         ops.rownorm(x, lw["n1g"], lw["n1b"], 1e-12, rows=T, C_=512, out_act=hn, dtype=dt)
-        qkv = self._new(T, 1536)
-        ops.linear(hn, lw["wqkv"], 512, dtype=dt, bias=lw["bqkv"], out_act=qkv)
         p = self._new(2 * T - 1, 512)
         ops.linear(pos_act, lw["wpos"], 512, dtype=dt, out_act=p)
         ao = self._new(T, 512)
-        ops.attn_dense(qkv, qkv[:, 512:], qkv[:, 1024:], ao, B=1, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
-                       q_bs=0, k_bs=0, v_bs=0, o_bs=0, scale=0.125, dtype=dt, chunk=chunk, pos=p, ldp=512,
-                       pos_u=lw["pu"], pos_v=lw["pv"])
+        if self.enc_mfma:
+            qk = self._new(T, 1024)
+            ops.linear(hn, lw["wqkv"][:1024], 512, dtype=dt, bias=lw["bqkv"][:1024], out_act=qk)
+            Tp = ops.round_up(T, 8)
+            vt = self._vt_buf(1, Tp)[0]                       # [512][Tp], pad columns zero
+            ops.gemm(lw["wqkv"][1024:], hn, 512, T, dtype=dt, lda=lw["wqkv"].shape[1], cin=512, bias=lw["bqkv"][1024:],
+                     bias_per_row=True, out_act=vt, ldo_a=Tp)
+            ops.attn_relpos_bf16(qk, qk[:, 512:], vt, p, lw["pu"], lw["pv"], ao, B=1, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp,
+                                 ldp=512, ldo=512, q_bs=0, k_bs=0, vt_bs=0, o_bs=0, scale=0.125, chunk=chunk)
+        else:
+            qkv = self._new(T, 1536)
+            ops.linear(hn, lw["wqkv"], 512, dtype=dt, bias=lw["bqkv"], out_act=qkv)
+            ops.attn_dense(qkv, qkv[:, 512:], qkv[:, 1024:], ao, B=1, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                           q_bs=0, k_bs=0, v_bs=0, o_bs=0, scale=0.125, dtype=dt, chunk=chunk, pos=p, ldp=512,
+                           pos_u=lw["pu"], pos_v=lw["pv"])
         x2 = self._new(T, 512, f32=True)
         ops.linear(ao, lw["wo"], 512, dtype=dt, bias=lw["bo"], residual=x, out_f32=x2)
         ops.rownorm(x2, lw["n2g"], lw["n2b"], 1e-12, rows=T, C_=512, out_act=hn, dtype=dt)

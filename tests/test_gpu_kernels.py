@@ -217,6 +217,37 @@ def test_attn_flash_bf16(env, T, chunk, q_begin, fp8):
     assert float(out[:, :q_begin].abs().max() if q_begin else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("T,chunk", [(16, 0), (77, 0), (100, 50), (500, 0), (1000, 100), (1003, 0)])
+def test_attn_relpos_bf16(env, T, chunk):
+    """Conformer rel-pos attention on the MFMA (mmx_attn_relpos_bf16) against the float64 statement of
+    RelPositionMultiHeadedAttention (attention.py:215-330): (q + u) k^T + rel_shift((q + v) p^T), chunk mask, softmax, P V.
+    Ragged lengths (last query fragment partly empty, window rows clamped at both ends), batch 2."""
+    from oracle import flow as OF
+    L, ops = env
+    g = torch.Generator().manual_seed(T + 3)
+    B, H, D = 2, 8, 64
+    q, k, v = (torch.randn(B, T, H * D, generator=g).cuda().bfloat16() for _ in range(3))
+    pos = torch.randn(2 * T - 1, H * D, generator=g).cuda().bfloat16()
+    pu, pv = torch.randn(H, D, generator=g).cuda() * 0.2, torch.randn(H, D, generator=g).cuda() * 0.2
+    Tp = ops.round_up(T, 8)
+    vt = torch.zeros(B, H * D, Tp, device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :T] = v.transpose(1, 2)
+    out = torch.zeros(B, T, H * D, device="cuda", dtype=torch.bfloat16)
+    ops.attn_relpos_bf16(q, k, vt, pos, pu, pv, out, B=B, H=H, T=T, ldq=H * D, ldk=H * D, ldvt=Tp, ldp=H * D, ldo=H * D,
+                         q_bs=T * H * D, k_bs=T * H * D, vt_bs=H * D * Tp, o_bs=T * H * D, scale=D ** -0.5, chunk=chunk)
+    qh = q.double().cpu().view(B, T, H, D)
+    kh, vh = (t.double().cpu().view(B, T, H, D).transpose(1, 2) for t in (k, v))
+    ph = pos.double().cpu().view(1, 2 * T - 1, H, D).transpose(1, 2)
+    ac = (qh + pu.double().cpu()).transpose(1, 2) @ kh.transpose(-2, -1)
+    bd = OF.rel_shift((qh + pv.double().cpu()).transpose(1, 2) @ ph.transpose(-2, -1))
+    s = (ac + bd) * D ** -0.5
+    if chunk:
+        s = s.masked_fill(~OF.subsequent_chunk_mask(T, chunk)[None, None], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, H * D)
+    err = rel_err(out.cpu().double(), ref)
+    assert err < 2e-2, err                              # bf16 operands (q + u, q + v, P rounded to bf16), as the flash kernel
+
+
 @pytest.mark.parametrize("T,chunk", [(200, 0), (500, 0), (500, 50), (1000, 0), (130, 0)])
 def test_attn_flash_klen(env, T, chunk):
     """klen (valid keys per batch row of a padded batch) gives the result of the same prefix mask passed as keymask, on
