@@ -185,12 +185,13 @@ int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, const void* v
  *   score(i, j) = ((q_i + pos_u) . k_j + (q_i + pos_v) . pos[T - 1 - i + j]) * scale      (rel_shift folded into the index)
  * q, k: bf16 rows (head h at column h * 64), vt: V TRANSPOSED [B][H * 64][ldvt] (zero padded to ldvt >= round_up(T, 8)
  * columns), pos: bf16 [2T - 1][ldp] = linear_pos(pos_emb) (head h at column h * 64), pos_u / pos_v fp32 [H * 64];
- * chunk > 0: query i sees keys j < (i / chunk + 1) * chunk (streaming).  Replaces mmx_attn_dense's VALU path for the
+ * chunk > 0: query i sees keys j < (i / chunk + 1) * chunk (streaming); klen (optional, int32 [B]): valid rows per member of
+ * a zero-padded batch (keys beyond are masked; `pos` is the table of the padded length T).  Replaces mmx_attn_dense's VALU path for the
  * encoder's 10 layers in the bf16 build; the fp32 / split builds keep mmx_attn_dense. */
 int mmx_attn_relpos_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                          const void* vt, int64_t ldvt, int64_t vt_bs, const void* pos, int64_t ldp,
                          const float* pos_u, const float* pos_v, void* out, int64_t ldo, int64_t o_bs,
-                         int B, int H, int T, float scale, int chunk, hipStream_t stream);
+                         int B, int H, int T, float scale, int chunk, const int32_t* klen, hipStream_t stream);
 
 /* The same contract (bf16 tensors in HBM) with Q, K, V^T and P quantised to OCP fp8 e4m3 inside the kernel and both
  * products on the fp8 MFMA (BASELINE config 5).  Accuracy: the bound stated in tests/test_gpu_kernels.py (<= 7 % of the output RMS). */

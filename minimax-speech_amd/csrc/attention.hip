@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
     const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
     const bf16_t* __restrict__ vt, long ldvt, long vt_bs, const bf16_t* __restrict__ pos, long ldp,
     const float* __restrict__ pos_u, const float* __restrict__ pos_v, bf16_t* __restrict__ out, long ldo, long o_bs,
-    int Tn, float scale, int chunk, int nq, int nheads, int npairs) {
+    int Tn, float scale, int chunk, int nq, int nheads, int npairs, const int32_t* __restrict__ klen) {
     constexpr int D = 64, KT = 64, LDK = 80, LD = 72, BW = 84;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][KT * LDK];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[2][D * LDK];
@@ -492,6 +492,9 @@ __global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
     out += (long)b * o_bs + h * D;
     pos += h * D;
     const float sc2 = scale * 1.44269504088896341f;
+    // klen: valid rows of batch member b in a padded batch (keys beyond it are masked; the relative position of a pair does
+    // not depend on the sequence length, so the table of the padded length serves every member)
+    const int Tk = klen ? (klen[b] < Tn ? klen[b] : Tn) : Tn;
 
     short8_t aqu[2], aqv[2];                           // lane (q = l16, k-group g): (q + u), (q + v) [ks*32 + 8g .. +7]
     {
@@ -518,9 +521,9 @@ __global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = float4_t{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    int lim = Tn;
+    int lim = Tk;
     if (chunk > 0) { const int c2 = ((qb + l16) / chunk + 1) * chunk; lim = c2 < lim ? c2 : lim; }
-    int kend = Tn;
+    int kend = Tk;
     if (chunk > 0) {
         int qlast = qt * (NW * 16) + NW * 16 - 1;
         if (qlast > Tn - 1) qlast = Tn - 1;
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
         if (e < kend) kend = e;
     }
     const int ntile = (kend + KT - 1) / KT;
-    int vis_all = Tn;
+    int vis_all = Tk;
     if (chunk > 0) {
         const int e = ((qt * (NW * 16)) / chunk + 1) * chunk;
         if (e < vis_all) vis_all = e;
@@ -543,8 +546,8 @@ __global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
             const int id = tid + i * 64 * NW;
             const int r = id >> 3, c = (id & 7) * 8;
             const int key = j0 + r;
-            kreg[i] = key < Tn ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
-            vreg[i] = (j0 + c < Tn) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
+            kreg[i] = key < Tk ? *reinterpret_cast<const uint4*>(k + (long)key * ldk + c) : make_uint4(0, 0, 0, 0);
+            vreg[i] = (j0 + c < Tk) ? *reinterpret_cast<const uint4*>(vt + (long)r * ldvt + j0 + c) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();               // every lane has read the window before P overwrites the patch
-        const bool need_mask = j0 + KT > vis_all;      // uniform per tile (vis_all <= Tn)
+        const bool need_mask = j0 + KT > vis_all;      // uniform per tile (vis_all <= Tk)
         float mx = -INFINITY;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(64 * NW) void attn_relpos_kernel(
 extern "C" int mmx_attn_relpos_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                                     const void* vt, int64_t ldvt, int64_t vt_bs, const void* pos, int64_t ldp,
                                     const float* pos_u, const float* pos_v, void* out, int64_t ldo, int64_t o_bs,
-                                    int B, int H, int T_, float scale, int chunk, hipStream_t stream) {
+                                    int B, int H, int T_, float scale, int chunk, const int32_t* klen, hipStream_t stream) {
     MMX_CHECK_ARG(q && k && vt && pos && pos_u && pos_v && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0);
     MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldp % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
     MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8 && ldo % 4 == 0 && o_bs % 4 == 0);
@@ -698,7 +701,7 @@ extern "C" int mmx_attn_relpos_bf16(const void* q, int64_t ldq, int64_t q_bs, co
     const int npairs = H * B, nq = (T_ + 63) / 64;
     hipLaunchKernelGGL((attn_relpos_kernel<4>), dim3(8 * ((npairs + 7) / 8) * nq), dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs,
                        (const bf16_t*)k, ldk, k_bs, (const bf16_t*)vt, ldvt, vt_bs, (const bf16_t*)pos, ldp, pos_u, pos_v, (bf16_t*)out, ldo,
-                       o_bs, T_, scale, chunk, nq, H, npairs);
+                       o_bs, T_, scale, chunk, nq, H, npairs, klen);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

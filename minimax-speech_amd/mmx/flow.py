@@ -292,45 +292,49 @@ class FlowEngine:
         return self._pe[T]
 
     # ------------------------------------------------------------------ encoder
-    def _conformer(self, lw, x, T, pos_act, chunk):
+    def _conformer(self, lw, x, T, pos_act, chunk, B=1, klen=None, keymask=None):
+        """One conformer layer on x fp32 [B * T, 512] (B utterances zero padded to T rows each; klen int32 [B] / keymask fp32
+        [B, T]: the valid rows - the rows beyond them carry finite garbage that no valid row ever reads)."""
         dt = self.dtype
-        hn = self._new(T, 512)
-        ops.rownorm(x, lw["n1g"], lw["n1b"], 1e-12, rows=T, C_=512, out_act=hn, dtype=dt)
+        R = B * T
+        hn = self._new(R, 512)
+        ops.rownorm(x, lw["n1g"], lw["n1b"], 1e-12, rows=R, C_=512, out_act=hn, dtype=dt)
         p = self._new(2 * T - 1, 512)
         ops.linear(pos_act, lw["wpos"], 512, dtype=dt, out_act=p)
-        ao = self._new(T, 512)
+        ao = self._new(R, 512)
         if self.enc_mfma:
-            qk = self._new(T, 1024)
+            qk = self._new(R, 1024)
             ops.linear(hn, lw["wqkv"][:1024], 512, dtype=dt, bias=lw["bqkv"][:1024], out_act=qk)
             Tp = ops.round_up(T, 8)
-            vt = self._vt_buf(1, Tp)[0]                       # [512][Tp], pad columns zero
-            ops.gemm(lw["wqkv"][1024:], hn, 512, T, dtype=dt, lda=lw["wqkv"].shape[1], cin=512, bias=lw["bqkv"][1024:],
-                     bias_per_row=True, out_act=vt, ldo_a=Tp)
-            ops.attn_relpos_bf16(qk, qk[:, 512:], vt, p, lw["pu"], lw["pv"], ao, B=1, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp,
-                                 ldp=512, ldo=512, q_bs=0, k_bs=0, vt_bs=0, o_bs=0, scale=0.125, chunk=chunk)
+            vt = self._vt_buf(B, Tp)                          # [B][512][Tp], pad columns zero
+            ops.gemm(lw["wqkv"][1024:], hn, 512, T, dtype=dt, lda=lw["wqkv"].shape[1], cin=512, batch=B, a_bstride=0,
+                     w_bstride=T * 512, bias=lw["bqkv"][1024:], bias_per_row=True, out_act=vt, ldo_a=Tp, oa_bstride=512 * Tp)
+            ops.attn_relpos_bf16(qk, qk[:, 512:], vt, p, lw["pu"], lw["pv"], ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp,
+                                 ldp=512, ldo=512, q_bs=T * 1024, k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125,
+                                 chunk=chunk, klen=klen)
         else:
-            qkv = self._new(T, 1536)
+            qkv = self._new(R, 1536)
             ops.linear(hn, lw["wqkv"], 512, dtype=dt, bias=lw["bqkv"], out_act=qkv)
-            ops.attn_dense(qkv, qkv[:, 512:], qkv[:, 1024:], ao, B=1, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
-                           q_bs=0, k_bs=0, v_bs=0, o_bs=0, scale=0.125, dtype=dt, chunk=chunk, pos=p, ldp=512,
-                           pos_u=lw["pu"], pos_v=lw["pv"])
-        x2 = self._new(T, 512, f32=True)
+            ops.attn_dense(qkv, qkv[:, 512:], qkv[:, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
+                           q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, chunk=chunk, pos=p,
+                           ldp=512, pos_u=lw["pu"], pos_v=lw["pv"], keymask=keymask)
+        x2 = self._new(R, 512, f32=True)
         ops.linear(ao, lw["wo"], 512, dtype=dt, bias=lw["bo"], residual=x, out_f32=x2)
-        ops.rownorm(x2, lw["n2g"], lw["n2b"], 1e-12, rows=T, C_=512, out_act=hn, dtype=dt)
-        ff = self._new(T, 2048)
+        ops.rownorm(x2, lw["n2g"], lw["n2b"], 1e-12, rows=R, C_=512, out_act=hn, dtype=dt)
+        ff = self._new(R, 2048)
         ops.linear(hn, lw["w1"], 512, dtype=dt, bias=lw["b1"], act="silu", out_act=ff)
-        x3 = self._new(T, 512, f32=True)
+        x3 = self._new(R, 512, f32=True)
         ops.linear(ff, lw["w2"], 2048, dtype=dt, bias=lw["b2"], residual=x2, out_f32=x3)
         return x3
 
-    def _embed(self, ew, a, T):
-        """LinearNoSubsampling + LayerNorm (eps 1e-5) * sqrt(512): act [T,512] -> fp32 [T,512] and act copy."""
+    def _embed(self, ew, a, T, rowmask=None):
+        """LinearNoSubsampling + LayerNorm (eps 1e-5) * sqrt(512): act [T,512] -> fp32 [T,512] and act copy (* rowmask)."""
         dt = self.dtype
         tmp = self._new(T, 512, f32=True)
         ops.linear(a, ew["w"], 512, dtype=dt, bias=ew["b"], out_f32=tmp)
         x = self._new(T, 512, f32=True)
         xa = self._new(T, 512)
-        ops.rownorm(tmp, ew["g"], ew["beta"], 1e-5, rows=T, C_=512, out_f32=x, out_act=xa, dtype=dt)
+        ops.rownorm(tmp, ew["g"], ew["beta"], 1e-5, rows=T, C_=512, out_f32=x, out_act=xa, dtype=dt, rowmask=rowmask)
         return x, xa
 
     def encode(self, ids: torch.Tensor, finalize: bool, streaming: bool) -> torch.Tensor:
@@ -377,6 +381,56 @@ class FlowEngine:
         mu = self._new(T2, 80, f32=True)
         ops.linear(hn, E["wproj"], 512, dtype=dt, bias=E["bproj"], out_f32=mu)
         return mu
+
+    def encode_batch(self, ids_list) -> list:
+        """UpsampleConformerEncoder.forward + encoder_proj for several whole utterances at once (finalize, no chunk masks):
+        the token rows are zero padded to the longest, every launch covers the batch (the encoder is ~115 launches, most of
+        them too small to fill the chip one utterance at a time).  What makes the padding invisible to the valid rows:
+        the embedding output is masked to zero beyond each length (the look-ahead conv reads 3 rows to the right - zeros, as
+        at the end of a lone utterance), the other convs only look left, attention masks the keys beyond the length, and the
+        relative position of a (query, key) pair does not depend on the sequence length.  Returns mu fp32 [2 * L_b, 80] per
+        utterance (views of one buffer)."""
+        dt, E = self.dtype, self.enc
+        B = len(ids_list)
+        lens = [int(i.numel()) for i in ids_list]
+        if B == 1:
+            return [self.encode(ids_list[0].reshape(-1), True, False)]
+        T = max(lens)
+        ids = torch.zeros(B, T, dtype=torch.int64, device=self.dev)
+        for b, i in enumerate(ids_list):
+            ids[b, :lens[b]] = i.reshape(-1)
+        lens_t = torch.tensor(lens, dtype=torch.int32, device=self.dev)
+        ar = torch.arange(2 * T, device=self.dev)
+        mask = (ar[None, :T] < lens_t[:, None]).float().contiguous()             # [B, T]
+        mask2 = (ar[None, :] < 2 * lens_t[:, None]).float().contiguous()         # [B, 2T]
+        klen2 = (2 * lens_t).contiguous()
+        R = B * T
+        a0 = self._new(R, 512)
+        ops.gather_rows(ids.reshape(-1), self.emb_table, out_act=a0, dtype=dt)
+        x_all, xa_all = self._embed(E["embed"], a0, R, rowmask=mask.reshape(-1))
+        h1 = self._new(R, 512)
+        ops.gemm(xa_all, E["pl_w1"], T, 512, dtype=dt, lda=512, cin=512, ntaps=4, row_off=0, row_lo=0, row_hi=T, batch=B,
+                 a_bstride=T * 512, bias=E["pl_b1"], act="lrelu", slope=0.01, out_act=h1, ldo_a=512, oa_bstride=T * 512)
+        x = self._new(R, 512, f32=True)
+        ops.conv1d(h1, E["pl_w2"], T=T, Cin=512, k=3, pad_left=2, dtype=dt, batch=B, bias=E["pl_b2"], residual=x_all, out_f32=x)
+        pos = self._pos(T)
+        km, km2 = (None, None) if self.enc_mfma else (mask, mask2)
+        for lw in E["layers"]:
+            x = self._conformer(lw, x, T, pos, 0, B=B, klen=lens_t, keymask=km)
+        T2 = 2 * T
+        up = self._new(B * T2, 512)
+        ops.copy2d(x, F32, T * 512, 512, 1, up, dt, T2 * 512, 512, 1, rows=T2, cols=512, batch=B, rep=2)
+        c5 = self._new(B * T2, 512)
+        ops.conv1d(up, E["up_w"], T=T2, Cin=512, k=5, pad_left=4, dtype=dt, batch=B, bias=E["up_b"], out_act=c5)
+        x, _ = self._embed(E["up_embed"], c5, B * T2)
+        pos = self._pos(T2)
+        for lw in E["up_layers"]:
+            x = self._conformer(lw, x, T2, pos, 0, B=B, klen=klen2, keymask=km2)
+        hn = self._new(B * T2, 512)
+        ops.rownorm(x, E["ang"], E["anb"], 1e-5, rows=B * T2, C_=512, out_act=hn, dtype=dt)
+        mu = self._new(B, T2, 80, f32=True)
+        ops.linear(hn, E["wproj"], 512, dtype=dt, bias=E["bproj"], out_f32=mu)
+        return [mu[b, :2 * lens[b]] for b in range(B)]
 
     # ------------------------------------------------------------------ streaming encoder with cached state
     def _enc_stream_state(self, st):
@@ -1085,6 +1139,26 @@ class FlowEngine:
         if mel_len1:
             cond[:mel_len1].copy_(prompt_feat[0].to(self.dev, torch.float32))
         return mu, spks, cond, mel_len1
+
+    def conditions_batch(self, tokens, prompt_tokens, prompt_feats, embeddings):
+        """conditions() for several whole utterances (finalize, not streaming), the conformer encoder batched over them
+        (encode_batch).  Returns the list of (mu, spks, cond, Tp) conditions() would."""
+        dt, n = self.dtype, len(tokens)
+        emb = torch.cat([e.to(self.dev, torch.float32).reshape(1, -1) for e in embeddings], 0).contiguous()
+        en = self._new(n, self.spk_dim)
+        ops.rownorm(emb, self.spk_gamma, None, 1e-30, rows=n, C_=self.spk_dim, rms=True, out_act=en, dtype=dt)
+        spks = self._new(n, 80, f32=True)
+        ops.linear(en, self.spk_w, self.spk_dim, dtype=dt, bias=self.spk_b, out_f32=spks)
+        ids = [torch.cat([p.reshape(-1), t.reshape(-1)]).to(self.dev, torch.int64) for p, t in zip(prompt_tokens, tokens)]
+        mus = self.encode_batch(ids)
+        out = []
+        for b in range(n):
+            T, L1 = mus[b].shape[0], prompt_feats[b].shape[1]
+            cond = torch.zeros(T, 80, device=self.dev)
+            if L1:
+                cond[:L1].copy_(prompt_feats[b][0].to(self.dev, torch.float32))
+            out.append((mus[b], spks[b:b + 1], cond, L1))
+        return out
 
     @torch.no_grad()
     def inference(self, token, prompt_token, prompt_feat, embedding, streaming=False, finalize=True, reference_mels=None):

@@ -225,10 +225,13 @@ def attn_dense(q, k, v, out, *, B, H, Tq, Tk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_
           "mmx_attn_dense")
 
 
-def attn_relpos_bf16(q, k, vt, pos, pos_u, pos_v, out, *, B, H, T, ldq, ldk, ldvt, ldp, ldo, q_bs, k_bs, vt_bs, o_bs, scale, chunk=0):
+def attn_relpos_bf16(q, k, vt, pos, pos_u, pos_v, out, *, B, H, T, ldq, ldk, ldvt, ldp, ldo, q_bs, k_bs, vt_bs, o_bs, scale, chunk=0,
+                     klen=None):
+    if klen is not None:
+        assert klen.dtype == torch.int32 and klen.numel() >= B
     check(load().mmx_attn_relpos_bf16(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(vt), i64(ldvt), i64(vt_bs),
                                       _p(pos), i64(ldp), _p(pos_u), _p(pos_v), _p(out), i64(ldo), i64(o_bs), B, H, T,
-                                      C.c_float(scale), chunk, stream()), "mmx_attn_relpos_bf16")
+                                      C.c_float(scale), chunk, _p(klen), stream()), "mmx_attn_relpos_bf16")
 
 
 def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, keymask=None,

@@ -53,6 +53,7 @@ class TtsEngine:
     # measured on the config-4 rank share, 2 / 3 / 4 streams cost 15 % / 13 % / 32 % of the step (more queues beside the decode
     # loop slow its launches more than the per-utterance stages gain); useful only without a decode loop alongside
     group_fan = 1
+    batch_encoder = True      # the conformer encoder of a flow group runs as one zero-padded batch (FlowEngine.encode_batch)
 
     def _aux_streams(self, cur, n):
         """n auxiliary streams belonging to the stream `cur` (one set per flow worker stream; created once)."""
@@ -317,7 +318,12 @@ class TtsEngine:
             return out
 
         mark()
-        conds = fanned([(lambda b=b: flow.conditions(toks[b].reshape(1, -1), pr(b)[0], pr(b)[1], embs[b])) for b in grp])
+        if self.batch_encoder and len(grp) > 1:
+            # one encoder pass over the zero-padded group (FlowEngine.encode_batch)
+            conds = flow.conditions_batch([toks[b].reshape(1, -1) for b in grp], [pr(b)[0] for b in grp], [pr(b)[1] for b in grp],
+                                          [embs[b] for b in grp])
+        else:
+            conds = fanned([(lambda b=b: flow.conditions(toks[b].reshape(1, -1), pr(b)[0], pr(b)[1], embs[b])) for b in grp])
         mark()
         xs = flow.cfm_batch([c[0] for c in conds], [c[1] for c in conds], [c[2] for c in conds], pad_to=frame_quantum)
         mark()

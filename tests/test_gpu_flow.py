@@ -173,6 +173,27 @@ def test_batched_masked_cfm_equals_single(engines, dt, tol):
             assert (a - b).abs().max().item() < tol, (dt, rep, (a - b).abs().max().item())
 
 
+@pytest.mark.parametrize("dt,tol", [(0, 2e-5), (1, 6e-2)])
+def test_batched_encoder_equals_single(engines, dt, tol):
+    """FlowEngine.encode_batch (one zero-padded pass over a flow group) == the per-utterance encoder: the padding never
+    reaches a valid row (masked embedding rows for the look-ahead conv, left-looking convs, key lengths in the attention,
+    length-independent relative positions).  fp32 build: the same arithmetic per row; bf16 build: the MFMA tiles of a
+    row differ between the two launches' shapes only in nothing - the bound is the build's own rounding noise."""
+    eng = engines[dt]
+    g = torch.Generator().manual_seed(5)
+    vocab = eng.emb_table.shape[0]
+    ids = [torch.randint(0, vocab, (n,), generator=g).cuda() for n in (37, 64, 9, 50)]
+    single = [eng.encode(i, True, False).clone() for i in ids]
+    batch = eng.encode_batch(ids)
+    for a, b, i in zip(batch, single, ids):
+        assert a.shape == b.shape == (2 * i.numel(), 80)
+        err = (a - b).abs().max().item()
+        assert err < tol, (dt, i.numel(), err)
+    cb = eng.conditions_batch([i[3:].reshape(1, -1) for i in ids], [i[:3].reshape(1, -1) for i in ids],
+                              [torch.randn(1, 6, 80, generator=g).cuda() for _ in ids], [torch.randn(1, 192, generator=g).cuda() for _ in ids])
+    assert [c[0].shape[0] for c in cb] == [2 * i.numel() for i in ids] and all(c[3] == 6 and c[1].shape == (1, 80) for c in cb)
+
+
 def test_estimator_max_profile_length_bf16_vs_fp32(engines):
     """T = 3000 frames (the reference's TensorRT profile maximum, cli/model.py:96-101), ragged (not a multiple of any
     tile): the bf16 build (MFMA flash attention) agrees with the fp32 build (dense attention) within the bf16 bound."""
