@@ -17,18 +17,21 @@ kstats() {      # name, command...
 }
 pmc() {         # name, counters, filter words, command...
     local name=$1 ctr=$2 keep=$3; shift 3
-    rocprofv3 --pmc $ctr --output-format csv -d $out/pmc_$name -- "$@" > /dev/null 2>&1
+    rocprofv3 --pmc $ctr --output-format csv -d $out/pmc_$name -- "$@" > $out/pmc_$name.log 2>&1
     python tools/pmc_by_kernel.py $out/pmc_$name $keep > $out/pmc_$name.txt 2>&1
+    [ -s $out/pmc_$name.txt ] || { echo "no counters for $name:"; tail -5 $out/pmc_$name.log; find $out/pmc_$name -name "*.csv" | head; }
     rm -rf $out/pmc_$name
     echo "pmc $name done" >> $out/progress.log
 }
+if [ "$2" != "pmc" ]; then
 kstats bench python3 bench.py --steps 5 --warmup 2 --no-extras --no-cpu-baseline &&
 kstats bench_x python3 bench.py --dtype x --steps 3 --warmup 1 --no-extras --no-cpu-baseline &&
 kstats decode_bf16 python3 tools/decode_alone.py --dtype bf16 --steps 2 &&
 kstats decode_x python3 tools/decode_alone.py --dtype x --steps 2 &&
 kstats cfm8x896 python3 tools/prof_cfm.py 8 896 bf16 &&
 kstats cfm8x896_x python3 tools/prof_cfm.py 8 896 x &&
-kstats dac python3 tools/prof_dac.py &&
+kstats dac python3 tools/prof_dac.py || exit 1
+fi
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
     pmc decode_bf16_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/prof_decode.py bf16 8 || exit 1
     pmc decode_x_$c "$c" "skinny3 decode_attn sample_step decode_prep" python3 tools/prof_decode.py x 8 || exit 1
