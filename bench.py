@@ -53,7 +53,7 @@ def measure_lm_kernel(eng, iters=240):
     achieved = nbytes / (us * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": f"skinny3_kernel (LM gate/up + SwiGLU, K=896, N=2x4864, batch {B}, {ns} activation plane(s))",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
+            "traffic": _pmc("lm_gate_up_hbm_bytes_per_launch", ns > 1), "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
 
 
 def measure_lm_step(eng, ctx=300, iters=96):
@@ -86,7 +86,20 @@ def measure_lm_step(eng, ctx=300, iters=96):
     achieved = nbytes / (us * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": f"one captured LM decode step at batch {B}, context {ctx}..{ctx + iters} ({llm.n_layers} layers x 5 launches + head + sampler)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "bytes_per_launch": int(nbytes), "us_per_launch": round(us, 2), "launches_per_step": None}
+            "traffic": _pmc("lm_step_hbm_bytes", llm.tdt != torch.bfloat16), "bytes_per_launch": int(nbytes), "us_per_launch": round(us, 2),
+            "launches_per_step": 5 * llm.n_layers + 3}
+
+
+def _pmc(key, split=False):
+    """HBM bytes per launch from the committed PMC passes (profiles/r03_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, collected and
+    corrected as MI355X_MICROARCH.md prescribes, one counter per rocprofv3 pass); None when the file or the key is absent."""
+    for name in ("r03_pmc.json", "r02_pmc_flow.json"):
+        pj = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pj):
+            v = json.load(open(pj)).get(key + ("_x" if split else ""))
+            if v is not None:
+                return v
+    return None
 
 
 def _event_time_graph(fn, iters):
@@ -170,10 +183,7 @@ def measure_attn_kernel(eng, shapes, steps=1):
         tot_n += cnt
     us, flops = tot_us / tot_n, tot_fl / tot_n
     tfs = flops / (us * 1e-6) / 1e12
-    traffic = None
-    pj = os.path.join(ROOT, "profiles", "r02_pmc_flow.json")
-    if os.path.exists(pj):
-        traffic = json.load(open(pj)).get("attn_flash_bench_hbm_bytes_per_launch")
+    traffic = _pmc("attn_flash_bench_hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": f"attn_flash_kernel (estimator attention, 8 heads x 64, bf16) over the {int(tot_n) // max(1, steps)} flow groups of a step",
             "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
             "traffic": traffic, "flops_per_launch": round(flops), "us_per_launch": round(us, 3)}
@@ -212,11 +222,7 @@ def measure_flow_kernel(eng, shapes, steps=1):
     tfs_fast = flops / (tot_fast / tot_n * 1e-6) / 1e12
     us_l, bm_l = _time_est_tail(fl, 8, 896)
     tfs_l = per_row * 14336 / (us_l * 1e-6) / 1e12
-    traffic = traffic_l = None
-    pj = os.path.join(ROOT, "profiles", "r02_pmc_flow.json")
-    if os.path.exists(pj):
-        pm = json.load(open(pj))
-        traffic, traffic_l = pm.get("est_tail_bench_hbm_bytes_per_launch"), pm.get("est_tail_8x896_hbm_bytes_per_launch")
+    traffic, traffic_l = _pmc("est_tail_bench_hbm_bytes_per_launch"), _pmc("est_tail_8x896_hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": f"est_tail_kernel<bf16, {'|'.join(str(t) for t in sorted(tiles))} rows per workgroup> (fused transformer-block tail) over the "
             f"{int(tot_n) // max(1, steps)} flow groups of a step ({len(count)} shapes, M = 2nT from {min(2 * n * T for n, T, _ in count)} to {max(2 * n * T for n, T, _ in count)} rows; "
             f"{sum(c[0] for k, c in count.items() if k[2]) // max(1, steps)} of them beside the decode loop, on 64-row tiles)",

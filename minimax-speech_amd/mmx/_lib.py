@@ -77,7 +77,7 @@ def fill_struct(st, **kw):
     return st
 
 
-ABI_VERSION = 4                                          # include/mmx_hip.h: mmx_abi_version()
+ABI_VERSION = 5                                          # include/mmx_hip.h: mmx_abi_version()
 _lib = None
 
 
