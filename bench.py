@@ -93,13 +93,8 @@ def measure_lm_step(eng, ctx=300, iters=96):
 def _pmc(key, split=False):
     """HBM bytes per launch from the committed PMC passes (profiles/r03_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE, collected and
     corrected as MI355X_MICROARCH.md prescribes, one counter per rocprofv3 pass); None when the file or the key is absent."""
-    for name in ("r03_pmc.json", "r02_pmc_flow.json"):
-        pj = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(pj):
-            v = json.load(open(pj)).get(key + ("_x" if split else ""))
-            if v is not None:
-                return v
-    return None
+    pj = os.path.join(ROOT, "profiles", "r03_pmc.json")
+    return json.load(open(pj)).get(key + ("_x" if split else "")) if os.path.exists(pj) else None
 
 
 def _event_time_graph(fn, iters):
