@@ -327,6 +327,7 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
+    ap.add_argument("--lm-cfg", default="", help="tuning: LlmEngine.v2_cfg overrides (output tiles per workgroup, k slices), e.g. gu=2,1:down=2,4")
     ap.add_argument("--group-fan", type=int, default=None, help="auxiliary streams per flow group for its per-utterance stages (TtsEngine.group_fan)")
     ap.add_argument("--pad-ratio", type=float, default=2.0, help="max length ratio inside one flow group")
     ap.add_argument("--flow-workers", type=int, default=2, help="host threads / streams solving flow groups concurrently")
@@ -340,6 +341,9 @@ def main():
     a = ap.parse_args()
     global ATTN, GROUP_FAN
     ATTN, GROUP_FAN = a.attn, a.group_fan
+    if a.lm_cfg:
+        from mmx.llm import LlmEngine
+        LlmEngine.v2_cfg = dict(LlmEngine.v2_cfg, **{kv.split("=")[0]: tuple(int(v) for v in kv.split("=")[1].split(",")) for kv in a.lm_cfg.split(":")})
     if a.gqa_min_batch is not None:
         from mmx.llm import LlmEngine
         LlmEngine.gqa_min_batch = a.gqa_min_batch

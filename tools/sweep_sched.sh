@@ -16,6 +16,14 @@ if [ "$3" = "w1" ]; then
   run workers1_h30 --flow-workers 1 --hold-steps 30
   exit 0
 fi
+if [ "$3" = "lm" ]; then
+  run base
+  run down24 --lm-cfg down=2,4
+  run down22 --lm-cfg down=2,2
+  run gu11 --lm-cfg gu=1,1
+  run down18 --lm-cfg down=1,8
+  exit 0
+fi
 if [ "$3" = "fan" ]; then
   run fan3
   run fan1 --group-fan 1
