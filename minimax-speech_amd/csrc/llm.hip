@@ -607,8 +607,28 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     if (kvg >= Hkv * nseq) return;                     // uniform: the grid is padded to a multiple of 8 pairs
     const int b = kvg / Hkv, hk = kvg % Hkv, h = hk * group + slot % group;
     const int32_t* bt = block_table + (long)b * max_pages;
+    // The first pass's cached rows are requested BEFORE anything that depends on `pos`: the page ids come straight from the
+    // block table in global memory (every entry is a valid page - unreserved ones point at the scratch page), the rows
+    // beyond `pos` are loaded and never consumed.  The launch is a chain of memory round trips (pos -> rope table / block
+    // table -> K / V rows -> merge); this takes the K / V trip off the pos -> rope -> barrier leg.
+    constexpr int U = sizeof(T) == 2 ? 12 : 10;       // (fp32 cache: 10 x 64 B per thread in flight, 320 keys per pass)
+    const int kg = tid >> 3, dc = tid & 7;
+    int pg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int pi = (kg + u * NG) / page;
+        pg[u] = bt[pi < max_pages ? pi : max_pages - 1];
+    }
     for (int i = tid; i < max_pages; i += 256) bts[i] = bt[i];
     const int p = pos[b];
+    Raw8<T> rk0[U], rv0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = kg + u * NG;
+        const long o = (((long)pg[u] * Hkv + hk) * page + j % page) * D + dc * 8;
+        rk0[u].load(kc + o);
+        rv0[u].load(vc + o);
+    }
     const float* src = qkv + (long)b * ldqkv;
     const float sc2 = scale * 1.44269504088896341f;
     if (tid < 2 * HALF) {
@@ -636,7 +656,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
         kc[o] = Cvt<T>::from_f(kn[tid]);
         vc[o] = Cvt<T>::from_f(vn[tid]);
     }
-    const int kg = tid >> 3, dc = tid & 7;
     float qv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] = qs[dc * 8 + e];
@@ -656,9 +675,17 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
         m = mn;
     };
     // cached keys: U keys per thread in flight at a time (the loop is a chain of memory round trips otherwise:
-    // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys
-    constexpr int U = sizeof(T) == 2 ? 12 : 10;       // (fp32 cache: 10 x 64 B per thread in flight, 320 keys per pass)
-    for (int j0 = kg; j0 < p; j0 += NG * U) {
+    // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys.  Pass 0 was requested at the top.
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (kg + u * NG < p) {
+            float kv[8], vv[8];
+            rk0[u].to_float(kv);
+            rv0[u].to_float(vv);
+            consume(kv, vv);
+        }
+    }
+    for (int j0 = kg + NG * U; j0 < p; j0 += NG * U) {
         Raw8<T> rk[U], rv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
