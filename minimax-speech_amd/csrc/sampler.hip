@@ -84,8 +84,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     __shared__ int cand_i[SAMP_MAXK];
     __shared__ int sh_n, sh_top, sh_cnt, sh_thr_i;
     __shared__ float sh_thr_v;
-    __shared__ float lmax_p[SAMP_THREADS];
-    __shared__ int lmax_i[SAMP_THREADS];
+    __shared__ __attribute__((aligned(16))) float lmax_p[SAMP_THREADS];
+    __shared__ __attribute__((aligned(16))) int lmax_i[SAMP_THREADS];
     __shared__ float p_lds[SAMP_THREADS * SAMP_MAXV];
     __shared__ float list_p[SAMP_LIST];
     __shared__ int list_i[SAMP_LIST];
@@ -112,17 +112,17 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     for (int i = 0; i < SAMP_MAXV; ++i) se += (tid + i * SAMP_THREADS < V) ? expf(x[i] - mx) : 0.f;
     se = block_sum(se, shf);
     const float lse = logf(se);
-    float mx2 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SAMP_MAXV; ++i) {
         int idx = tid + i * SAMP_THREADS;
         if (idx < V) {
             x[i] = (x[i] - mx) - lse;                  // logp
             if (logp_out) logp_out[(long)b * V + idx] = x[i];
-            mx2 = fmaxf(mx2, x[i]);
         }
     }
-    mx2 = block_max(mx2, shf);
+    // max(logp) without another block reduction: the maximal logit gives (mx - mx) - lse = 0.0f - lse exactly, and every
+    // other element's (x - mx) is <= 0, so the maximum of the values just computed IS this one
+    const float mx2 = 0.0f - lse;
     float se2 = 0.f;
 #pragma unroll
     for (int i = 0; i < SAMP_MAXV; ++i) {
@@ -159,7 +159,12 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
         const float mv = lmax_p[tid];
         const int mi = lmax_i[tid];
         int rk = 0;
-        for (int j = 0; j < SAMP_THREADS; ++j) rk += precedes(lmax_p[j], lmax_i[j], mv, mi) ? 1 : 0;
+        for (int j = 0; j < SAMP_THREADS; j += 4) {     // 16-byte broadcast reads: a quarter of the LDS instructions
+            const float4 pv = *reinterpret_cast<const float4*>(lmax_p + j);
+            const int4 iv = *reinterpret_cast<const int4*>(lmax_i + j);
+            rk += (precedes(pv.x, iv.x, mv, mi) ? 1 : 0) + (precedes(pv.y, iv.y, mv, mi) ? 1 : 0) +
+                  (precedes(pv.z, iv.z, mv, mi) ? 1 : 0) + (precedes(pv.w, iv.w, mv, mi) ? 1 : 0);
+        }
         if (rk == min(top_k, SAMP_THREADS) - 1) { sh_thr_v = mv; sh_thr_i = mi; }
     }
     __syncthreads();
@@ -170,9 +175,18 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
             const ArgMax e{x[i], tid + i * SAMP_THREADS};
             // e >= thr in the sort order  <=>  !(thr strictly precedes e)
             const bool take = e.i < V && !precedes(thr.v, thr.i, e.v, e.i);
-            if (take) {
-                int slot = atomicAdd(&sh_cnt, 1);
-                if (slot < SAMP_LIST) { list_p[slot] = e.v; list_i[slot] = e.i; }
+            // one LDS atomic per wave and round instead of one per taker (the list's order is irrelevant: ranks are
+            // recomputed from (value, index) below)
+            const unsigned long long tm = __ballot(take);
+            if (tm) {
+                const int lane = tid & 63, leader = __ffsll((long long)tm) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&sh_cnt, __popcll(tm));
+                base = __shfl(base, leader, 64);
+                if (take) {
+                    const int slot = base + __popcll(tm & ((1ull << lane) - 1ull));
+                    if (slot < SAMP_LIST) { list_p[slot] = e.v; list_i[slot] = e.i; }
+                }
             }
         }
     }
