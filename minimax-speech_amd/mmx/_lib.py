@@ -20,7 +20,7 @@ def is_split(dtype):
     return dtype in (X2, X3)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")
+LIB_PATH = os.environ.get("MMX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")   # MMX_LIB: A/B of two builds
 
 SYMBOLS = [
     "mmx_abi_version", "mmx_gemm_win", "mmx_gemm_win_tile", "mmx_rownorm", "mmx_groupnorm", "mmx_act_rows", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
