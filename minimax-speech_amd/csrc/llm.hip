@@ -623,36 +623,42 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     }
     for (int i = tid; i < max_pages; i += 256) bts[i] = bt[i];
     const int p = pos[b];
+    const float* src = qkv + (long)b * ldqkv;
+    const float sc2 = scale * 1.44269504088896341f;
+    // Rope operands of EVERY thread first (threads that rope nothing load harmless duplicates), then the cached rows, all
+    // without a branch around a load: a wave waits for loads in issue order (s_waitcnt vmcnt(N)), so the rope leg's
+    // operands must be OLDER than the 2 * U row loads or it would wait for all of them, and a load under a branch makes the
+    // compiler drain everything.  Rows beyond pos read the cache's first line instead (one line, shared by all).
+    const int which = tid >> 5, d = tid & 31;          // 0: q head h, 1: k head hk, 2-3: the new value's 64 channels
+    float xa, xb, rc, rs, vsrc;
+    {
+        const float* x = src + (which == 0 ? h * D : (Hq + hk) * D);
+        xa = x[d];
+        xb = x[d + HALF];
+        if (rope_tab) {                                // [pos][cos 0..31 | sin 0..31], computed like HF on the host
+            rc = rope_tab[(long)p * D + d];
+            rs = rope_tab[(long)p * D + HALF + d];
+        } else {
+            const float ang = (float)p * inv_freq[d];
+            rc = cosf(ang);
+            rs = sinf(ang);
+        }
+        vsrc = src[(Hq + Hkv + hk) * D + (tid & 63)];
+    }
     Raw8<T> rk0[U], rv0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int j = kg + u * NG;
-        if (j < p) {
-            const long o = (((long)pg[u] * Hkv + hk) * page + j % page) * D + dc * 8;
-            rk0[u].load(kc + o);
-            rv0[u].load(vc + o);
-        }
+        const long o = j < p ? (((long)pg[u] * Hkv + hk) * page + j % page) * D + dc * 8 : (long)dc * 8;   // (beyond pos: one line)
+        rk0[u].load(kc + o);
+        rv0[u].load(vc + o);
     }
-    const float* src = qkv + (long)b * ldqkv;
-    const float sc2 = scale * 1.44269504088896341f;
     if (tid < 2 * HALF) {
-        const int which = tid >> 5, d = tid & 31;      // 0: q head h, 1: k head hk
-        const float* x = src + (which == 0 ? h * D : (Hq + hk) * D);
-        float c, s;
-        if (rope_tab) {                                // [pos][cos 0..31 | sin 0..31], computed like HF on the host
-            c = rope_tab[(long)p * D + d];
-            s = rope_tab[(long)p * D + HALF + d];
-        } else {
-            const float ang = (float)p * inv_freq[d];
-            c = cosf(ang);
-            s = sinf(ang);
-        }
-        const float y0 = x[d] * c - x[d + HALF] * s, y1 = x[d + HALF] * c + x[d] * s;
+        const float y0 = xa * rc - xb * rs, y1 = xb * rc + xa * rs;
         if (which == 0) { qs[d] = y0 * sc2; qs[d + HALF] = y1 * sc2; }
         else { kn[d] = Cvt<T>::to_f(Cvt<T>::from_f(y0)); kn[d + HALF] = Cvt<T>::to_f(Cvt<T>::from_f(y1)); }
     } else if (tid < 2 * HALF + D) {
-        const int d = tid - 2 * HALF;
-        vn[d] = Cvt<T>::to_f(Cvt<T>::from_f(src[(Hq + Hkv + hk) * D + d]));
+        vn[tid - 2 * HALF] = Cvt<T>::to_f(Cvt<T>::from_f(vsrc));
     }
     __syncthreads();
     if (h % group == 0 && tid < D) {                   // one workgroup per kv head appends to the cache
