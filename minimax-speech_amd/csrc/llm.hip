@@ -607,58 +607,28 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     if (kvg >= Hkv * nseq) return;                     // uniform: the grid is padded to a multiple of 8 pairs
     const int b = kvg / Hkv, hk = kvg % Hkv, h = hk * group + slot % group;
     const int32_t* bt = block_table + (long)b * max_pages;
-    // The first pass's cached rows are requested as soon as `pos` and the page ids are known (the ids straight from the
-    // block table in global memory, in flight together with `pos`), BEFORE the rope / LDS staging / barrier leg.  The launch is
-    // a chain of memory round trips (pos -> rope table / block table -> K / V rows -> merge); this takes the K / V trip off
-    // the rope -> barrier leg.  (Requesting the rows without waiting for `pos` - all 32 * U of them, masked afterwards - was
-    // measured 2 % slower over the decode loop: at short contexts the unused rows cost more of the CU's memory pipe than the
-    // round trip saves.)
-    constexpr int U = sizeof(T) == 2 ? 12 : 10;       // (fp32 cache: 10 x 64 B per thread in flight, 320 keys per pass)
-    const int kg = tid >> 3, dc = tid & 7;
-    int pg[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int pi = (kg + u * NG) / page;
-        pg[u] = bt[pi < max_pages ? pi : max_pages - 1];
-    }
     for (int i = tid; i < max_pages; i += 256) bts[i] = bt[i];
     const int p = pos[b];
     const float* src = qkv + (long)b * ldqkv;
     const float sc2 = scale * 1.44269504088896341f;
-    // Rope operands of EVERY thread first (threads that rope nothing load harmless duplicates), then the cached rows, all
-    // without a branch around a load: a wave waits for loads in issue order (s_waitcnt vmcnt(N)), so the rope leg's
-    // operands must be OLDER than the 2 * U row loads or it would wait for all of them, and a load under a branch makes the
-    // compiler drain everything.  Rows beyond pos read the cache's first line instead (one line, shared by all).
-    const int which = tid >> 5, d = tid & 31;          // 0: q head h, 1: k head hk, 2-3: the new value's 64 channels
-    float xa, xb, rc, rs, vsrc;
-    {
+    if (tid < 2 * HALF) {
+        const int which = tid >> 5, d = tid & 31;      // 0: q head h, 1: k head hk
         const float* x = src + (which == 0 ? h * D : (Hq + hk) * D);
-        xa = x[d];
-        xb = x[d + HALF];
+        float c, s;
         if (rope_tab) {                                // [pos][cos 0..31 | sin 0..31], computed like HF on the host
-            rc = rope_tab[(long)p * D + d];
-            rs = rope_tab[(long)p * D + HALF + d];
+            c = rope_tab[(long)p * D + d];
+            s = rope_tab[(long)p * D + HALF + d];
         } else {
             const float ang = (float)p * inv_freq[d];
-            rc = cosf(ang);
-            rs = sinf(ang);
+            c = cosf(ang);
+            s = sinf(ang);
         }
-        vsrc = src[(Hq + Hkv + hk) * D + (tid & 63)];
-    }
-    Raw8<T> rk0[U], rv0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = kg + u * NG;
-        const long o = j < p ? (((long)pg[u] * Hkv + hk) * page + j % page) * D + dc * 8 : (long)dc * 8;   // (beyond pos: one line)
-        rk0[u].load(kc + o);
-        rv0[u].load(vc + o);
-    }
-    if (tid < 2 * HALF) {
-        const float y0 = xa * rc - xb * rs, y1 = xb * rc + xa * rs;
+        const float y0 = x[d] * c - x[d + HALF] * s, y1 = x[d + HALF] * c + x[d] * s;
         if (which == 0) { qs[d] = y0 * sc2; qs[d + HALF] = y1 * sc2; }
         else { kn[d] = Cvt<T>::to_f(Cvt<T>::from_f(y0)); kn[d + HALF] = Cvt<T>::to_f(Cvt<T>::from_f(y1)); }
     } else if (tid < 2 * HALF + D) {
-        vn[tid - 2 * HALF] = Cvt<T>::to_f(Cvt<T>::from_f(vsrc));
+        const int d = tid - 2 * HALF;
+        vn[d] = Cvt<T>::to_f(Cvt<T>::from_f(src[(Hq + Hkv + hk) * D + d]));
     }
     __syncthreads();
     if (h % group == 0 && tid < D) {                   // one workgroup per kv head appends to the cache
@@ -666,6 +636,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
         kc[o] = Cvt<T>::from_f(kn[tid]);
         vc[o] = Cvt<T>::from_f(vn[tid]);
     }
+    const int kg = tid >> 3, dc = tid & 7;
     float qv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] = qs[dc * 8 + e];
@@ -685,17 +656,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
         m = mn;
     };
     // cached keys: U keys per thread in flight at a time (the loop is a chain of memory round trips otherwise:
-    // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys.  Pass 0 was requested at the top.
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if (kg + u * NG < p) {
-            float kv[8], vv[8];
-            rk0[u].to_float(kv);
-            rv0[u].to_float(vv);
-            consume(kv, vv);
-        }
-    }
-    for (int j0 = kg + NG * U; j0 < p; j0 += NG * U) {
+    // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys
+    constexpr int U = sizeof(T) == 2 ? 12 : 10;       // (fp32 cache: 10 x 64 B per thread in flight, 320 keys per pass)
+    for (int j0 = kg; j0 < p; j0 += NG * U) {
         Raw8<T> rk[U], rv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
