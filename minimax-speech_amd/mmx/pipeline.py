@@ -55,6 +55,23 @@ class TtsEngine:
     group_fan = 1
     batch_encoder = True      # the conformer encoder of a flow group runs as one zero-padded batch (FlowEngine.encode_batch)
 
+    flow_priority = 0      # HIP stream priority of the flow workers' streams (the decode loop runs at -1 = high)
+
+    def _flow_stream(self):
+        """A flow worker's stream.  Priorities outside torch's range (HIP has a low level, +1) go through
+        hipStreamCreateWithPriority and torch.cuda.ExternalStream."""
+        if self.flow_priority in (0, -1):
+            return torch.cuda.Stream(device=self.dev, priority=self.flow_priority)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.dev):
+            rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(0), ctypes.c_int(self.flow_priority))
+        if rc != 0:
+            raise RuntimeError(f"hipStreamCreateWithPriority({self.flow_priority}) -> {rc}")
+        self.__dict__.setdefault("_ext_streams", []).append(h)
+        return torch.cuda.ExternalStream(h.value, device=self.dev)
+
     def _aux_streams(self, cur, n):
         """n auxiliary streams belonging to the stream `cur` (one set per flow worker stream; created once)."""
         pool = self.__dict__.setdefault("_aux", {})
@@ -418,7 +435,7 @@ class TtsEngine:
             # weights are shared), solve different groups concurrently.
             # (CU-masked flow streams, hipExtStreamCreateWithCUMask, were tried to keep CUs free for the decode loop:
             # the mask is not honoured on this pool — an 8192^3 GEMM takes the same time with 1/4 and 4/4 of the CUs)
-            self._sides = [torch.cuda.Stream(device=self.dev, priority=0) for _ in range(flow_workers)]
+            self._sides = [self._flow_stream() for _ in range(flow_workers)]
             self._flows = [self.flow] + [self.flow.clone_shared() for _ in range(flow_workers - 1)]
             self._hi = torch.cuda.Stream(device=self.dev, priority=-1)
         qs, err = [queue_mod.Queue() for _ in range(flow_workers)], []

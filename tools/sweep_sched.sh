@@ -16,6 +16,12 @@ if [ "$3" = "w1" ]; then
   run workers1_h30 --flow-workers 1 --hold-steps 30
   exit 0
 fi
+if [ "$3" = "prio" ]; then
+  run base
+  run prio1 --flow-priority 1
+  run prio2 --flow-priority 2
+  exit 0
+fi
 if [ "$3" = "lm" ]; then
   run base
   run down24 --lm-cfg down=2,4
