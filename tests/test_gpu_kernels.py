@@ -549,7 +549,13 @@ def test_est_tail_fused(env, dt, B, T, masked, with_next):
     w = dict(wo_p=_pk(ops, wo, dt), w1_p=_pk(ops, w1, dt), w2_p=_pk(ops, w2, dt), bo=bo, b1=b1, b2=b2, n3g=n3g, n3b=n3b)
     wqkv_p = _pk(ops, wqkv, dt)
     tol = FUSED_TOL[dt]
-    for bm in FUSED_BM[dt]:
+    # every kernel variant of the build: the library defaults (bf16: 8 waves with 32-column passes for 64 / 32 rows), the
+    # one-wave-per-SIMD kernels, the 64-column-pass 8-wave ones and the two-workgroups-per-CU ones (explicit cfg)
+    variants = [(bm, {}) for bm in FUSED_BM[dt]]
+    if dt == 1:
+        variants += [(64, dict(waves=4, pf=2)), (64, dict(waves=4, pf=4)), (32, dict(waves=4, pf=4)), (32, dict(waves=8, pf=2)),
+                     (32, dict(occ2=True, pf=2)), (16, dict(waves=8)), (32, dict(narrow=True, pf=4)), (64, dict(narrow=True, pf=4))]
+    for bm, cfg in variants:
         xio = x.clone()
         Tp = ops.round_up(T, 8)
         ldq = 1024 if dt == 1 else 1536
@@ -557,7 +563,7 @@ def test_est_tail_fused(env, dt, B, T, masked, with_next):
         vt = torch.full((B, 512, Tp), 7.0, device="cuda", dtype=L.TORCH_DT[dt]) if dt == 1 else None
         act = torch.zeros(B, T, 512, device="cuda", dtype=L.TORCH_DT[dt])
         nxt = ops.est_next(wqkv=wqkv_p, n1g=n1g, n1b=n1b, q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp, vt_bs=512 * Tp) if with_next else None
-        ops.est_tail(aoq.contiguous(), xio, w, B=B, T=T, dtype=dt, bm=bm, rowmask=mask, act_out=act[:, :, 256:], act_ld=512, nxt=nxt)
+        ops.est_tail(aoq.contiguous(), xio, w, B=B, T=T, dtype=dt, bm=bm, rowmask=mask, act_out=act[:, :, 256:], act_ld=512, nxt=nxt, **cfg)
         torch.cuda.synchronize()
         assert rel_err(xio, x2) < tol, (bm, "x", rel_err(xio, x2))
         assert rel_err(act[:, :, 256:], x2) < max(tol, 1e-2 if dt == 1 else 0) and float(act[:, :, :256].abs().max()) == 0.0
