@@ -528,7 +528,6 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     const long ns0 = (long)NK0 * 64 * E, ns1 = (long)NK1 * 64 * E, ns2 = (long)NK2T * 64 * E;
     WRing<T, PW, PF> ring;
     const T* wo_w = wo + (long)(wave * NFN) * ns0;     // this wave's NFN n-fragments of the 256 output columns
-    ring.prime(wo_w, ns0, NK0, NFN);
 
     // Global epilogue operands (residual rows, row mask) are loaded BEFORE the MFMA stage whose epilogue uses them.  A wave
     // waits for a load with s_waitcnt vmcnt(N), which counts in issue order: a load issued in the epilogue would wait for
@@ -538,24 +537,37 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     auto w1_pass = [&](int q) { return w1 + (long)(((q / PPC) * CH + (wave * PPC + q % PPC) * PC) / 16) * ns1; };
     float x1[MF][CW];
     {
-        for (int id = tid; id < TAIL_PRM_FLOATS / 4; id += 64 * NW) {
+        // Everything the prologue reads from global memory is requested before the first wait (the tile copy's): the
+        // parameter vectors into registers, the residual rows (clamped, no branch around a load), the head of the weight
+        // ring, then the attention tile - one memory round trip instead of three.
+        constexpr int PRM_PER = (TAIL_PRM_FLOATS / 4 + 64 * NW - 1) / (64 * NW);
+        float4_t pr[PRM_PER];
+#pragma unroll
+        for (int k = 0; k < PRM_PER; ++k) {
+            const int id0 = tid + k * 64 * NW, id = id0 < TAIL_PRM_FLOATS / 4 ? id0 : TAIL_PRM_FLOATS / 4 - 1;
             const int seg = id >> 6, o4 = (id & 63) * 4;            // 64 float4 per 256-float vector; b1 is segments 6..9
             const float* src = seg == 0 ? p.bo : seg == 1 ? p.n3g : seg == 2 ? p.n3b : seg == 3 ? p.b2
                              : seg == 4 ? (p.next.wqkv ? p.next.n1g : p.b2) : seg == 5 ? (p.next.wqkv ? p.next.n1b : p.b2) : p.b1 + (seg - 6) * 256;
-            *reinterpret_cast<float4_t*>(prm + id * 4) = *reinterpret_cast<const float4_t*>(src + o4);
+            pr[k] = *reinterpret_cast<const float4_t*>(src + o4);
         }
         const float* xr = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int t = t0 + i * 16 + rl;
-            if (t < Tn) loadn<CW>(xr + (long)t * C + col0, x1[i]);
-            else {
+            loadn<CW>(xr + (long)(t < Tn ? t : Tn - 1) * C + col0, x1[i]);
+            if (t >= Tn) {
 #pragma unroll
                 for (int c = 0; c < CW; ++c) x1[i][c] = 0.f;
             }
         }
+        ring.prime(wo_w, ns0, NK0, NFN);
         if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
         else load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, PL0, tid, 64 * NW);
+#pragma unroll
+        for (int k = 0; k < PRM_PER; ++k) {
+            const int id = tid + k * 64 * NW;
+            if (id < TAIL_PRM_FLOATS / 4) *reinterpret_cast<float4_t*>(prm + id * 4) = pr[k];
+        }
         TSTAMP(1);
         __syncthreads();
         TSTAMP(2);
