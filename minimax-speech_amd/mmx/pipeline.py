@@ -474,7 +474,9 @@ class TtsEngine:
         issued = [0]
         arrived, steps_done = {}, [1]
         free_at = [0.0] * flow_workers
-        STEP_MS, GROUP_MS, FRAME_MS = 1.2, 28.0, 0.025          # fitted to MMX_TIMING=2 traces of the round-2 kernels
+        # fitted to MMX_TIMING=3 traces of the round-3 kernels beside the decode loop (a decode step 0.86 ms; a flow group
+        # 44 ms + 9.5 us per frame: 536 frames 50 ms, 2 904 frames 74 ms, 4 196 frames 85 ms)
+        STEP_MS, GROUP_MS, FRAME_MS = 0.86, 44.0, 0.0095
 
         cur = [self.llm, list(range(NS))]                           # active engine, slot -> utterance index
         waiting = list(range(NS, B))                                # utterances waiting for a slot
