@@ -16,7 +16,7 @@ from mmx.llm import LlmEngine  # noqa: E402
 
 dev = torch.device("cuda")
 B = 32
-llm = LlmEngine(synth.synth_state_dict(shapes.llm_manifest(), 0), dtype=1, max_batch=B, max_ctx=640)
+llm = LlmEngine(synth.synth_state_dict(shapes.llm_manifest(), 0), dtype=1, max_batch=B, max_ctx=768)
 fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=1, use_graphs=False)
 blocks = [w for st in fl.mid for w in st["blocks"]]
 g = torch.Generator().manual_seed(2)
@@ -59,7 +59,7 @@ def flash_graph(n, T):
 
 
 def measure(name, gr):
-    llm.start(xs, [400] * B, [400] * B, seed=0)
+    llm.start(xs, [300] * B, [300] * B, seed=0)
     with torch.cuda.stream(hi):
         for _ in range(8):
             llm.step()
