@@ -14,7 +14,7 @@ from mmx import ops, shapes, synth  # noqa: E402
 from mmx.flow import FlowEngine  # noqa: E402
 from mmx.llm import LlmEngine  # noqa: E402
 
-dev = torch.device("cuda")
+dev = torch.device("cuda", 0)
 B = 32
 llm = LlmEngine(synth.synth_state_dict(shapes.llm_manifest(), 0), dtype=1, max_batch=B, max_ctx=768)
 fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=1, use_graphs=False)
