@@ -302,7 +302,6 @@ def _time_steps(fn, build, warmup, steps):
 ATTN = "bf16"
 GROUP_FAN = None
 FLOW_PRIO = None
-FLASH_CAP = None
 
 
 def make_engine(dt, device, max_batch, max_ctx):
@@ -313,9 +312,6 @@ def make_engine(dt, device, max_batch, max_ctx):
         TtsEngine.group_fan = GROUP_FAN
     if FLOW_PRIO is not None:
         TtsEngine.flow_priority = FLOW_PRIO
-    if FLASH_CAP is not None:
-        from mmx.flow import FlowEngine
-        FlowEngine.polite_flash_wgs_default = FLASH_CAP
     return TtsEngine(*build_weights(0), dtype=dt, device=device, max_batch=max_batch, max_ctx=max_ctx, attn=ATTN)
 
 
@@ -334,7 +330,6 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
-    ap.add_argument("--flash-cap", type=int, default=None, help="tuning: workgroup cap of the flash attention in polite flow groups (FlowEngine.polite_flash_wgs; 0 = none)")
     ap.add_argument("--flow-priority", type=int, default=None, help="tuning: HIP stream priority of the flow workers' streams (TtsEngine.flow_priority)")
     ap.add_argument("--lm-cfg", default="", help="tuning: LlmEngine.v2_cfg overrides (output tiles per workgroup, k slices), e.g. gu=2,1:down=2,4")
     ap.add_argument("--group-fan", type=int, default=None, help="auxiliary streams per flow group for its per-utterance stages (TtsEngine.group_fan)")
@@ -348,8 +343,8 @@ def main():
     ap.add_argument("--tail-active", type=int, default=0, help="with at most this many sequences still decoding, finished utterances go to an idle flow worker at once")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
-    global ATTN, GROUP_FAN, FLOW_PRIO, FLASH_CAP
-    ATTN, GROUP_FAN, FLOW_PRIO, FLASH_CAP = a.attn, a.group_fan, a.flow_priority, a.flash_cap
+    global ATTN, GROUP_FAN, FLOW_PRIO
+    ATTN, GROUP_FAN, FLOW_PRIO = a.attn, a.group_fan, a.flow_priority
     if a.lm_cfg:
         from mmx.llm import LlmEngine
         LlmEngine.v2_cfg = dict(LlmEngine.v2_cfg, **{kv.split("=")[0]: tuple(int(v) for v in kv.split("=")[1].split(",")) for kv in a.lm_cfg.split(":")})

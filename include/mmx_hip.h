@@ -158,9 +158,7 @@ int mmx_cfg_euler(float* x, const float* d_cond, const float* d_uncond, float cf
  *   prefixes (decoder.py:433-445 with a padding mask): keys j >= klen[b] are invisible, key tiles beyond klen[b] are not
  *   visited, query rows >= klen[b] (padding) that fill a whole workgroup are written as zeros.  Cheaper than the same
  *   mask given as keymask (which makes every tile a masked tile).
- 
- * max_wgs (mmx_attn_flash_bf16 only; 0 = one workgroup per query tile): caps the grid - a workgroup then walks several query
- * tiles - so that a launch beside the LM decode loop leaves CUs free (rounded down to a multiple of 8). */
+ */
 int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                    const void* v, int64_t ldv, int64_t v_bs, void* out, int64_t ldo, int64_t o_bs,
                    int B, int H, int D, int Tq, int Tk, float scale, const float* keymask, int64_t km_bs, int chunk,
@@ -169,7 +167,7 @@ int mmx_attn_dense(const void* q, int64_t ldq, int64_t q_bs, const void* k, int6
 int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                         int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk, int q_begin,
-                        const int32_t* klen, int max_wgs, hipStream_t stream);
+                        const int32_t* klen, hipStream_t stream);
 /* mmx_attn_flash_xs: the split build's attention on operands the PRODUCER has already split (MmxEstNext, MMX_X2 with
  * vt_out): qk bf16 [B][T][ldqk >= 2048] = [hi Q | hi K | lo Q | lo K], vt bf16 [B][2][512][ldvt], out fp32 [B][T][ldo].
  * mmx_attn_flash_x: the same contract on fp32 operands:

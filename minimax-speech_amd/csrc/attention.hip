@@ -3,7 +3,6 @@
 //                       masks) — the parity path and the conformer encoder (10 layers, once per utterance).
 //   attn_flash_kernel : bf16 MFMA flash attention for the estimator's 56 blocks x 10 Euler steps
 //                       (the flow's dominant FLOPs: SURVEY.md §8d, 57.3 of 189.5 GFLOP per call).
-#include <algorithm>
 #include "common.h"
 #include "../../include/mmx_hip.h"
 #include <type_traits>
@@ -162,12 +161,12 @@ __device__ __forceinline__ uint2 bf16x8_to_fp8(uint4 v) {      // 8 bf16 -> 8 e4
 // NW waves of 16 * MF queries.  NW = 8, MF = 1 (two waves per SIMD, 128 queries per workgroup as with NW = 4, MF = 2): the softmax
 // VALU phase of one wave runs under the MFMA phase of its SIMD partner (one wave per SIMD runs them one after the other: PMC
 // of round 2, VALU active 50 %, MFMA busy 17 %); every K / V^T fragment read then feeds one MFMA instead of two.
-template <int MF, bool FP8, int NW>
-__device__ __forceinline__ void attn_flash_item(
+template <int MF, bool FP8, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_flash_kernel(
     const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
     const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
     int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
-    int q_begin, const int32_t* __restrict__ klen, int item) {
+    int q_begin, const int32_t* __restrict__ klen) {
     // LDS row pitches.  A fragment read is ds_read_b128 at (row l16, 16-byte chunk g); the hardware serves it in the lane
     // groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS), i.e. 16 different rows with two
     // adjacent chunks per group: a 144 B pitch puts 7 of the 16 lanes on busy banks (8 LDS cycles instead of 4; PMC:
@@ -184,7 +183,7 @@ __device__ __forceinline__ void attn_flash_item(
     const int g = lane >> 4, l16 = lane & 15;
     // XCD-aware mapping (1-D grid): the query tiles of one (batch, head) pair read the same K / V^T rows; they get
     // linear ids with the same id % 8, i.e. the same XCD and L2, instead of being dealt round robin over all eight.
-    const int xcd = item & 7, slot = item >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pair = (slot / nq) * 8 + xcd;
     if (pair >= npairs) return;                        // uniform: the grid is padded to a multiple of 8 pairs
     const int qt = slot % nq;
@@ -456,25 +455,6 @@ __device__ __forceinline__ void attn_flash_item(
             pk.y = pack_bf16x2(o[mf][df][2] * inv, o[mf][df][3] * inv);
             *reinterpret_cast<uint2*>(out + (long)i * ldo + df * 16 + 4 * g) = pk;
         }
-    }
-}
-
-
-// The launch: workgroup w takes the items (query tile of a (batch, head) pair) w, w + gridDim.x, ...  With the full grid
-// (gridDim.x = nitems) that is one item each.  A capped grid (max_wgs of mmx_attn_flash_bf16, a multiple of 8 so that an
-// item keeps its XCD) keeps the rest of the chip free: beside the LM decode loop a full-grid flash launch (640 workgroups at
-// 5 x 1000 frames, two per CU) was the flow kernel that slowed the decode step most (tools/contention_lab.py: 2.6 x while
-// it runs, against 1.6 x beside the 160 workgroups of the fused tail kernel).
-template <int MF, bool FP8, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void attn_flash_kernel(
-    const bf16_t* __restrict__ q, long ldq, long q_bs, const bf16_t* __restrict__ k, long ldk, long k_bs,
-    const bf16_t* __restrict__ vt, long ldvt, long vt_bs, bf16_t* __restrict__ out, long ldo, long o_bs,
-    int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
-    int q_begin, const int32_t* __restrict__ klen, int nitems) {
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        if (item != (int)blockIdx.x) __syncthreads();  // every wave is done with the previous item's LDS tiles
-        attn_flash_item<MF, FP8, NW>(q, ldq, q_bs, k, ldk, k_bs, vt, ldvt, vt_bs, out, ldo, o_bs, Tn, scale, keymask, km_bs, chunk, nq, nheads,
-                                     npairs, q_begin, klen, item);
     }
 }
 
@@ -929,8 +909,8 @@ __global__ __launch_bounds__(256) void attn_flash_splitk_kernel(
 extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk, int64_t k_bs,
                                    const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                                    int B, int H, int T_, float scale, const float* keymask, int64_t km_bs, int chunk,
-                                   int q_begin, const int32_t* klen, int max_wgs, hipStream_t stream) {
-    MMX_CHECK_ARG(q && k && vt && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0 && max_wgs >= 0);
+                                   int q_begin, const int32_t* klen, hipStream_t stream) {
+    MMX_CHECK_ARG(q && k && vt && out && B > 0 && H > 0 && T_ > 0 && chunk >= 0);
     MMX_CHECK_ARG(q_begin >= 0 && q_begin < T_ && q_begin % 16 == 0);
     MMX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0);
     MMX_CHECK_ARG(ldvt >= ((T_ + 7) / 8) * 8);
@@ -949,15 +929,13 @@ extern "C" int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, con
     }
     const bool small = (long)npairs * ((Tq + 127) / 128) < 192;         // fewer 128-query tiles than ~3/4 of the CUs
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
-    const int nitems = 8 * ((npairs + 7) / 8) * nq;
-    const int cap = max_wgs > 0 ? std::max(8, max_wgs / 8 * 8) : nitems;     // a multiple of 8: an item keeps its XCD
-    dim3 grid(std::min(nitems, cap));
+    dim3 grid(8 * ((npairs + 7) / 8) * nq);
     if (small)
         hipLaunchKernelGGL((attn_flash_kernel<1, false>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
-                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen, nitems);
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     else
         hipLaunchKernelGGL((attn_flash_kernel<1, false, 8>), grid, dim3(512), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
-                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen, nitems);
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
@@ -975,14 +953,13 @@ extern "C" int mmx_attn_flash_fp8(const void* q, int64_t ldq, int64_t q_bs, cons
     const int npairs = H * B, Tq = T_ - q_begin;
     const bool small = (long)npairs * ((Tq + 127) / 128) < 192;
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
-    const int nitems = 8 * ((npairs + 7) / 8) * nq;
-    dim3 grid(nitems);
+    dim3 grid(8 * ((npairs + 7) / 8) * nq);
     if (small)
         hipLaunchKernelGGL((attn_flash_kernel<1, true>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
-                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen, nitems);
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     else
         hipLaunchKernelGGL((attn_flash_kernel<2, true>), grid, dim3(256), 0, stream, (const bf16_t*)q, ldq, q_bs, (const bf16_t*)k, ldk, k_bs,
-                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen, nitems);
+                           (const bf16_t*)vt, ldvt, vt_bs, (bf16_t*)out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

@@ -150,9 +150,6 @@ class FlowEngine:
         # beside them on another stream (the LM decode loop of TtsEngine.tts_batch) keeps more of the chip
         # (measured, 32-utterance step: decode loop 548 -> 523 ms, step 643 -> 622 ms).  Part of the plan key.
         self.polite = False
-        # polite groups also cap the flash attention's grid (workgroups walk several query tiles): a full-grid flash launch
-        # is the flow kernel that slows the decode step beside it most (tools/contention_lab.py)
-        self.polite_flash_wgs = getattr(FlowEngine, "polite_flash_wgs_default", 160)
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -705,8 +702,7 @@ class FlowEngine:
             if bf:
                 ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
                                     k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125,
-                                    keymask=(None if klen is not None else mask), chunk=chunk, fp8=self.attn_fp8, klen=klen,
-                                    max_wgs=(self.polite_flash_wgs if self.polite else 0))
+                                    keymask=(None if klen is not None else mask), chunk=chunk, fp8=self.attn_fp8, klen=klen)
             elif self.split:
                 ops.attn_flash_xs(qk, vt, ao, B=B, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=vt_bs, o_bs=T * 512,
                                   scale=0.125, keymask=(None if klen is not None else mask), chunk=chunk, klen=klen)

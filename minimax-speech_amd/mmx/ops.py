@@ -235,7 +235,7 @@ def attn_relpos_bf16(q, k, vt, pos, pos_u, pos_v, out, *, B, H, T, ldq, ldk, ldv
 
 
 def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, keymask=None,
-                    chunk=0, q_begin=0, km_bs=None, fp8=False, klen=None, max_wgs=0):
+                    chunk=0, q_begin=0, km_bs=None, fp8=False, klen=None):
     """klen: int32 [B] valid keys per batch row (prefix masks of a padded batch) - see include/mmx_hip.h."""
     if klen is not None:
         assert klen.dtype == torch.int32 and klen.numel() >= B
@@ -246,8 +246,7 @@ def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, 
         return
     check(load().mmx_attn_flash_bf16(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(vt), i64(ldvt),
                                      i64(vt_bs), _p(out), i64(ldo), i64(o_bs), B, H, T, C.c_float(scale),
-                                     _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen), int(max_wgs), stream()),
-          "mmx_attn_flash_bf16")
+                                     _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen), stream()), "mmx_attn_flash_bf16")
 
 
 def attn_flash_x(q, k, v, out, *, B, H, T, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, keymask=None, chunk=0, q_begin=0,

@@ -49,13 +49,13 @@ def tail_graph(n, T, bm, **cfg):
     return graph_of(one, 112)
 
 
-def flash_graph(n, T, max_wgs=0):
+def flash_graph(n, T):
     Bf, Tp = 2 * n, ops.round_up(T, 8)
     qk = torch.randn(Bf, T, 1024, device=dev).to(fl.tdt)
     vt = torch.randn(Bf, 512, Tp, device=dev).to(fl.tdt)
     ao = torch.empty(Bf, T, 512, device=dev, dtype=fl.tdt)
     return graph_of(lambda i=0: ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=Bf, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
-                                                    k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, max_wgs=max_wgs), 112)
+                                                    k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125), 112)
 
 
 def measure(name, gr):
@@ -96,6 +96,4 @@ measure("beside est_tail 5x1000, 64 rows x 4 waves (160 wg)", tail_graph(5, 1000
 measure("beside est_tail 5x1000, 32 rows x 8 waves (320 wg)", tail_graph(5, 1000, 32))
 measure("beside est_tail 2x1000, 64 rows (64 wg)", tail_graph(2, 1000, 64))
 measure("beside flash 5x1000", flash_graph(5, 1000))
-for cap in (256, 160, 128, 96):
-    measure(f"beside flash 5x1000, grid capped at {cap}", flash_graph(5, 1000, cap))
 measure("alone again", None)

@@ -16,14 +16,6 @@ if [ "$3" = "w1" ]; then
   run workers1_h30 --flow-workers 1 --hold-steps 30
   exit 0
 fi
-if [ "$3" = "flash" ]; then
-  run cap0 --flash-cap 0
-  run cap160 --flash-cap 160
-  run cap128 --flash-cap 128
-  run cap96 --flash-cap 96
-  run cap256 --flash-cap 256
-  exit 0
-fi
 if [ "$3" = "prio" ]; then
   run base
   run prio1 --flow-priority 1
