@@ -64,6 +64,34 @@ def test_dac_fused_residual_units_vs_two_launch_path(golden_dir, dt, tol):
         assert err < tol, (dt, B, T, err)
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+def test_dac_fused_unit_lengths(golden_dir, dt):
+    """mmx_dac_ru with per-utterance lengths (a zero-padded batch): a member's valid rows equal the unit run on that member
+    alone (rows beyond its length read as conv padding), its rows beyond the length are written as zero - x_out and act_out."""
+    from mmx import ops
+    from mmx._lib import TORCH_DT
+    from mmx.dac import DacDecoderEngine
+    from oracle import weights as W
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_dac80.json")), SEED)
+    eng = DacDecoderEngine(sd, RATES, dtype=dt)
+    g = torch.Generator().manual_seed(3)
+    for blk in eng.blocks:
+        if not blk["fused"]:
+            continue
+        C_, T, lens = blk["cout"], 300, [300, 173]
+        x = torch.randn(2, T, C_, generator=g).cuda()
+        lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        for ru in blk["rus"]:
+            xo, ao = torch.full_like(x, 7.0), torch.full((2, T, C_), 7.0, dtype=TORCH_DT[dt], device="cuda")
+            ops.dac_ru(x, xo, ru, B=2, T=T, C_=C_, dil=ru["dil"], dtype=dt, act_out=ao, alpha_next=ru["a0"], lens=lens_t)
+            for b, n in enumerate(lens):
+                x1 = x[b:b + 1, :n].contiguous()
+                xo1, ao1 = torch.empty_like(x1), torch.empty(1, n, C_, dtype=TORCH_DT[dt], device="cuda")
+                ops.dac_ru(x1, xo1, ru, B=1, T=n, C_=C_, dil=ru["dil"], dtype=dt, act_out=ao1, alpha_next=ru["a0"])
+                assert torch.equal(xo[b, :n], xo1[0]) and torch.equal(ao[b, :n], ao1[0]), (C_, ru["dil"], b)
+                assert float(xo[b, n:].abs().max() if n < T else 0.0) == 0.0 and float(ao[b, n:].float().abs().max() if n < T else 0.0) == 0.0
+
+
 # ----------------------------------------------------------------------------- encoder (SURVEY §8f row 3)
 ENC_RATES = [2, 3, 4, 4, 5]
 
