@@ -306,7 +306,9 @@ class FlowEngine:
             qk = self._new(R, 1024)
             ops.linear(hn, lw["wqkv"][:1024], 512, dtype=dt, bias=lw["bqkv"][:1024], out_act=qk)
             Tp = ops.round_up(T, 8)
-            vt = self._vt_buf(B, Tp)                          # [B][512][Tp], pad columns zero
+            vt = self._new(B, 512, Tp)                        # [B][512][Tp]; not from the plan-lifetime cache (_vt_buf):
+            if Tp > T:                                        # an encoder call's shape is arbitrary, the cache would only grow
+                vt[:, :, T:].zero_()                          # pad columns must be finite: the flash tiles read 8 at a time
             ops.gemm(lw["wqkv"][1024:], hn, 512, T, dtype=dt, lda=lw["wqkv"].shape[1], cin=512, batch=B, a_bstride=0,
                      w_bstride=T * 512, bias=lw["bqkv"][1024:], bias_per_row=True, out_act=vt, ldo_a=Tp, oa_bstride=512 * Tp)
             ops.attn_relpos_bf16(qk, qk[:, 512:], vt, p, lw["pu"], lw["pv"], ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp,
