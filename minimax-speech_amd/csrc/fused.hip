@@ -492,8 +492,8 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 // spilling (the 64-column-pass version spilled 400 bytes per lane), with a ring 4 k-steps deep: 8 waves x 8 KB of weight
 // fragments in flight per CU instead of 4 x 8 KB.  At depth 2 a fragment is requested two k-steps (0.25 us of MFMAs) before
 // its use, less than an L2 hit takes, so the one-wave-per-SIMD kernel waits in every k-step (tools/tail_lab.py --stamps).
-template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1, int PW = 4>
-__global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams p) {
+template <typename T, int BM, int PF, int NW, int NS, int PW>
+__device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const int tile) {
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PC = 16 * PW, PPC = CH / (PC * NW);
     static_assert(NFN <= PW, "the ring is PW fragments wide");
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
     float* patch = patch_all + wave * PATCH_FLOATS;
-    const int b = blockIdx.y, t0 = p.t_begin + blockIdx.x * BM, Tn = p.T;
+    const int b = blockIdx.y, t0 = p.t_begin + tile * BM, Tn = p.T;
     const int col0 = wave * WC + (lane & 3) * CW;      // this lane's CW columns of a 256-wide row
     unsigned long long* st = g_tail_stamps;
     if (st) st += ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 64;
@@ -683,6 +683,27 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
         ln_qkv<T, MF, PF, NW, NS, PW>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
     }
     TSTAMP(63);
+}
+
+// TPW row tiles per workgroup, one after the other (compile-time: TPW = 1 is the plain kernel).  TPW = 2 halves the number of
+// workgroups of a launch at the same work: the flow groups that run beside the LM decode loop then leave more CUs to it
+// (tools/contention_lab.py: the decode step takes 1.6 x beside 160 resident workgroups of this kernel, 2.4 x beside 320).
+template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1, int PW = 4, int TPW = 1>
+__global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams p) {
+    if constexpr (TPW == 1) {
+        est_tail_tile<T, BM, PF, NW, NS, PW>(p, blockIdx.x);
+    } else {
+        const int ntiles = (p.T - p.t_begin + BM - 1) / BM;
+        // (two inlined copies: as a rolled loop the compiler spilled 300 - 1700 bytes per lane)
+        est_tail_tile<T, BM, PF, NW, NS, PW>(p, blockIdx.x * TPW);
+        if (blockIdx.x * TPW + 1 < ntiles) {            // uniform
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                            // every wave is done with the previous tile's LDS
+            __builtin_amdgcn_sched_barrier(0);
+            est_tail_tile<T, BM, PF, NW, NS, PW>(p, blockIdx.x * TPW + 1);
+        }
+        static_assert(TPW == 2, "two copies");
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1073,18 +1094,27 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % (dtype == MMX_X2 ? 4 : 8) == 0 && p.act_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
     const int nw = (cfg >> 4) & 15, occ2 = (cfg >> 8) & 1;
-#define TAILP(TT, BM, PF, NW, NS, OCC, PW)                                                                \
+#define TAILT(TT, BM, PF, NW, NS, OCC, PW, TPW)                                                           \
     do {                                                                                                   \
         const size_t lds = tail_lds<TT, BM, NW, NS>();                                                     \
         MMX_CHECK_ARG(lds * OCC <= 160 * 1024);                                                            \
-        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW>), lds);                               \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW>), lds);                          \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW>), dim3(((p.T - p.t_begin + BM - 1) / BM + TPW - 1) / TPW, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
+#define TAILP(TT, BM, PF, NW, NS, OCC, PW) TAILT(TT, BM, PF, NW, NS, OCC, PW, 1)
 #define TAILO(TT, BM, PF, NW, NS, OCC) TAILP(TT, BM, PF, NW, NS, OCC, 4)
 #define TAILN(TT, BM, PF, NW, NS) TAILO(TT, BM, PF, NW, NS, 1)
 #define TAIL(TT, BM, PF, NW) TAILN(TT, BM, PF, NW, 1)
     int narrow = (cfg >> 9) & 1;
     int pf = cfg & 15;
+    if ((cfg >> 10) & 1) {                             // two row tiles per workgroup: the tile defaults of the two fast builds only
+        if (dtype == MMX_BF16 && bm == 64) TAILT(bf16_t, 64, 2, 8, 1, 1, 2, 2);
+        else if (dtype == MMX_BF16 && bm == 32) TAILT(bf16_t, 32, 8, 8, 1, 1, 2, 2);
+        else if (dtype == MMX_X2 && bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 2);
+        else return MMX_EARG;
+        MMX_LAUNCH_CHECK();
+        return MMX_OK;
+    }
     // library defaults of the bf16 build (cfg = 0): the narrow-pass 8-wave kernels for the 64- and 32-row tiles (measured per
     // launch at 10 000 rows: 51.1 us against 58.7 us with 4 waves x 64-column passes; 32 rows, 4 000 rows: 31.8 against 33.0)
     if (cfg == 0 && dtype == MMX_BF16 && (bm == 64 || bm == 32)) { narrow = 1; pf = bm == 64 ? 2 : 8; }
@@ -1127,6 +1157,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
 #undef TAILN
 #undef TAILO
 #undef TAILP
+#undef TAILT
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }

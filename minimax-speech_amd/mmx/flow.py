@@ -18,7 +18,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, is_split
+from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, X2, is_split
 
 
 def espnet_rel_pe(T: int, d: int) -> torch.Tensor:
@@ -150,6 +150,7 @@ class FlowEngine:
         # beside them on another stream (the LM decode loop of TtsEngine.tts_batch) keeps more of the chip
         # (measured, 32-utterance step: decode loop 548 -> 523 ms, step 643 -> 622 ms).  Part of the plan key.
         self.polite = False
+        self.polite_tpw2 = getattr(FlowEngine, "polite_tpw2_default", False)   # polite groups: two row tiles per est_tail workgroup
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -721,7 +722,8 @@ class FlowEngine:
                 attention()
                 last = j == len(blocks) - 1
                 ops.est_tail(ao, xs, w, B=B, T=T, dtype=dt, bm=bm_t, rowmask=(mask if last else None),
-                             act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])))
+                             act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])),
+                             tpw2=(self.polite and self.polite_tpw2 and bm_t in (32, 64) and dt in (BF16, X2)))
 
         # down block: its last transformer block drops the masked activation copy into cat[:, :, C:] (the skip)
         stage(self.down, h0, 320, 320, cat[:, :, C:], 2 * C)

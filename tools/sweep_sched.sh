@@ -16,6 +16,11 @@ if [ "$3" = "w1" ]; then
   run workers1_h30 --flow-workers 1 --hold-steps 30
   exit 0
 fi
+if [ "$3" = "tpw" ]; then
+  run base
+  run tpw2 --tpw2
+  exit 0
+fi
 if [ "$3" = "prio" ]; then
   run base
   run prio1 --flow-priority 1

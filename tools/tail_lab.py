@@ -38,15 +38,16 @@ def run(n, T, bm, waves, pf):
         w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
         nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
                            vt_bs=vt_bs)
-        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=100 <= waves < 200, narrow=waves >= 200)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=100 <= waves < 200, narrow=200 <= waves < 300, tpw2=waves >= 300)
 
     return _event_time_graph(one, 2 * len(blocks))
 
 
 def sweep():
     # waves 1xx: the two-workgroups-per-CU variants (4 waves each); 2xx: 8 waves with 32-column passes
-    cfgs = ([(32, 8, 0), (32, 208, 2), (32, 208, 4), (16, 8, 0), (16, 104, 2)] if split else
-            [(64, 4, 2), (64, 208, 2), (64, 208, 4), (32, 8, 2), (32, 208, 4), (32, 208, 8), (32, 104, 2), (16, 8, 4)])
+    # 3xx: the default kernel of (dtype, rows) with two row tiles per workgroup
+    cfgs = ([(32, 8, 0), (32, 300, 0), (16, 8, 0), (16, 104, 2)] if split else
+            [(64, 4, 2), (64, 208, 2), (64, 300, 0), (32, 208, 8), (32, 300, 0), (32, 104, 2), (16, 8, 4)])
     for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
         line = []
