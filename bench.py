@@ -330,7 +330,7 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
-    ap.add_argument("--tpw2", action="store_true", help="tuning: polite flow groups run est_tail with two row tiles per workgroup (FlowEngine.polite_tpw2)")
+    ap.add_argument("--tpw2", type=int, default=None, help="tuning: 1 / 0 = polite flow groups run est_tail with two / one row tiles per workgroup (FlowEngine.polite_tpw2; default: split build only)")
     ap.add_argument("--flow-priority", type=int, default=None, help="tuning: HIP stream priority of the flow workers' streams (TtsEngine.flow_priority)")
     ap.add_argument("--lm-cfg", default="", help="tuning: LlmEngine.v2_cfg overrides (output tiles per workgroup, k slices), e.g. gu=2,1:down=2,4")
     ap.add_argument("--group-fan", type=int, default=None, help="auxiliary streams per flow group for its per-utterance stages (TtsEngine.group_fan)")
@@ -346,9 +346,9 @@ def main():
     a = ap.parse_args()
     global ATTN, GROUP_FAN, FLOW_PRIO
     ATTN, GROUP_FAN, FLOW_PRIO = a.attn, a.group_fan, a.flow_priority
-    if a.tpw2:
+    if a.tpw2 is not None:
         from mmx.flow import FlowEngine
-        FlowEngine.polite_tpw2_default = True
+        FlowEngine.polite_tpw2_default = bool(a.tpw2)
     if a.lm_cfg:
         from mmx.llm import LlmEngine
         LlmEngine.v2_cfg = dict(LlmEngine.v2_cfg, **{kv.split("=")[0]: tuple(int(v) for v in kv.split("=")[1].split(",")) for kv in a.lm_cfg.split(":")})

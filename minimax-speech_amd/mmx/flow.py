@@ -150,7 +150,10 @@ class FlowEngine:
         # beside them on another stream (the LM decode loop of TtsEngine.tts_batch) keeps more of the chip
         # (measured, 32-utterance step: decode loop 548 -> 523 ms, step 643 -> 622 ms).  Part of the plan key.
         self.polite = False
-        self.polite_tpw2 = getattr(FlowEngine, "polite_tpw2_default", False)   # polite groups: two row tiles per est_tail workgroup
+        # polite groups: two row tiles per est_tail workgroup.  On for the split build, whose LDS allows 32-row tiles only (twice
+        # the workgroups of the bf16 build's polite launches): measured on the config-4 share 465 -> 473 audio-s/s (the decode
+        # loop ends 15 ms earlier); off for the bf16 build (64-row tiles: 702 -> 670, the flow groups fall behind)
+        self.polite_tpw2 = getattr(FlowEngine, "polite_tpw2_default", None)
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -723,7 +726,7 @@ class FlowEngine:
                 last = j == len(blocks) - 1
                 ops.est_tail(ao, xs, w, B=B, T=T, dtype=dt, bm=bm_t, rowmask=(mask if last else None),
                              act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])),
-                             tpw2=(self.polite and self.polite_tpw2 and bm_t in (32, 64) and dt in (BF16, X2)))
+                             tpw2=(self.polite and (self.split if self.polite_tpw2 is None else self.polite_tpw2) and bm_t in (32, 64) and dt in (BF16, X2)))
 
         # down block: its last transformer block drops the masked activation copy into cat[:, :, C:] (the skip)
         stage(self.down, h0, 320, 320, cat[:, :, C:], 2 * C)

@@ -554,7 +554,8 @@ def test_est_tail_fused(env, dt, B, T, masked, with_next):
     variants = [(bm, {}) for bm in FUSED_BM[dt]]
     if dt == 1:
         variants += [(64, dict(waves=4, pf=2)), (64, dict(waves=4, pf=4)), (32, dict(waves=4, pf=4)), (32, dict(waves=8, pf=2)),
-                     (32, dict(occ2=True, pf=2)), (16, dict(waves=8)), (32, dict(narrow=True, pf=4)), (64, dict(narrow=True, pf=4))]
+                     (32, dict(occ2=True, pf=2)), (16, dict(waves=8)), (32, dict(narrow=True, pf=4)), (64, dict(narrow=True, pf=4)),
+                     (64, dict(tpw2=True)), (32, dict(tpw2=True))]
     for bm, cfg in variants:
         xio = x.clone()
         Tp = ops.round_up(T, 8)

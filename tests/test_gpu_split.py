@@ -312,3 +312,29 @@ def test_zero_shot_batch_vs_oracle():
             err = (wavs[b].cpu() - wav).abs().max().item()
             print(f"zero-shot batch (overlap={overlap}) utterance {b}: {len(toks)} ids identical, waveform max abs err {err:.3e}")
             assert wavs[b].shape == wav.shape and err <= 1e-3, (b, err)
+
+
+def test_est_tail_two_tiles_per_workgroup_split_build():
+    """mmx_est_tail, split build, two row tiles per workgroup (the polite flow groups' launch form) == one tile per workgroup,
+    bit for bit: the same per-tile arithmetic, only the workgroup that runs a tile differs (ragged last tile, odd tile count)."""
+    from mmx import ops, shapes, synth
+    from mmx.flow import FlowEngine
+    fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0), dtype=X2, use_graphs=False)
+    blocks = [w for st in fl.mid for w in st["blocks"]]
+    g = torch.Generator().manual_seed(9)
+    B, T = 3, 150                                       # 5 tiles of 32 rows per batch member, the last one ragged
+    Tp = ops.round_up(T, 8)
+    ao = torch.randn(B, T, 512, generator=g).cuda()
+    x0 = torch.randn(B, T, 256, generator=g).cuda()
+    outs = []
+    for tpw2 in (False, True):
+        x = x0.clone()
+        qk = torch.zeros(B, T, 2048, dtype=torch.bfloat16, device="cuda")
+        vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device="cuda")
+        w, wn = blocks[0], blocks[1]
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=2048, q_bs=T * 2048, vt_out=vt, ldvt=Tp, vt_bs=2 * 512 * Tp)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=X2, bm=32, nxt=nxt, tpw2=tpw2)
+        torch.cuda.synchronize()
+        outs.append((x, qk, vt))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -18,7 +18,8 @@ if [ "$3" = "w1" ]; then
 fi
 if [ "$3" = "tpw" ]; then
   run base
-  run tpw2 --tpw2
+  run tpw2 --tpw2 1
+  run tpw1 --tpw2 0
   exit 0
 fi
 if [ "$3" = "prio" ]; then
