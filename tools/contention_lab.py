@@ -1,5 +1,5 @@
 """How much one kind of flow launch, replayed continuously on a normal-priority stream, slows the LM decode step that runs
-on the high-priority stream beside it (batch 32, context ~300).    python tools/contention_lab.py"""
+on the high-priority stream beside it (batch 32, context ~300).    python tools/contention_lab.py [bf16|x]"""
 import gc
 import os
 import sys
@@ -16,8 +16,10 @@ from mmx.llm import LlmEngine  # noqa: E402
 
 dev = torch.device("cuda", 0)
 B = 32
-llm = LlmEngine(synth.synth_state_dict(shapes.llm_manifest(), 0), dtype=1, max_batch=B, max_ctx=768)
-fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=1, use_graphs=False)
+SPLIT = len(sys.argv) > 1 and sys.argv[1] == "x"
+FDT = 2 if SPLIT else 1
+llm = LlmEngine(synth.synth_state_dict(shapes.llm_manifest(), 0), dtype=(3 if SPLIT else 1), max_batch=B, max_ctx=768)
+fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=FDT, use_graphs=False)
 blocks = [w for st in fl.mid for w in st["blocks"]]
 g = torch.Generator().manual_seed(2)
 z = torch.zeros(1, 0, dtype=torch.long, device=dev)
@@ -40,17 +42,29 @@ def tail_graph(n, T, bm, **cfg):
     Bf, Tp = 2 * n, ops.round_up(T, 8)
     ao = torch.randn(Bf, T, 512, device=dev).to(fl.tdt)
     x = torch.randn(Bf, T, fl.C, device=dev)
-    qk, vt = fl._new(Bf, T, 1024), torch.zeros(Bf, 512, Tp, dtype=fl.tdt, device=dev)
+    if SPLIT:
+        qk = torch.empty(Bf, T, 2048, dtype=torch.bfloat16, device=dev)
+        vt = torch.zeros(Bf, 2, 512, Tp, dtype=torch.bfloat16, device=dev)
+        ldq, vt_bs = 2048, 2 * 512 * Tp
+    else:
+        qk, vt = fl._new(Bf, T, 1024), torch.zeros(Bf, 512, Tp, dtype=fl.tdt, device=dev)
+        ldq, vt_bs = 1024, 512 * Tp
 
     def one(i=0):
         w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
-        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=1024, q_bs=T * 1024, vt_out=vt, ldvt=Tp, vt_bs=512 * Tp)
-        ops.est_tail(ao, x, w, B=Bf, T=T, dtype=1, bm=bm, nxt=nxt, **cfg)
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp, vt_bs=vt_bs)
+        ops.est_tail(ao, x, w, B=Bf, T=T, dtype=FDT, bm=bm, nxt=nxt, **cfg)
     return graph_of(one, 112)
 
 
 def flash_graph(n, T):
     Bf, Tp = 2 * n, ops.round_up(T, 8)
+    if SPLIT:
+        qk = torch.randn(Bf, T, 2048, device=dev).bfloat16()
+        vt = torch.randn(Bf, 2, 512, Tp, device=dev).bfloat16()
+        ao = torch.empty(Bf, T, 512, device=dev)
+        return graph_of(lambda i=0: ops.attn_flash_xs(qk, vt, ao, B=Bf, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=2 * 512 * Tp,
+                                                      o_bs=T * 512, scale=0.125), 112)
     qk = torch.randn(Bf, T, 1024, device=dev).to(fl.tdt)
     vt = torch.randn(Bf, 512, Tp, device=dev).to(fl.tdt)
     ao = torch.empty(Bf, T, 512, device=dev, dtype=fl.tdt)
@@ -91,6 +105,14 @@ def measure(name, gr):
 
 
 measure("alone", None)
+if SPLIT:
+    measure("beside est_tail 5x1000, 32 rows x 8 waves (320 wg)", tail_graph(5, 1000, 32))
+    measure("beside est_tail 5x1000, 32 rows, 2 tiles per wg (160 wg)", tail_graph(5, 1000, 32, tpw2=True))
+    measure("beside est_tail 2x1000, 32 rows (128 wg)", tail_graph(2, 1000, 32))
+    measure("beside flash_xs 5x1000", flash_graph(5, 1000))
+    measure("beside flash_xs 2x1000", flash_graph(2, 1000))
+    measure("alone again", None)
+    sys.exit(0)
 measure("beside est_tail 5x1000, 64 rows x 8 waves (160 wg)", tail_graph(5, 1000, 64))
 measure("beside est_tail 5x1000, 64 rows x 4 waves (160 wg)", tail_graph(5, 1000, 64, waves=4, pf=2))
 measure("beside est_tail 5x1000, 32 rows x 8 waves (320 wg)", tail_graph(5, 1000, 32))
