@@ -180,9 +180,7 @@ int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const float* k, 
                      int q_begin, const int32_t* klen, hipStream_t stream);
 int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, const void* vt, int64_t ldvt, int64_t vt_bs,
                       float* out, int64_t ldo, int64_t o_bs, int B, int H, int T, float scale, const float* keymask,
-                      int64_t km_bs, int chunk, int q_begin, const int32_t* klen, int max_wgs, hipStream_t stream);
-/* (max_wgs, mmx_attn_flash_xs only: 0 = one workgroup per 128-query tile; otherwise the grid is capped at max_wgs rounded down
- * to a multiple of 8 and a workgroup walks several tiles - a launch beside the LM decode loop then leaves CUs free.) */
+                      int64_t km_bs, int chunk, int q_begin, const int32_t* klen, hipStream_t stream);
 /* Conformer rel-pos attention on the MFMA (speech/cosyvoice/transformer/attention.py:215-330), bf16 build:
  *   score(i, j) = ((q_i + pos_u) . k_j + (q_i + pos_v) . pos[T - 1 - i + j]) * scale      (rel_shift folded into the index)
  * q, k: bf16 rows (head h at column h * 64), vt: V TRANSPOSED [B][H * 64][ldvt] (zero padded to ldvt >= round_up(T, 8)

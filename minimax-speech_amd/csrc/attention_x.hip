@@ -37,11 +37,11 @@ __device__ __forceinline__ void split4(const float x[4], uint2& hi, uint2& lo) {
 // of P, one wave per SIMD runs its MFMA phase and its softmax / split VALU phase one after the other (~1500 cycles each per
 // key tile); two waves per SIMD overlap one's VALU with the other's MFMAs on the same SIMD for the same LDS footprint.
 template <int MF, bool PRE, int NW>
-__device__ __forceinline__ void attn_flash_x_item(
+__global__ __launch_bounds__(64 * NW) void attn_flash_x_kernel(
     const void* __restrict__ q_, long ldq, long q_bs, const void* __restrict__ k_, long ldk, long k_bs,
     const void* __restrict__ v_, long ldv, long v_bs, float* __restrict__ out, long ldo, long o_bs,
     int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
-    int q_begin, const int32_t* __restrict__ klen, const int item) {
+    int q_begin, const int32_t* __restrict__ klen) {
     typedef std::conditional_t<PRE, bf16_t, float> TI;
     const TI* q = reinterpret_cast<const TI*>(q_);
     const TI* k = reinterpret_cast<const TI*>(k_);
@@ -57,7 +57,7 @@ __device__ __forceinline__ void attn_flash_x_item(
     char* Pl = Ph + NW * QW * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
-    const int xcd = item & 7, slot = item >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pair = (slot / nq) * 8 + xcd;            // XCD-aware: the query tiles of one (batch, head) share an L2
     if (pair >= npairs) return;
     const int qt = slot % nq;
@@ -349,38 +349,14 @@ __device__ __forceinline__ void attn_flash_x_item(
     }
 }
 
-// PERSIST: workgroup w walks the items (query tile of a (batch, head) pair) w, w + gridDim.x, ... of a grid capped by the
-// caller (a multiple of 8: an item keeps its XCD).  This kernel keeps one workgroup of 8 waves and 96 KB of LDS on every CU for
-// 50 - 120 us per launch; beside it the LM decode step of the split build takes 2.6 - 3.4 x as long (tools/contention_lab.py x).
-// A capped grid leaves the other CUs to the decode loop.  (The plain form stays a separate instantiation: wrapping the bf16
-// flash kernel in such a loop cost it 1.5 % even with the full grid.)
-template <int MF, bool PRE, int NW, bool PERSIST>
-__global__ __launch_bounds__(64 * NW) void attn_flash_x_kernel(
-    const void* __restrict__ q_, long ldq, long q_bs, const void* __restrict__ k_, long ldk, long k_bs,
-    const void* __restrict__ v_, long ldv, long v_bs, float* __restrict__ out, long ldo, long o_bs,
-    int Tn, float scale, const float* __restrict__ keymask, long km_bs, int chunk, int nq, int nheads, int npairs,
-    int q_begin, const int32_t* __restrict__ klen, int nitems) {
-    if constexpr (!PERSIST) {
-        attn_flash_x_item<MF, PRE, NW>(q_, ldq, q_bs, k_, ldk, k_bs, v_, ldv, v_bs, out, ldo, o_bs, Tn, scale, keymask, km_bs, chunk, nq, nheads,
-                                       npairs, q_begin, klen, blockIdx.x);
-    } else {
-        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-            if (item != (int)blockIdx.x) __syncthreads();  // every wave is done with the previous item's LDS tiles
-            attn_flash_x_item<MF, PRE, NW>(q_, ldq, q_bs, k_, ldk, k_bs, v_, ldv, v_bs, out, ldo, o_bs, Tn, scale, keymask, km_bs, chunk, nq,
-                                           nheads, npairs, q_begin, klen, item);
-        }
-    }
-}
-
-template <int MF, bool PRE, int NW, bool PERSIST = false>
+template <int MF, bool PRE, int NW>
 int launch_flash_x(dim3 grid, hipStream_t stream, const void* q, long ldq, long q_bs, const void* k, long ldk, long k_bs,
                    const void* v, long ldv, long v_bs, float* out, long ldo, long o_bs, int T_, float scale,
-                   const float* keymask, long km_bs, int chunk, int nq, int H, int npairs, int q_begin, const int32_t* klen,
-                   int nitems = 0) {
+                   const float* keymask, long km_bs, int chunk, int nq, int H, int npairs, int q_begin, const int32_t* klen) {
     const size_t lds = (size_t)8 * 64 * 128 + (size_t)2 * NW * 16 * MF * 128;
-    MMX_LDS_OPT_IN((attn_flash_x_kernel<MF, PRE, NW, PERSIST>), lds);
-    hipLaunchKernelGGL((attn_flash_x_kernel<MF, PRE, NW, PERSIST>), grid, dim3(64 * NW), lds, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_,
-                       scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen, nitems);
+    MMX_LDS_OPT_IN((attn_flash_x_kernel<MF, PRE, NW>), lds);
+    hipLaunchKernelGGL((attn_flash_x_kernel<MF, PRE, NW>), grid, dim3(64 * NW), lds, stream, q, ldq, q_bs, k, ldk, k_bs, v, ldv, v_bs, out, ldo, o_bs, T_,
+                       scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
@@ -407,8 +383,8 @@ extern "C" int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const
 // [hi Q | hi K | lo Q | lo K], vt bf16 [B][2 planes][512][ldvt] (V transposed, zero padded columns), out fp32.
 extern "C" int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, const void* vt, int64_t ldvt, int64_t vt_bs,
                                  float* out, int64_t ldo, int64_t o_bs, int B, int H, int T_, float scale, const float* keymask,
-                                 int64_t km_bs, int chunk, int q_begin, const int32_t* klen, int max_wgs, hipStream_t stream) {
-    MMX_CHECK_ARG(qk && vt && out && B > 0 && H > 0 && H * 64 <= 512 && T_ > 0 && chunk >= 0 && max_wgs >= 0);
+                                 int64_t km_bs, int chunk, int q_begin, const int32_t* klen, hipStream_t stream) {
+    MMX_CHECK_ARG(qk && vt && out && B > 0 && H > 0 && H * 64 <= 512 && T_ > 0 && chunk >= 0);
     MMX_CHECK_ARG(q_begin >= 0 && q_begin < T_ && q_begin % 16 == 0);
     MMX_CHECK_ARG(ldqk >= 2048 && ldqk % 8 == 0 && qk_bs % 8 == 0 && ldvt % 8 == 0 && ldvt >= ((T_ + 7) / 8) * 8 && vt_bs % 8 == 0 && vt_bs >= 2 * 512 * ldvt);
     MMX_CHECK_ARG(ldo % 4 == 0 && o_bs % 4 == 0 && ((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 16) == 0);
@@ -418,8 +394,5 @@ extern "C" int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, co
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
     const bf16_t* q = (const bf16_t*)qk;
     if (small) return launch_flash_x<1, true, 4>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
-    const int cap = max_wgs / 8 * 8;
-    if (cap >= 8 && cap < (int)grid.x)
-        return launch_flash_x<1, true, 8, true>(dim3(cap), stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen, (int)grid.x);
     return launch_flash_x<1, true, 8>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
 }

@@ -154,8 +154,6 @@ class FlowEngine:
         # the workgroups of the bf16 build's polite launches): measured on the config-4 share 465 -> 473 audio-s/s (the decode
         # loop ends 15 ms earlier); off for the bf16 build (64-row tiles: 702 -> 670, the flow groups fall behind)
         self.polite_tpw2 = getattr(FlowEngine, "polite_tpw2_default", None)
-        # polite groups of the split build: workgroup cap of the flash attention (0 = none); see csrc/attention_x.hip, PERSIST
-        self.polite_flash_wgs = getattr(FlowEngine, "polite_flash_wgs_default", 0)
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -713,8 +711,7 @@ class FlowEngine:
                                     keymask=(None if klen is not None else mask), chunk=chunk, fp8=self.attn_fp8, klen=klen)
             elif self.split:
                 ops.attn_flash_xs(qk, vt, ao, B=B, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=vt_bs, o_bs=T * 512,
-                                  scale=0.125, keymask=(None if klen is not None else mask), chunk=chunk, klen=klen,
-                                  max_wgs=(self.polite_flash_wgs if self.polite else 0))
+                                  scale=0.125, keymask=(None if klen is not None else mask), chunk=chunk, klen=klen)
             else:
                 ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
                                q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, keymask=mask,

@@ -260,13 +260,13 @@ def attn_flash_x(q, k, v, out, *, B, H, T, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs,
 
 
 def attn_flash_xs(qk, vt, out, *, B, H, T, ldqk, ldvt, ldo, qk_bs, vt_bs, o_bs, scale, keymask=None, chunk=0, q_begin=0, km_bs=None,
-                  klen=None, max_wgs=0):
+                  klen=None):
     """The split build's flash attention on pre-split operands (include/mmx_hip.h): qk bf16 [B, T, >=2048], vt bf16 [B, 2, 512, ldvt]."""
     if klen is not None:
         assert klen.dtype == torch.int32 and klen.numel() >= B
     check(load().mmx_attn_flash_xs(_p(qk), i64(ldqk), i64(qk_bs), _p(vt), i64(ldvt), i64(vt_bs), _p(out), i64(ldo), i64(o_bs), B, H, T,
                                    C.c_float(scale), _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen),
-                                   int(max_wgs), stream()), "mmx_attn_flash_xs")
+                                   stream()), "mmx_attn_flash_xs")
 
 
 # ----------------------------------------------------------------------------- LM decode

@@ -338,23 +338,3 @@ def test_est_tail_two_tiles_per_workgroup_split_build():
         outs.append((x, qk, vt))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
-
-
-def test_flash_xs_capped_grid_equals_full_grid():
-    """mmx_attn_flash_xs with a capped grid (a workgroup walks several query tiles) == one workgroup per tile, bit for bit."""
-    from mmx import ops
-    g = torch.Generator().manual_seed(21)
-    B, H, T = 4, 8, 700                                 # 32 pairs x 6 tiles of 128 queries = 192 items (>= 192: the 8-wave kernel)
-    Tp = ops.round_up(T, 8)
-    qk = torch.randn(B, T, 2048, generator=g).cuda().bfloat16()
-    vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device="cuda")
-    vt[:, :, :, :T] = torch.randn(B, 2, 512, T, generator=g).cuda().bfloat16()
-    klen = torch.tensor([700, 650, 700, 333], dtype=torch.int32, device="cuda")
-    outs = []
-    for cap in (0, 64, 40):
-        out = torch.full((B, T, 512), 7.0, device="cuda")
-        ops.attn_flash_xs(qk, vt, out, B=B, H=H, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=2 * 512 * Tp, o_bs=T * 512,
-                          scale=0.125, chunk=0, klen=klen, max_wgs=cap)
-        torch.cuda.synchronize()
-        outs.append(out)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

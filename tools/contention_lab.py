@@ -57,14 +57,14 @@ def tail_graph(n, T, bm, **cfg):
     return graph_of(one, 112)
 
 
-def flash_graph(n, T, max_wgs=0):
+def flash_graph(n, T):
     Bf, Tp = 2 * n, ops.round_up(T, 8)
     if SPLIT:
         qk = torch.randn(Bf, T, 2048, device=dev).bfloat16()
         vt = torch.randn(Bf, 2, 512, Tp, device=dev).bfloat16()
         ao = torch.empty(Bf, T, 512, device=dev)
         return graph_of(lambda i=0: ops.attn_flash_xs(qk, vt, ao, B=Bf, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=2 * 512 * Tp,
-                                                      o_bs=T * 512, scale=0.125, max_wgs=max_wgs), 112)
+                                                      o_bs=T * 512, scale=0.125), 112)
     qk = torch.randn(Bf, T, 1024, device=dev).to(fl.tdt)
     vt = torch.randn(Bf, 512, Tp, device=dev).to(fl.tdt)
     ao = torch.empty(Bf, T, 512, device=dev, dtype=fl.tdt)
@@ -111,8 +111,6 @@ if SPLIT:
     measure("beside est_tail 2x1000, 32 rows (128 wg)", tail_graph(2, 1000, 32))
     measure("beside flash_xs 5x1000", flash_graph(5, 1000))
     measure("beside flash_xs 2x1000", flash_graph(2, 1000))
-    for cap in (192, 160, 128):
-        measure(f"beside flash_xs 5x1000, grid capped at {cap}", flash_graph(5, 1000, cap))
     measure("alone again", None)
     sys.exit(0)
 measure("beside est_tail 5x1000, 64 rows x 8 waves (160 wg)", tail_graph(5, 1000, 64))

@@ -16,13 +16,6 @@ if [ "$3" = "w1" ]; then
   run workers1_h30 --flow-workers 1 --hold-steps 30
   exit 0
 fi
-if [ "$3" = "flashx" ]; then
-  run cap0 --flash-cap 0
-  run cap192 --flash-cap 192
-  run cap160 --flash-cap 160
-  run cap128 --flash-cap 128
-  exit 0
-fi
 if [ "$3" = "tpw" ]; then
   run base
   run tpw2 --tpw2 1
