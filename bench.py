@@ -330,6 +330,7 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
+    ap.add_argument("--tpw2-min-tiles", type=int, default=None, help="tuning: two-tile workgroups only for est_tail launches of at least this many row tiles")
     ap.add_argument("--tpw2", type=int, default=None, help="tuning: 1 / 0 = polite flow groups run est_tail with two / one row tiles per workgroup (FlowEngine.polite_tpw2; default: split build only)")
     ap.add_argument("--flow-priority", type=int, default=None, help="tuning: HIP stream priority of the flow workers' streams (TtsEngine.flow_priority)")
     ap.add_argument("--lm-cfg", default="", help="tuning: LlmEngine.v2_cfg overrides (output tiles per workgroup, k slices), e.g. gu=2,1:down=2,4")
@@ -346,6 +347,9 @@ def main():
     a = ap.parse_args()
     global ATTN, GROUP_FAN, FLOW_PRIO
     ATTN, GROUP_FAN, FLOW_PRIO = a.attn, a.group_fan, a.flow_priority
+    if a.tpw2_min_tiles is not None:
+        from mmx.flow import FlowEngine
+        FlowEngine.polite_tpw2_min_tiles_default = a.tpw2_min_tiles
     if a.tpw2 is not None:
         from mmx.flow import FlowEngine
         FlowEngine.polite_tpw2_default = bool(a.tpw2)

@@ -154,6 +154,7 @@ class FlowEngine:
         # the workgroups of the bf16 build's polite launches): measured on the config-4 share 465 -> 473 audio-s/s (the decode
         # loop ends 15 ms earlier); off for the bf16 build (64-row tiles: 702 -> 670, the flow groups fall behind)
         self.polite_tpw2 = getattr(FlowEngine, "polite_tpw2_default", None)
+        self.polite_tpw2_min_tiles = getattr(FlowEngine, "polite_tpw2_min_tiles_default", 0)   # only launches of at least this many tiles
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -726,7 +727,8 @@ class FlowEngine:
                 last = j == len(blocks) - 1
                 ops.est_tail(ao, xs, w, B=B, T=T, dtype=dt, bm=bm_t, rowmask=(mask if last else None),
                              act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])),
-                             tpw2=(self.polite and (self.split if self.polite_tpw2 is None else self.polite_tpw2) and bm_t in (32, 64) and dt in (BF16, X2)))
+                             tpw2=(self.polite and (self.split if self.polite_tpw2 is None else self.polite_tpw2) and bm_t in (32, 64) and dt in (BF16, X2)
+                                   and B * ((T + bm_t - 1) // bm_t) >= self.polite_tpw2_min_tiles))
 
         # down block: its last transformer block drops the masked activation copy into cat[:, :, C:] (the skip)
         stage(self.down, h0, 320, 320, cat[:, :, C:], 2 * C)

@@ -16,6 +16,13 @@ if [ "$3" = "w1" ]; then
   run workers1_h30 --flow-workers 1 --hold-steps 30
   exit 0
 fi
+if [ "$3" = "tpwmin" ]; then
+  run min0
+  run min129 --tpw2-min-tiles 129
+  run min193 --tpw2-min-tiles 193
+  run min257 --tpw2-min-tiles 257
+  exit 0
+fi
 if [ "$3" = "tpw" ]; then
   run base
   run tpw2 --tpw2 1
