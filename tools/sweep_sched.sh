@@ -16,6 +16,16 @@ if [ "$3" = "w1" ]; then
   run workers1_h30 --flow-workers 1 --hold-steps 30
   exit 0
 fi
+if [ "$3" = "groups" ]; then
+  run base
+  run pad15 --pad-ratio 1.5
+  run pad30 --pad-ratio 3.0
+  run ramp248 --flow-group 2,4,8
+  run ramp48 --flow-group 4,8
+  run hold50 --hold-steps 50
+  run hold70 --hold-steps 70
+  exit 0
+fi
 if [ "$3" = "tpwmin" ]; then
   run min0
   run min129 --tpw2-min-tiles 129
