@@ -6,11 +6,20 @@ generator: the same weights can be regenerated anywhere without shipping 600 M p
 so activations stay O(1) through the deep stacks (56 transformer blocks, 37 convs); plain random init gives a
 ~1e-3 waveform and degenerate (uniform) token distributions.
 
-Every matrix-shaped parameter (Linear / Conv / embedding weights) is **bf16-representable**: the checkpoint this path
-serves ships in bf16 (Qwen2.5-0.5B does), so weights are inputs that both sides hold exactly — the CPU oracle computes
-in fp32 on these values, the GPU streams them as bf16 with no rounding.  Weight-normed convs (DAC-VAE) are in the
-state torch's weight_norm leaves a freshly initialised module in: weight_g = ||weight_v|| per output channel, so the
-effective weight g * v / ||v|| is weight_v itself.  Vectors (biases, norm gains, snake alphas) stay fp32.
+Two kinds of checkpoint (`kind` of synth_state_dict):
+
+  * "bf16" (default): every matrix-shaped parameter (Linear / Conv / embedding weights) is **bf16-representable** — a
+    checkpoint that ships in bf16 (Qwen2.5-0.5B does).  Both sides hold the weights exactly: the CPU oracle computes in
+    fp32 on these values, the GPU streams them as bf16 with no rounding.  Weight-normed convs (DAC-VAE) are in the state
+    torch's weight_norm leaves a freshly initialised module in: weight_g = ||weight_v|| per output channel, so the
+    effective weight g * v / ||v|| is weight_v itself.
+  * "fp32": what the reference's own loaders hand over (speech/cosyvoice/cli/model.py:67-75 loads fp32 llm.pt / flow.pt,
+    dac-vae/inference.py:42-46 a generator with trained weight_g / weight_v): the same draws WITHOUT the rounding to bf16,
+    and weight_g = s * ||weight_v|| with a per-channel s in [0.6, 1.5] that is not a power of two (a trained weight norm:
+    dac-vae/model.py:509-514, layers.py:9-14), so the folded conv weight g * v / ||v|| is a general fp32 value and a
+    wrong norm axis (the ConvTranspose1d's weight_g is [Cin, 1, 1]) changes the result.
+
+Vectors (biases, norm gains, snake alphas) stay fp32 in both.
 """
 import math
 import zlib
@@ -40,11 +49,17 @@ def _wn_gain(n: str, shape) -> float:
     return 1.0
 
 
-def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
+def synth_tensor(name: str, shape: Tuple[int, ...], seed: int, kind: str = "bf16") -> torch.Tensor:
     t = _synth_tensor(name, shape, seed)
-    if len(shape) >= 2 and not name.endswith(".alpha") and not name.endswith(".weight_g"):
+    if kind == "bf16" and len(shape) >= 2 and not name.endswith(".alpha") and not name.endswith(".weight_g"):
         t = _bf16_exact(t)
     return t
+
+
+def wn_scale(name: str, n: int, seed: int) -> torch.Tensor:
+    """Per-channel ratio weight_g / ||weight_v|| of the "fp32" kind: uniform in [0.6, 1.5], never a power of two."""
+    s = 0.6 + 0.9 * torch.rand(n, generator=_gen(seed, name + "#g"))
+    return torch.where((s - 1.0).abs() < 1e-3, s + 0.01, s)
 
 
 def _synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
@@ -98,11 +113,15 @@ def _synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
     return _randn(shape, g, 0.05)
 
 
-def synth_state_dict(manifest: Dict[str, Tuple[int, ...]], seed: int = 0) -> Dict[str, torch.Tensor]:
-    sd = {k: synth_tensor(k, tuple(v), seed) for k, v in manifest.items() if not k.endswith(".weight_g")}
+def synth_state_dict(manifest: Dict[str, Tuple[int, ...]], seed: int = 0, kind: str = "bf16") -> Dict[str, torch.Tensor]:
+    assert kind in ("bf16", "fp32")
+    sd = {k: synth_tensor(k, tuple(v), seed, kind) for k, v in manifest.items() if not k.endswith(".weight_g")}
     for k, shp in manifest.items():
         if k.endswith(".weight_g"):
             # torch.nn.utils.weight_norm at init: g = ||v|| over every dim but 0 (the same call the module's forward makes)
             v = sd[k[:-1] + "v"]
-            sd[k] = torch.norm_except_dim(v, 2, 0).reshape(tuple(shp)).clone()
+            g = torch.norm_except_dim(v, 2, 0).reshape(tuple(shp)).clone()
+            if kind == "fp32":
+                g = g * wn_scale(k, g.numel(), seed).reshape(g.shape)
+            sd[k] = g
     return {k: sd[k] for k in manifest}

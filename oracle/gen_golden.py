@@ -5,7 +5,7 @@ Generates the golden vectors under tests/golden/ by importing the reference's ow
 oracle/weights.py into them, and recording inputs + outputs.  Only data is written: no reference source
 or bytecode enters the repo (sys.dont_write_bytecode is set by ref_shims).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [dac] [dacenc] [flow] [llm] [sampler] [spk]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [dac] [dacfp32] [dacenc] [flow] [blocks] [llm] [bistream] [sampler] [spk] [stream]
 """
 import json
 import math
@@ -33,16 +33,24 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
-def gen_dac():
+def gen_dac(kind="bf16"):
+    """kind "fp32": the checkpoint kind of mmx/synth.py with trained-like weight norms (weight_g = s * ||weight_v||, per-channel
+    s that is no power of two; folded weights are general fp32 values) -> dac80_fp32.npz.  SURVEY 8c(i): "default init and a
+    scaled variant"."""
     m = R.import_dac()
-    for lat in (80, 128):
+    for lat in ((80, 128) if kind == "bf16" else (80,)):
         torch.manual_seed(0)
         d = m.DACVAE(encoder_dim=64, encoder_rates=[2, 3, 4, 4, 5], latent_dim=lat, decoder_dim=1536,
                      decoder_rates=[5, 4, 4, 3, 2], sample_rate=24000, d_in=1, d_out=1, weight_init="xavier",
                      activation="snake", gain=1.0).eval()
         sd = {k: v for k, v in d.state_dict().items() if k.startswith("decoder.") or k.startswith("de_conv_pre.")}
-        W.save_manifest(sd, os.path.join(GOLD, f"manifest_dac{lat}.json"))
-        syn = W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED)
+        if kind == "bf16":
+            W.save_manifest(sd, os.path.join(GOLD, f"manifest_dac{lat}.json"))
+        syn = W.synth_state_dict({k: v.shape for k, v in sd.items()}, SEED, kind=kind)
+        if kind == "fp32":                                  # the fixture is about g != ||v||: make sure it is so
+            k0 = "decoder.model.1.block.1."                 # the first ConvTranspose1d: weight_g is [Cin, 1, 1]
+            r = syn[k0 + "weight_g"].flatten() / torch.norm_except_dim(syn[k0 + "weight_v"], 2, 0).flatten()
+            assert syn[k0 + "weight_g"].shape[0] == syn[k0 + "weight_v"].shape[0] and 0.59 < r.min() < 0.7 and 1.4 < r.max() < 1.51
         missing, unexpected = d.load_state_dict(syn, strict=False)
         assert not unexpected
         out = {}
@@ -62,7 +70,7 @@ def gen_dac():
                 print(f"   stage{i}: {tuple(h.shape)} std {h.std():.3f}")
             if i < 3:
                 out[f"stage{i}_T8"] = np_(h)
-        np.savez_compressed(os.path.join(GOLD, f"dac{lat}.npz"), **out)
+        np.savez_compressed(os.path.join(GOLD, f"dac{lat}.npz" if kind == "bf16" else f"dac{lat}_fp32.npz"), **out)
 
 
 def gen_dac_enc():
@@ -403,6 +411,52 @@ def build_flow_spk():
                                     decoder=base.decoder).eval()
 
 
+def gen_stream():
+    """The hop schedule of the reference's own CosyVoice2Model.tts(stream=True) loop (cli/model.py:336-378), driven with stub
+    llm / flow / hift objects: the llm stub yields N ids at once, the flow stub records (tokens seen, finalize, streaming) and
+    returns zeros of the length flow.inference would (the prompt's frames dropped), the hift stub returns silence of the right
+    length; token_offset is recovered from the length of the mel the hift stub is handed (:296 slices it off, :298-301 puts
+    mel_cache_len cached frames in front).  Pins oracle/stream.py::hop_schedule to the reference."""
+    R.import_cosyvoice()
+    from cosyvoice.cli.model import CosyVoice2Model
+    out = {}
+    cases = [(118, 0), (130, 30), (20, 0), (28, 0), (1499, 75), (53, 25), (103, 7)]
+    for N, Lp in cases:
+        calls = []
+
+        class Llm:
+            def inference(self, **kw):
+                for i in range(N):
+                    yield i % 6561
+
+        class Flow:
+            pre_lookahead_len, token_mel_ratio, input_frame_rate = 3, 2, 25
+
+            def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding,
+                          streaming, finalize):
+                calls.append([int(token.shape[1]), -1, int(bool(finalize)), int(bool(streaming))])
+                return torch.zeros(1, 80, 2 * int(token.shape[1])), None
+
+        class Hift:
+            def inference(self, speech_feat, cache_source):
+                rec = calls[-1]
+                cached = 0 if cache_source.shape[2] == 0 else 8           # mel_cache_len frames of the previous pass in front
+                rec[1] = rec[0] - (int(speech_feat.shape[2]) - cached) // 2
+                n = int(speech_feat.shape[2]) * 480
+                return torch.zeros(1, n), torch.zeros(1, 1, n)
+
+        model = CosyVoice2Model(Llm(), Flow(), Hift())
+        model.device = torch.device("cpu")
+        chunks = list(model.tts(text=torch.zeros(1, 4, dtype=torch.int32), flow_embedding=torch.zeros(1, 192),
+                                llm_embedding=torch.zeros(1, 192), flow_prompt_speech_token=torch.zeros(1, Lp, dtype=torch.int32),
+                                prompt_speech_feat=torch.zeros(1, 2 * Lp, 80), stream=True))
+        assert len(chunks) == len(calls)
+        out[f"calls_{N}_{Lp}"] = np.array(calls, dtype=np.int64)
+        print(f"stream N={N} Lp={Lp}: {len(calls)} flow calls; first {calls[0]}, last {calls[-1]}")
+    out["cases"] = np.array(cases, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "stream.npz"), **out)
+
+
 def gen_sampler():
     R.import_cosyvoice()
     from cosyvoice.utils.common import ras_sampling, nucleus_sampling, random_sampling
@@ -421,8 +475,8 @@ def gen_sampler():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["dac", "dacenc", "flow", "blocks", "llm", "bistream", "sampler", "spk"]
+    which = sys.argv[1:] or ["dac", "dacfp32", "dacenc", "flow", "blocks", "llm", "bistream", "sampler", "spk", "stream"]
     for w in which:
         t0 = time.time()
-        {"dac": gen_dac, "dacenc": gen_dac_enc, "flow": gen_flow, "blocks": gen_blocks, "llm": gen_llm, "bistream": gen_bistream, "sampler": gen_sampler, "spk": gen_spk}[w]()
+        {"dac": gen_dac, "dacfp32": lambda: gen_dac("fp32"), "stream": gen_stream, "dacenc": gen_dac_enc, "flow": gen_flow, "blocks": gen_blocks, "llm": gen_llm, "bistream": gen_bistream, "sampler": gen_sampler, "spk": gen_spk}[w]()
         print(f"[{w}] done in {time.time() - t0:.1f}s")

@@ -338,3 +338,160 @@ def test_est_tail_two_tiles_per_workgroup_split_build():
         outs.append((x, qk, vt))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ full-size configs 4 and 5
+def test_config4_rank_share_full_size_split_vs_oracle(case):
+    """BASELINE config 4, one rank's share at FULL size on the split build — the shape `bench.py` times: 32 utterances, lengths
+    U{50..500} tokens (seed 3), 24-layer LM, the overlapped schedule (decode loop with two 16-row MFMA tiles and the ticketed
+    split-K down projection, compaction into the 16-slot engine, ragged zero-padded flow groups with the batched encoder,
+    two-tile est_tail workgroups beside the decode loop).  The two shortest and the longest utterance against the CPU oracle's
+    composed path: ids identical, waveform within 1e-3 (the north star; sequence id = position in the batch keys the Philox
+    stream on both sides).  The back-to-back schedule must give the same ids for all 32."""
+    from mmx.pipeline import TtsEngine
+    from oracle import dac as ODAC, flow as OFLOW, llm as OLLM
+    lens = torch.randint(50, 501, (32,), generator=torch.Generator().manual_seed(3)).tolist()
+    g = torch.Generator().manual_seed(2)
+    texts = [torch.randint(0, 151936, (1, 48), generator=g) for _ in range(32)]
+    emb = case["emb"].cuda()
+    tc = [t.cuda() for t in texts]
+    eng = TtsEngine(case["llm_sd"], case["flow_sd"], case["dac_sd"], dtype=X2, max_batch=32, max_ctx=640)
+    for rep in range(2):                                   # eager pass, then the recorded graphs
+        wavs = eng.tts_batch(tc, [emb] * 32, seed=0, exact_steps=lens, overlap=True)
+        torch.cuda.synchronize()
+        ids = [t.tolist() for t in eng.last_tokens]
+        if rep == 0:
+            first = ([w.clone() for w in wavs], ids)
+    assert ids == first[1]
+    for b in range(32):                                    # other flow groups / graphs: rounding of the fp32 activations only
+        assert wavs[b].shape == first[0][b].shape == (1, 1, 2 * len(ids[b]) * 480)
+        assert (wavs[b] - first[0][b]).abs().max().item() < 2e-4, b
+    eng.tts_batch(tc, [emb] * 32, seed=0, exact_steps=lens, overlap=False)
+    assert [t.tolist() for t in eng.last_tokens] == ids
+    z = torch.zeros(1, 0, dtype=torch.long)
+    order = sorted(range(32), key=lambda i: lens[i])
+    for b in order[:2] + order[-1:]:
+        with torch.no_grad():
+            toks = OLLM.lm_inference(case["llm_sd"], OLLM.QwenCfg(), texts[b], z, z, seed=0, seq=b, max_steps=lens[b], ignore_eos_always=True)
+            lat = OFLOW.flow_inference(case["flow_sd"], torch.tensor(toks).reshape(1, -1), z, torch.zeros(1, 0, 80), case["emb"])
+            wav = ODAC.decode(case["dac_sd"], lat, [5, 4, 4, 3, 2])
+        assert ids[b] == toks, (b, next(i for i, (x, y) in enumerate(zip(ids[b], toks)) if x != y))
+        err = (wavs[b].cpu() - wav).abs().max().item()
+        print(f"config-4 share on the split build, utterance {b} ({lens[b]} steps): {len(toks)} ids identical, waveform max abs err {err:.3e}")
+        assert wavs[b].shape == wav.shape and err <= 1e-3, (b, err)
+
+
+def test_config5_long_form_streaming_full_size_split_vs_oracle(case):
+    """BASELINE config 5 at FULL size on the split build: ONE 60 s utterance (290 text ids, 1500 decode steps, 24-layer LM,
+    captured decode graph), streamed in 25-token hops with the estimator state cache, against the oracle:
+      (a) all ~1500 token ids identical to oracle.llm's;
+      (b) the first four chunks within 1e-3 of oracle/stream.py's first four hops (a hop sees only the tokens before it, so the
+          prefix of the oracle's schedule is the schedule of the prefix);
+      (c) the closing chunk within 1e-3 of the oracle's closing chunk.  The oracle side of (c) is two flow passes instead of
+          sixty: the LAST streaming pass and the closing pass — streaming passes agree on finished frames (the flow is chunk
+          causal; tests/test_oracle_golden.py, test_stream_cached_state_equals_recompute), so the last streaming pass alone
+          holds every latent frame the earlier ones rendered."""
+    from mmx.pipeline import TtsEngine
+    from oracle import flow as OFLOW, llm as OLLM, stream as OS
+    N = 1500
+    text = torch.randint(0, 151936, (1, 290), generator=torch.Generator().manual_seed(6))
+    emb = case["emb"]
+    eng = TtsEngine(case["llm_sd"], case["flow_sd"], case["dac_sd"], dtype=X2, max_batch=1, max_ctx=2048)
+    chunks = [c.reshape(-1).cpu() for c in eng.tts_stream(text.cuda(), emb.cuda(), seed=1, exact_steps=N, cache=True)]
+    n_out = int(eng.llm.state[2, 0])
+    got = eng.llm.out_tokens[0, :n_out].tolist()
+    CL, CR = eng.dac.ctx_left, eng.dac.ctx_right
+    del eng
+    torch.cuda.empty_cache()
+    z, zf = torch.zeros(1, 0, dtype=torch.long), torch.zeros(1, 0, 80)
+    with torch.no_grad():
+        toks = OLLM.lm_inference(case["llm_sd"], OLLM.QwenCfg(), text, z, z, seed=1, seq=0, max_steps=N, ignore_eos_always=True)
+    assert got == toks, ("token ids differ from the oracle", next(i for i, (a, b) in enumerate(zip(got, toks)) if a != b))
+    tk = torch.tensor(toks).reshape(1, -1)
+    sched = OS.hop_schedule(len(toks), 0)
+    assert len(chunks) == len(sched) and sum(c.shape[0] for c in chunks) == len(toks) * 960
+    with torch.no_grad():
+        head = [(off * 2, OFLOW.flow_inference(case["flow_sd"], tk[:, :vis], z, zf, emb, streaming=True, finalize=False)[0].t().contiguous(), False)
+                for vis, off, _ in sched[:4]]
+        want = OS.render_passes(case["dac_sd"], [5, 4, 4, 3, 2], head, CL, CR)
+        errs = [(g - w).abs().max().item() for g, w in zip(chunks[:4], want)]
+        assert [g.shape for g in chunks[:4]] == [w.shape for w in want]
+        print(f"config 5 on the split build ({len(toks)} ids identical, {len(chunks)} chunks): first four chunks vs the oracle's hops {[f'{e:.2e}' for e in errs]}")
+        assert max(errs) <= 1e-3, errs
+        vis, off, _ = sched[-2]
+        last = OFLOW.flow_inference(case["flow_sd"], tk[:, :vis], z, zf, emb, streaming=True, finalize=False)[0].t().contiguous()
+        fin = OFLOW.flow_inference(case["flow_sd"], tk, z, zf, emb, streaming=False, finalize=True)[0].t().contiguous()
+        tail = OS.render_passes(case["dac_sd"], [5, 4, 4, 3, 2], [(off * 2, last, False), (sched[-1][1] * 2, fin, True)], CL, CR)[-1]
+    err = (chunks[-1] - tail).abs().max().item()
+    print(f"config 5 on the split build: closing chunk ({tail.shape[0]} samples, cross-faded seam included) vs the oracle {err:.3e}")
+    assert chunks[-1].shape == tail.shape and err <= 1e-3, err
+
+
+# ------------------------------------------------------------------------------------------------ fp32 checkpoints
+def test_dac_trained_weight_norm_vs_reference_golden(golden_dir):
+    """weight_g != ||weight_v|| (tests/golden/dac80_fp32.npz: the reference's Decoder on the "fp32" checkpoint kind of
+    mmx/synth.py, per-channel weight_g / ||weight_v|| in [0.6, 1.5], ConvTranspose1d gains per dim-0 slice).  fp32 build: the
+    fold (ops.fold_weight_norm) must reproduce the reference within 1e-4.  The split and bf16 builds ROUND the folded weights
+    to bf16 at load (2^-9 relative per weight): their distance is reported and held to the bf16-weight bound below."""
+    from mmx.dac import DacDecoderEngine
+    from oracle import weights as W
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_dac80.json")), SEED, kind="fp32")
+    g = np.load(os.path.join(golden_dir, "dac80_fp32.npz"))
+    for dt, tol in ((0, 1e-4), (X2, 3e-2), (1, 6e-2)):
+        eng = DacDecoderEngine(sd, [5, 4, 4, 3, 2], dtype=dt)
+        for T in (8, 50):
+            wav = eng.decode(torch.from_numpy(g[f"z_T{T}"]).cuda()).cpu()
+            ref = torch.from_numpy(g[f"wav_T{T}"])
+            err = (wav - ref).abs().max().item()
+            print(f"DAC on a trained-like weight norm, dtype {dt}, T={T}: max abs err {err:.3e}")
+            assert wav.shape == ref.shape and err < tol, (dt, T, err)
+
+
+@pytest.fixture(scope="module")
+def case_fp32():
+    """Config-3 inputs on the "fp32" checkpoint kind (general fp32 weights, trained-like weight norms: what the reference's
+    loaders hand over, cli/model.py:67-75, dac-vae/inference.py:42-46) and the oracle's composed outputs on them."""
+    import test_gpu_pipeline as TP
+    from mmx import shapes, synth
+    from oracle import dac as ODAC, flow as OFLOW, llm as OLLM
+    llm_sd = synth.synth_state_dict(shapes.llm_manifest(), 0, kind="fp32")
+    flow_sd = synth.synth_state_dict(shapes.flow_manifest(), 0, kind="fp32")
+    dac_sd = synth.synth_state_dict(shapes.dac_decoder_manifest(80), 0, kind="fp32")
+    text = torch.randint(0, 151936, (1, TP.N_TEXT), generator=torch.Generator().manual_seed(2))
+    emb = torch.randn(1, 192, generator=torch.Generator().manual_seed(1))
+    z = torch.zeros(1, 0, dtype=torch.long)
+    with torch.no_grad():
+        toks = OLLM.lm_inference(llm_sd, OLLM.QwenCfg(), text, z, z, seed=TP.SEED, seq=0, max_steps=TP.N_STEPS, ignore_eos_always=True)
+        lat = OFLOW.flow_inference(flow_sd, torch.tensor(toks).reshape(1, -1), z, torch.zeros(1, 0, 80), emb)
+        wav = ODAC.decode(dac_sd, lat, [5, 4, 4, 3, 2])
+    return dict(llm_sd=llm_sd, flow_sd=flow_sd, dac_sd=dac_sd, text=text, emb=emb, toks=toks, lat=lat, wav=wav)
+
+
+def test_split_build_on_an_fp32_checkpoint_measured(case_fp32):
+    """What the split build WITHOUT weight planes does on a checkpoint whose weights are not bf16-representable (it rounds
+    them to bf16 at load): measured against the oracle on the unrounded weights and printed for DESIGN.md — free-running id
+    agreement, teacher-forced draw agreement, and the waveform error of flow + DAC on the oracle's ids.  The requirement here
+    is only the bf16-WEIGHT bound (8 significant bits of every weight, 16 / 24 of every activation): teacher-forced agreement
+    >= 60 % and SNR >= 25 dB, the bf16 build's own bounds; the north star on such checkpoints is the job of the weight-plane
+    mode (test_weight_planes_*)."""
+    import test_gpu_pipeline as TP
+    case = case_fp32
+    eng = TP._engine(case, X2)
+    eng.tts(case["text"].cuda(), case["emb"].cuda(), seed=TP.SEED, exact_steps=TP.N_STEPS)
+    got, want = eng.llm.tokens()[0], case["toks"]
+    n = min(len(got), len(want))
+    first = next((i for i in range(n) if got[i] != want[i]), n)
+    mism = sum(1 for i in range(n) if got[i] != want[i]) + abs(len(got) - len(want))
+    z0 = torch.zeros(1, 0, dtype=torch.long, device="cuda")
+    x = eng.llm.build_lm_input(case["text"].cuda(), z0, z0)
+    eng.llm.start([x], [TP.N_STEPS], [TP.N_STEPS], seed=TP.SEED, forced=torch.tensor(want).reshape(1, -1))
+    eng.llm.run(TP.N_STEPS)
+    drawn = eng.llm.sampled[0, :len(want)].tolist()
+    agree = sum(1 for a, b in zip(drawn, want) if a == b) / len(want)
+    tok = torch.tensor(want, device="cuda").reshape(1, -1)
+    wav = eng.token2wav(tok, z0, torch.zeros(1, 0, 80, device="cuda"), case["emb"].cuda()).cpu()
+    err, snr = (wav - case["wav"]).abs().max().item(), TP._snr_db(case["wav"], wav)
+    print(f"split build, weights ROUNDED to bf16 at load, vs the oracle on the fp32 checkpoint: free running {mism}/{n} ids differ "
+          f"(first divergence at step {first}); teacher forced {agree * 100:.1f} % of the draws equal; same-ids waveform max abs err "
+          f"{err:.3e}, SNR {snr:.1f} dB")
+    assert agree >= TP.BF16_MIN_TF_AGREEMENT and snr >= TP.BF16_MIN_SNR_DB, (agree, snr)

@@ -38,6 +38,40 @@ def test_dac_decode_matches_reference(golden_dir, lat):
         assert torch.allclose(st[i], torch.from_numpy(g[f"stage{i}_T8"]), atol=2e-5), i
 
 
+def test_dac_decode_trained_weight_norm_matches_reference(golden_dir):
+    """The "fp32" checkpoint kind (mmx/synth.py): weight_g = s * ||weight_v|| with per-channel s in [0.6, 1.5], folded weights
+    that are general fp32 values — the reference's Decoder on it (dac80_fp32.npz).  A fold that ignored weight_g, or took the
+    ConvTranspose1d's norm over the wrong axis (its weight_g is [Cin, 1, 1], dac-vae/layers.py:13-14), fails here: both are
+    tried below and must miss the golden by far more than the tolerance."""
+    g = _load(golden_dir, "dac80_fp32.npz")
+    man = W.load_manifest(os.path.join(golden_dir, "manifest_dac80.json"))
+    sd = W.synth_state_dict(man, SEED, kind="fp32")
+    k0 = "decoder.model.1.block.1."
+    ratio = sd[k0 + "weight_g"].flatten() / torch.norm_except_dim(sd[k0 + "weight_v"], 2, 0).flatten()
+    assert sd[k0 + "weight_g"].shape == (sd[k0 + "weight_v"].shape[0], 1, 1) and ratio.min() < 0.7 and ratio.max() > 1.4
+    for T in (8, 50):
+        y = ODAC.decode(sd, torch.from_numpy(g[f"z_T{T}"]), RATES)
+        ref = torch.from_numpy(g[f"wav_T{T}"])
+        assert y.shape == ref.shape and (y - ref).abs().max() < 2e-5, float((y - ref).abs().max())
+    x = ODAC.wnconv1d_act(sd, "de_conv_pre", torch.from_numpy(g["z_T8"]))
+    _, st = ODAC.decoder_forward(sd, x, RATES, return_stages=True)
+    for i in range(3):
+        assert torch.allclose(st[i], torch.from_numpy(g[f"stage{i}_T8"]), atol=2e-5), i
+    ref = torch.from_numpy(g["wav_T8"])
+    # (a) weight_g ignored
+    bad = dict(sd)
+    for k in man:
+        if k.endswith(".weight_g"):
+            bad[k] = torch.norm_except_dim(sd[k[:-1] + "v"], 2, 0).reshape(sd[k].shape)
+    assert (ODAC.decode(bad, torch.from_numpy(g["z_T8"]), RATES) - ref).abs().max() > 1e-2
+    # (b) the ConvTranspose1d's gain applied per OUTPUT channel (axis 1) instead of per dim-0 slice
+    bad = dict(sd)
+    v, gg = sd[k0 + "weight_v"], sd[k0 + "weight_g"]
+    wrong = v * (gg.flatten()[:v.shape[1]].reshape(1, -1, 1) / v.norm(dim=(0, 2), keepdim=True))
+    bad[k0 + "weight_v"], bad[k0 + "weight_g"] = wrong, torch.norm_except_dim(wrong, 2, 0)
+    assert (ODAC.decode(bad, torch.from_numpy(g["z_T8"]), RATES) - ref).abs().max() > 1e-2
+
+
 def test_dac_encode_matches_reference(golden_dir):
     """DACVAE.encode / forward (dac-vae/model.py:469-506) on the reference's own outputs."""
     g = _load(golden_dir, "dacenc.npz")
@@ -242,6 +276,21 @@ def test_stream_schedule_restates_reference_hops():
     assert OS.hop_schedule(20, 0) == [(20, 0, True)]
     # exactly hop + look-ahead tokens: one hop, then the closing pass over the same tokens
     assert OS.hop_schedule(28, 0) == [(28, 0, False), (28, 25, True)]
+
+
+def test_stream_schedule_matches_reference_loop(golden_dir):
+    """hop_schedule against the calls the REFERENCE's own CosyVoice2Model.tts(stream=True) loop made when driven with stub
+    llm / flow / hift objects (oracle/gen_golden.py::gen_stream, tests/golden/stream.npz): per flow call (tokens seen,
+    token_offset as recovered from the mel handed to the vocoder, finalize, streaming flag); the closing pass runs with
+    streaming=False (cli/model.py:371-378 leaves `stream` at its default)."""
+    from oracle import stream as OS
+    g = _load(golden_dir, "stream.npz")
+    assert len(g["cases"]) >= 5
+    for N, Lp in g["cases"].tolist():
+        ref = g[f"calls_{N}_{Lp}"].tolist()
+        got = OS.hop_schedule(N, Lp)
+        assert [(v, o, bool(f)) for v, o, f, _ in ref] == got, (N, Lp)
+        assert all(st == (not f) for _, _, f, st in ref), (N, Lp)        # streaming flag of every call: not finalize
 
 
 def test_stream_rendering_rule_is_exact_when_passes_agree(golden_dir):
