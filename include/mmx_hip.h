@@ -264,8 +264,6 @@ int mmx_skinny_gemm(const void* x, int x_dtype, int64_t ldx, int B, int K, int N
  *   `part` (>= ksplit * ceil(N/16) * ceil(B/16)*4 * 64 floats) and are summed in slice order by the workgroup that
  *   takes the last ticket of its tile (`tickets`: ceil(N/16) int32, zero before the first launch; left zero).  Launches
  *   that share part / tickets must be ordered on one stream.
- *   debug_stamps: NULL in the product path; a measurement hook otherwise (uint64 [workgroups][8 waves][8]: shader-clock
- *   stamps of the kernel's phases, tools/decode_lab.py).
  *   Replace the q/k/v, o, gate/up (+SiLU*up), down projections and the llm_decoder head of one decode step
  *   (speech/cosyvoice/llm/llm.py:359-371,749; HF Qwen2 MLP / attention projections / RMSNorm). */
 int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const float* gamma, float* h, int64_t ldh, void* xs,
@@ -273,7 +271,7 @@ int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const float* gamm
 int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, const float* bias, const float* ssq_in, float eps,
                 int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
                 int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,
-                void* debug_stamps, hipStream_t stream);
+                hipStream_t stream);
 
 /* RoPE (HF rotate_half; inv_freq[D/2] fp32 = 1/theta^(2i/D) as HF computes it) on q/k of
  * qkv[b][t][: (Hq+2Hkv)*D] at position pos[b] + t, K/V appended to the paged cache, q written as T.  Cache layout:
@@ -421,10 +419,6 @@ typedef struct {
     float slope;
 } MmxDacRuParams;
 int mmx_dac_ru(const MmxDacRuParams* p, int dtype, int bm, hipStream_t stream);
-
-/* Measurement hook (not part of the product path): buf != NULL makes every later mmx_est_tail launch of this process write
- * shader-clock stamps uint64 [workgroup][wave][64] at its stage boundaries (tools/tail_lab.py); NULL switches it off. */
-int mmx_debug_tail_stamps(void* buf);
 
 #ifdef __cplusplus
 }

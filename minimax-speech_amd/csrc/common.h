@@ -3,6 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// MMX_LAB = 1 (csrc/Makefile, target lab): the measurement build libmmx_hip_lab.so of the SAME sources - shader-clock stamps at
+// the phase boundaries of the decode projections and of the fused estimator tail, switched on through the two mmx_lab_* entry
+// points of include/mmx_hip_lab.h.  The product library is built with MMX_LAB = 0: no stamp is compiled in, no kernel reads
+// a mutable global, no entry point carries a measurement argument.
+#ifndef MMX_LAB
+#define MMX_LAB 0
+#endif
+constexpr bool LAB = MMX_LAB != 0;
+
 #define MMX_OK 0
 #define MMX_EARG (-1)
 #define MMX_CHECK_ARG(c) do { if (!(c)) return MMX_EARG; } while (0)

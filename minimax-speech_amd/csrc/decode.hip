@@ -65,15 +65,18 @@ struct Skinny3Args {
     long ldo;
     int B, K, N, ntiles, kb_per_wg;
     float eps;
-    unsigned long long* stamps;   // measurement hook (NULL in the product path): [workgroup][wave][8] shader-clock stamps
 };
 
-#define STAMP(i) do { if (a.stamps && lane == 0) a.stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// lab build only (common.h, MMX_LAB): [workgroup][wave][8] shader-clock stamps of the kernel's phases, set by mmx_lab_skinny_stamps
+__device__ unsigned long long* g_skinny_stamps = nullptr;
+#define STAMP(i) do { if constexpr (LAB) { if (stamps && lane == 0) stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
 // MT: 16-row tiles of the batch; TW: output tiles (EPI 1: gate/up tile pairs) per workgroup; KPW: k-blocks per wave (bound)
 template <int MT, int TW, int KPW, int EPI, int NS>
 __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();      // (used by the measurement hook only)
+    unsigned long long* stamps = nullptr;
+    unsigned long long t_entry = 0;
+    if constexpr (LAB) { t_entry = __builtin_amdgcn_s_memtime(); stamps = g_skinny_stamps; }
     constexpr int NB = EPI == 1 ? 2 : 1;
     constexpr int PER = TW * NB * MT * 4;              // floats per lane a wave hands to the reduction
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     const int ntiles = a.ntiles;
 
     STAMP(0);
-    if (a.stamps && lane == 0) a.stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + 7] = t_entry;
+    if constexpr (LAB) { if (stamps && lane == 0) stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + 7] = t_entry; }
     // every load is a buffer load with a per-lane offset of lane*16 and a scalar offset; an index outside the work of this
     // wave gets the offset OOB (returns zeros: a zero fragment adds nothing) - no branch around any load
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wp), 0, 0x7fffffff, 0x00020000);
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
         pre_res[k] = (EPI == 2 && ok) ? a.out[(long)row * a.ldo + ncol] : 0.f;
     }
     STAMP(1);                                          // loads issued
-    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); }   // (measurement only) loads landed
+    if constexpr (LAB) { if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); } }   // (lab build only) loads landed
     float4_t acc[TW][NB][MT];
 #pragma unroll
     for (int t = 0; t < TW; ++t)
@@ -313,7 +316,7 @@ extern "C" int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const 
 extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, const float* bias, const float* ssq_in, float eps,
                            int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
                            int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,
-                           void* debug_stamps, hipStream_t stream) {
+                           hipStream_t stream) {
     MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 && (dtype == MMX_X3 || dtype == MMX_BF16));
     MMX_CHECK_ARG(((uintptr_t)xs % 16) == 0 && ((uintptr_t)wp % 16) == 0 && (!ssq_in || ((uintptr_t)ssq_in % 16) == 0));
     MMX_CHECK_ARG(ksplit >= 1 && ksplit <= 8 && (ksplit == 1 || (epi == 2 && part && tickets)));
@@ -326,7 +329,7 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
     // 32-bit buffer offsets: the packed weights and the planes must stay below 2 GiB
     MMX_CHECK_ARG((double)ntiles * (epi == 1 ? 2 : 1) * nkb * 1024.0 < 2147483000.0);
     Skinny3Args a{(const bf16_t*)xs, (const bf16_t*)wp, bias, ssq_in, out, (bf16_t*)xs_out, gamma_next, ssq_out, part, tickets,
-                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps, (unsigned long long*)debug_stamps};
+                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps};
 #define GO(MT, TW, KPW, EPI) do { if (dtype == MMX_X3) return launch<MT, TW, KPW, EPI, 3>(a, ksplit, stream); return launch<MT, TW, KPW, EPI, 1>(a, ksplit, stream); } while (0)
 #define BY_MT(TW, KPW, EPI) do { if (mt == 1) GO(1, TW, KPW, EPI); else GO(2, TW, KPW, EPI); } while (0)
     if (per_wave <= 4) {
@@ -338,3 +341,12 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
 #undef GO
     return MMX_EARG;
 }
+
+#if MMX_LAB
+// lab build only (include/mmx_hip_lab.h): buf uint64 [workgroups][8 waves][8] or NULL (off); set between launches, on the current device
+extern "C" int mmx_lab_skinny_stamps(void* buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_skinny_stamps), &p, sizeof(p));
+    return e == hipSuccess ? MMX_OK : -(int)e - 1000;
+}
+#endif

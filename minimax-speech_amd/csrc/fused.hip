@@ -40,10 +40,10 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-// measurement hook (NULL in the product path, set by mmx_debug_tail_stamps): est_tail_kernel writes shader-clock stamps
-// [workgroup][wave][64] at its stage boundaries (tools/tail_lab.py --stamps)
+// lab build only (common.h, MMX_LAB; set by mmx_lab_tail_stamps): est_tail_kernel writes shader-clock stamps
+// [workgroup][wave][64] at its stage boundaries (tools/tail_lab.py --stamps).  The product build compiles no stamp.
 __device__ unsigned long long* g_tail_stamps = nullptr;
-#define TSTAMP(i) do { if (st && lane == 0) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMP(i) do { if constexpr (LAB) { if (st && lane == 0) st[(i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
 template <typename T> struct FT;
 template <> struct FT<bf16_t> { static constexpr int E = 8, KB = 32; typedef short8_t frag_t; };
@@ -517,8 +517,11 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     float* patch = patch_all + wave * PATCH_FLOATS;
     const int b = blockIdx.y, t0 = p.t_begin + tile * BM, Tn = p.T;
     const int col0 = wave * WC + (lane & 3) * CW;      // this lane's CW columns of a 256-wide row
-    unsigned long long* st = g_tail_stamps;
-    if (st) st += ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 64;
+    unsigned long long* st = nullptr;
+    if constexpr (LAB) {
+        st = g_tail_stamps;
+        if (st) st += ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 64;
+    }
     TSTAMP(0);
 
     const T* wo = reinterpret_cast<const T*>(p.wo) + (long)lane * E;
@@ -1076,11 +1079,14 @@ int check_next(const MmxEstNext& nx, int dtype, int T_) {
 
 }  // namespace
 
-extern "C" int mmx_debug_tail_stamps(void* buf) {
+#if MMX_LAB
+// lab build only (include/mmx_hip_lab.h): buf uint64 [workgroups][waves][64] or NULL (off); set between launches, on the current device
+extern "C" int mmx_lab_tail_stamps(void* buf) {
     unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
     const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamps), &p, sizeof(p));
     return e == hipSuccess ? MMX_OK : -(int)e - 1000;
 }
+#endif
 
 // cfg = pf + 16 * waves: pf = k-steps of weight fragments a wave keeps in flight (2 / 4 / 8, 0 = default for the tile),
 // waves = 4 or 8 per workgroup (0 = default)

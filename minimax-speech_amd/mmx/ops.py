@@ -348,11 +348,11 @@ def decode_prep(x, xs, ssq, *, B, K, gamma=None, h=None, dtype=L.X3):
 
 
 def skinny2(xs, wp, *, B, K, N, dtype, bias=None, ssq_in=None, eps=1e-6, epi=0, out=None, ldo=None, xs_out=None, gamma_next=None,
-            ssq_out=None, tiles_per_wg=1, ksplit=1, part=None, tickets=None, stamps=None):
+            ssq_out=None, tiles_per_wg=1, ksplit=1, part=None, tickets=None):
     """The split build's decode-step projection on split-plane activations (include/mmx_hip.h mmx_skinny2)."""
     check(load().mmx_skinny2(_p(xs), B, K, N, _p(wp), _p(bias), _p(ssq_in), C.c_float(eps), epi, _p(out),
                              i64(ldo if ldo is not None else N), _p(xs_out), _p(gamma_next), _p(ssq_out), tiles_per_wg, ksplit,
-                             _p(part), i64(part.numel() if part is not None else 0), _p(tickets), dtype, _p(stamps), stream()), "mmx_skinny2")
+                             _p(part), i64(part.numel() if part is not None else 0), _p(tickets), dtype, stream()), "mmx_skinny2")
 
 
 def rope_kv_store(qkv, inv_freq, pos, q_out, kc, vc, block_table, *, B, rows, Hq, Hkv, page, dtype):

@@ -1,5 +1,5 @@
 """Where a decode-step projection kernel (csrc/decode.hip) spends its time: shader-clock stamps of the kernel's phases per wave
-(mmx_skinny2's debug_stamps hook), for the four projection shapes of a layer at batch 32, each launched back to back over 24
+(the lab build's mmx_lab_skinny_stamps switch: run with MMX_LIB=minimax-speech_amd/lib/libmmx_hip_lab.so, `make -C minimax-speech_amd/csrc lab`), for the four projection shapes of a layer at batch 32, each launched back to back over 24
 different weight sets (so the weights come from HBM as in the decode step).  Also the floor of a dependent launch chain: the
 same number of trivial kernels in one hipGraph.
 
@@ -12,9 +12,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "minimax-speech_amd"))
-from mmx import ops  # noqa: E402
+import ctypes as C  # noqa: E402
+
+from mmx import _lib, ops  # noqa: E402
 
 X3 = 3
+LIB = _lib.load()
+assert hasattr(LIB, "mmx_lab_skinny_stamps"), "run with MMX_LIB=<repo>/minimax-speech_amd/lib/libmmx_hip_lab.so (make -C minimax-speech_amd/csrc lab)"
 
 
 def main():
@@ -40,9 +44,11 @@ def main():
         stamps = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
 
         def run(l, st=None):
+            # lab build only (include/mmx_hip_lab.h): the stamp buffer is a device global of libmmx_hip_lab.so
+            assert LIB.mmx_lab_skinny_stamps(C.c_void_p(st.data_ptr() if st is not None else 0)) == 0
             ops.skinny2(xs, ws[l], B=B, K=K, N=N, dtype=X3, ssq_in=(ssq if rs else None), epi=epi, out=(out if epi != 1 else None),
                         xs_out=(xs_out if epi != 0 else None), gamma_next=None, ssq_out=(ssq_out if epi == 2 else None),
-                        tiles_per_wg=tw, ksplit=J, part=part, tickets=tickets, stamps=st)
+                        tiles_per_wg=tw, ksplit=J, part=part, tickets=tickets)
 
         for l in range(L):
             run(l)

@@ -61,7 +61,7 @@ def sweep():
 
 
 def stamps(n=5, T=1000, bm=64, waves=4, pf=2):
-    """Stage-boundary shader-clock stamps of every wave of one launch (mmx_debug_tail_stamps): median over workgroups of
+    """Stage-boundary shader-clock stamps of every wave of one launch (mmx_lab_tail_stamps): median over workgroups of
     the time between consecutive stamps of wave 0..NW-1, in us (s_memtime ticks / 2100)."""
     import ctypes as C
     from mmx import _lib
@@ -85,10 +85,10 @@ def stamps(n=5, T=1000, bm=64, waves=4, pf=2):
         nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
                            vt_bs=vt_bs)
         if i == 5:
-            assert lib.mmx_debug_tail_stamps(C.c_void_p(buf.data_ptr())) == 0
+            assert lib.mmx_lab_tail_stamps(C.c_void_p(buf.data_ptr())) == 0
         ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=100 <= waves < 200, narrow=waves >= 200)
     torch.cuda.synchronize()
-    assert lib.mmx_debug_tail_stamps(C.c_void_p(0)) == 0
+    assert lib.mmx_lab_tail_stamps(C.c_void_p(0)) == 0
     s = buf.cpu().reshape(nwg, nw, 64).double()
     names = {0: "entry", 1: "operand loads issued + tile copy", 2: "barrier", 3: "Wo MFMA", 4: "Wo epilogue", 5: "LN3 + A1 + barrier"}
     for ch in range(2):
