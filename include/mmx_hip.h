@@ -23,6 +23,11 @@
  *    bf16 MFMA with the activation split into 2 (hi + lo: 16 significant bits) or 3 (24 bits) bf16 terms accumulated
  *    in fp32.  With bf16-representable weights the result is fp32-grade (X3) at the bf16 build's weight bytes.
  *    Entry points without a matrix product treat MMX_X2 / MMX_X3 as MMX_F32.
+ *    MMX_X2W / MMX_X3W (the split build on an fp32 CHECKPOINT: mmx_gemm_win, mmx_skinny2): the weights too are carried as 2 / 3
+ *    bf16 planes hi + [mid +] lo = w, and a product keeps every term (activation plane s) x (weight plane p) with
+ *    s + p < 2 / 3 - three / six bf16 MFMAs per fragment pair, 16 / 24 significant bits of both operands.  Weight layout:
+ *    mmx_gemm_win: the planes side by side in every row, W[n][p * (ldw / planes) + k]; mmx_skinny2: the planes' packs one
+ *    after the other.  Every other argument as for MMX_X2 / MMX_X3.
  *  - activations are TIME-MAJOR: a [B,C,T] tensor of the reference is stored as rows of C channels.
  */
 #ifndef MMX_HIP_H
@@ -40,6 +45,8 @@ typedef struct ihipStream_t* hipStream_t;
 #define MMX_BF16 1
 #define MMX_X2 2
 #define MMX_X3 3
+#define MMX_X2W 0x12
+#define MMX_X3W 0x13
 
 /* activation codes */
 #define MMX_ACT_NONE 0

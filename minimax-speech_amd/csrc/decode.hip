@@ -65,6 +65,7 @@ struct Skinny3Args {
     long ldo;
     int B, K, N, ntiles, kb_per_wg;
     float eps;
+    unsigned wplane;         // NWP > 1 (MMX_X3W): bytes between two weight planes (each a whole pack)
 };
 
 // lab build only (common.h, MMX_LAB): [workgroup][wave][8] shader-clock stamps of the kernel's phases, set by mmx_lab_skinny_stamps
@@ -72,7 +73,9 @@ __device__ unsigned long long* g_skinny_stamps = nullptr;
 #define STAMP(i) do { if constexpr (LAB) { if (stamps && lane == 0) stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 
 // MT: 16-row tiles of the batch; TW: output tiles (EPI 1: gate/up tile pairs) per workgroup; KPW: k-blocks per wave (bound)
-template <int MT, int TW, int KPW, int EPI, int NS>
+// NWP = 3 (MMX_X3W, an fp32 checkpoint): the weights as three bf16 planes hi + mid + lo = w, each a pack of its own; a product keeps
+// the six terms (activation plane s) x (weight plane p) with s + p < 3 - both operands to fp32's 24 bits.
+template <int MT, int TW, int KPW, int EPI, int NS, int NWP = 1>
 __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     unsigned long long* stamps = nullptr;
     unsigned long long t_entry = 0;
@@ -101,17 +104,19 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wp), 0, 0x7fffffff, 0x00020000);
     const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.xs), 0, 0x7fffffff, 0x00020000);
     const unsigned voff = lane * 16;
-    u32x4_t wf[TW][NB][KPW];
+    u32x4_t wf[NWP][TW][NB][KPW];
 #pragma unroll
-    for (int t = 0; t < TW; ++t)
+    for (int p2 = 0; p2 < NWP; ++p2)
 #pragma unroll
-        for (int n = 0; n < NB; ++n)
+        for (int t = 0; t < TW; ++t)
 #pragma unroll
-            for (int i = 0; i < KPW; ++i) {
-                const bool ok = tile0 + t < ntiles && kb0 + i < kb1;
-                const unsigned so = ok ? ((unsigned)(((tile0 + t) * NB + n) * nkb + kb0 + i) << 10) : OOB;
-                wf[t][n][i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff, so, 2);          // aux 2: non-temporal
-            }
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int i = 0; i < KPW; ++i) {
+                    const bool ok = tile0 + t < ntiles && kb0 + i < kb1;
+                    const unsigned so = ok ? ((unsigned)(((tile0 + t) * NB + n) * nkb + kb0 + i) << 10) + p2 * a.wplane : OOB;
+                    wf[p2][t][n][i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, voff, so, 2);  // aux 2: non-temporal
+                }
     u32x4_t xf[NS][KPW][MT];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -159,14 +164,18 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
 #pragma unroll
         for (int t = 0; t < TW; ++t)
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const short8_t bfr = __builtin_bit_cast(short8_t, wf[t][n][i]);
+            for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int p2 = 0; p2 < NWP; ++p2) {
+                    const short8_t bfr = __builtin_bit_cast(short8_t, wf[p2][t][n][i]);
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
-                        acc[t][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, xf[s][i][m]), bfr, acc[t][n][m], 0, 0, 0);
-            }
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            if (s + p2 >= NS) continue;    // (compile time) terms below the last kept bit
+                            acc[t][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, xf[s][i][m]), bfr, acc[t][n][m], 0, 0, 0);
+                        }
+                }
     // reduction over the 8 k slices of the workgroup through LDS, fixed order
     {
         float* mine = red + wave * PER * 64 + lane;
@@ -268,13 +277,13 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     STAMP(6);
 }
 
-template <int MT, int TW, int KPW, int EPI, int NS>
+template <int MT, int TW, int KPW, int EPI, int NS, int NWP = 1>
 int launch(const Skinny3Args& a, int J, hipStream_t s) {
     constexpr int NB = EPI == 1 ? 2 : 1;
     const size_t lds = (size_t)8 * (TW * NB * MT * 4) * 64 * sizeof(float) + 32 * sizeof(float) + 16;
-    MMX_LDS_OPT_IN((skinny3_kernel<MT, TW, KPW, EPI, NS>), lds);
+    MMX_LDS_OPT_IN((skinny3_kernel<MT, TW, KPW, EPI, NS, NWP>), lds);
     dim3 grid((a.ntiles + TW - 1) / TW, J);
-    hipLaunchKernelGGL((skinny3_kernel<MT, TW, KPW, EPI, NS>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((skinny3_kernel<MT, TW, KPW, EPI, NS, NWP>), grid, dim3(512), lds, s, a);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
@@ -317,7 +326,8 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
                            int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
                            int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,
                            hipStream_t stream) {
-    MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 && (dtype == MMX_X3 || dtype == MMX_BF16));
+    MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 && (dtype == MMX_X3 || dtype == MMX_X3W || dtype == MMX_BF16));
+    MMX_CHECK_ARG(dtype != MMX_X3W || tiles_per_wg == 1);   // three weight planes in registers: one output tile per workgroup
     MMX_CHECK_ARG(((uintptr_t)xs % 16) == 0 && ((uintptr_t)wp % 16) == 0 && (!ssq_in || ((uintptr_t)ssq_in % 16) == 0));
     MMX_CHECK_ARG(ksplit >= 1 && ksplit <= 8 && (ksplit == 1 || (epi == 2 && part && tickets)));
     MMX_CHECK_ARG(epi == 1 ? (xs_out != nullptr && N % 32 == 0) : out != nullptr);
@@ -327,10 +337,13 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
     const int per_wave = ((nkb + ksplit - 1) / ksplit + 7) / 8;
     MMX_CHECK_ARG(ksplit == 1 || part_floats >= (int64_t)ksplit * ((ntiles + tiles_per_wg - 1) / tiles_per_wg) * tiles_per_wg * mt * 4 * 64);
     // 32-bit buffer offsets: the packed weights and the planes must stay below 2 GiB
-    MMX_CHECK_ARG((double)ntiles * (epi == 1 ? 2 : 1) * nkb * 1024.0 < 2147483000.0);
+    const double plane_bytes = (double)ntiles * (epi == 1 ? 2 : 1) * nkb * 1024.0;
+    MMX_CHECK_ARG(plane_bytes * (dtype == MMX_X3W ? 3 : 1) < 2147483000.0);
     Skinny3Args a{(const bf16_t*)xs, (const bf16_t*)wp, bias, ssq_in, out, (bf16_t*)xs_out, gamma_next, ssq_out, part, tickets,
-                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps};
-#define GO(MT, TW, KPW, EPI) do { if (dtype == MMX_X3) return launch<MT, TW, KPW, EPI, 3>(a, ksplit, stream); return launch<MT, TW, KPW, EPI, 1>(a, ksplit, stream); } while (0)
+                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps, (unsigned)plane_bytes};
+#define GO(MT, TW, KPW, EPI) do { if (dtype == MMX_X3) return launch<MT, TW, KPW, EPI, 3>(a, ksplit, stream); \
+                                  if (dtype == MMX_X3W) { if constexpr (TW == 1) return launch<MT, 1, KPW, EPI, 3, 3>(a, ksplit, stream); else return MMX_EARG; } \
+                                  return launch<MT, TW, KPW, EPI, 1>(a, ksplit, stream); } while (0)
 #define BY_MT(TW, KPW, EPI) do { if (mt == 1) GO(1, TW, KPW, EPI); else GO(2, TW, KPW, EPI); } while (0)
     if (per_wave <= 4) {
         if (epi == 0) { if (tiles_per_wg == 1) BY_MT(1, 4, 0); if (tiles_per_wg == 2) BY_MT(2, 4, 0); }

@@ -42,10 +42,14 @@ template <> struct Frag<float> {
 // into LDS (hi = bf16(x), then the rounded remainders), and every A x W fragment pair costs NS MFMAs into the same
 // accumulator: exact bf16 x bf16 products, fp32 accumulation, i.e. 16 (NS = 2) or 24 (NS = 3) significant bits of the
 // activation against exactly represented bf16 weights.
-template <typename T, typename TA, int NS, int BM, int BN, int WM, int WN>
+// NWP > 1 (MMX_X2W / MMX_X3W): the weights of an fp32 checkpoint, held as NWP bf16 PLANES hi + [mid +] lo = w (16 / 24 significant
+// bits) side by side in every row: W[n][plane * (ldw / NWP) + k].  A product keeps every term A_s x W_p of order s + p < NS
+// (NS = NWP = 2: hi*hi + hi*lo + lo*hi, 3 MFMAs; 3: 6 MFMAs): what is dropped is below the last kept bit of either operand.
+template <typename T, typename TA, int NS, int BM, int BN, int WM, int WN, int NWP = 1>
 __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     constexpr int BK = 32;
     constexpr bool XS = NS > 1;
+    static_assert(NWP == 1 || NWP == NS, "weight planes: as many as activation planes");
     static_assert(!XS || (sizeof(T) == 2 && sizeof(TA) == 4), "split build: bf16 weights, fp32 activations");
     static_assert(XS || sizeof(T) == sizeof(TA), "one storage type otherwise");
     constexpr int CH = Frag<T>::CH;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* As = reinterpret_cast<T*>(smem);                // [NS][2][BM][LR]
-    T* Ws = As + NS * 2 * BM * LR;                     // [2][BN][LR]
+    T* Ws = As + NS * 2 * BM * LR;                     // [NWP][2][BN][LR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     // register-staged prefetch ring: STAGES k-tiles of global loads in flight per workgroup (these GEMMs are
     // short-K and latency bound: M ~ 500-1000 rows, K = 256..1024), 2 LDS buffers, one barrier per k-tile
     constexpr int STAGES = (sizeof(T) == 2 && !XS) ? 4 : 2;
-    uint4 a_reg[STAGES][A_CHUNKS], w_reg[STAGES][W_CHUNKS];
+    uint4 a_reg[STAGES][A_CHUNKS], w_reg[STAGES][NWP][W_CHUNKS];
+    const unsigned w_plane = (unsigned)((p.ldw / NWP) * (long)sizeof(T));   // bytes between two planes of a weight row
     const int K = p.ntaps * p.cin;
     const int nk = (K + BK - 1) / BK;                  // W is zero padded to nk*BK columns (ldw >= nk*BK)
 
@@ -134,8 +139,11 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
-            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, kt < nk ? w_off[i] : OOB, 0, 0);
-            w_reg[slot][i] = make_uint4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int p2 = 0; p2 < NWP; ++p2) {
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (kt < nk && w_off[i] != OOB) ? w_off[i] + p2 * w_plane : OOB, 0, 0);
+                w_reg[slot][p2][i] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
             if (w_off[i] != OOB) w_off[i] += BK * (unsigned)sizeof(T);
         }
     };
@@ -167,8 +175,11 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
             int id = tid + i * 256;
-            if (W_FULL || id < BN * CPR)
-                *reinterpret_cast<uint4*>(Ws + (stage * BN + id / CPR) * LR + (id % CPR) * CH) = w_reg[slot][i];
+            if (W_FULL || id < BN * CPR) {
+#pragma unroll
+                for (int p2 = 0; p2 < NWP; ++p2)
+                    *reinterpret_cast<uint4*>(Ws + ((p2 * 2 + stage) * BN + id / CPR) * LR + (id % CPR) * CH) = w_reg[slot][p2][i];
+            }
         }
     };
 
@@ -182,19 +193,25 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
         const T* as = As + (st * BM + wm * (BM / WM) + l16) * LR;
         const T* ws = Ws + (st * BN + wn * (BN / WN) + l16) * LR;
         if constexpr (sizeof(T) == 2) {
-            short8_t bfr[NF];
+            short8_t bfr[NWP][NF];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) bfr[j] = *reinterpret_cast<const short8_t*>(ws + j * 16 * LR + 8 * g);
+            for (int p2 = 0; p2 < NWP; ++p2)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bfr[p2][j] = *reinterpret_cast<const short8_t*>(ws + p2 * 2 * BN * LR + j * 16 * LR + 8 * g);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {          // the planes of the split A tile (one plane otherwise)
                 short8_t af[MF];
 #pragma unroll
                 for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const short8_t*>(as + s2 * 2 * BM * LR + i * 16 * LR + 8 * g);
 #pragma unroll
-                for (int i = 0; i < MF; ++i)
+                for (int p2 = 0; p2 < NWP; ++p2) {
+                    if (s2 + p2 >= NS) continue;       // (compile time) terms below the last kept bit
 #pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[p2][j], acc[i][j], 0, 0, 0);
+                }
             }
         } else {
 #pragma unroll
@@ -371,19 +388,19 @@ __global__ __launch_bounds__(256) void gemm_win_kernel(GemmParams p) {
     }
 }
 
-template <typename T, typename TA, int NS, int BM, int BN, int WM, int WN>
+template <typename T, typename TA, int NS, int BM, int BN, int WM, int WN, int NWP = 1>
 static int launch_cfg(const GemmParams& p, hipStream_t s) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch);
-    size_t lds = (size_t)2 * (NS * BM + BN) * Frag<T>::LDS_ROW * sizeof(T);
+    size_t lds = (size_t)2 * (NS * BM + NWP * BN) * Frag<T>::LDS_ROW * sizeof(T);
     const size_t lds_epi = (size_t)4 * 16 * (BN / WN + 4) * sizeof(float);    // per-wave epilogue patches
     if (lds_epi > lds) lds = lds_epi;
-    MMX_LDS_OPT_IN((gemm_win_kernel<T, TA, NS, BM, BN, WM, WN>), lds);
-    hipLaunchKernelGGL((gemm_win_kernel<T, TA, NS, BM, BN, WM, WN>), grid, dim3(256), lds, s, p);
+    MMX_LDS_OPT_IN((gemm_win_kernel<T, TA, NS, BM, BN, WM, WN, NWP>), lds);
+    hipLaunchKernelGGL((gemm_win_kernel<T, TA, NS, BM, BN, WM, WN, NWP>), grid, dim3(256), lds, s, p);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
 
-template <typename T, typename TA, int NS>
+template <typename T, typename TA, int NS, int NWP = 1>
 static int launch_T(const GemmParams& p, hipStream_t s, int force_tile) {
     // shape validation the kernel relies on (16-byte chunk loads)
     constexpr int CH = Frag<T>::CH;
@@ -391,7 +408,7 @@ static int launch_T(const GemmParams& p, hipStream_t s, int force_tile) {
     MMX_CHECK_ARG(p.A && p.W && p.M > 0 && p.N > 0 && p.batch > 0 && p.ntaps >= 1);
     MMX_CHECK_ARG(p.cin % CH == 0 && p.lda % CHA == 0 && p.ldw % CH == 0);
     MMX_CHECK_ARG(p.a_bstride % CHA == 0 && p.w_bstride % CH == 0);
-    MMX_CHECK_ARG(p.ldw >= ((p.ntaps * p.cin + 31) / 32) * 32);
+    MMX_CHECK_ARG(p.ldw % NWP == 0 && (p.ldw / NWP) % CH == 0 && p.ldw / NWP >= ((p.ntaps * p.cin + 31) / 32) * 32);
     MMX_CHECK_ARG(p.bias_mod > 0 && p.alpha_mod > 0 && p.row_stride >= 1);
     MMX_CHECK_ARG(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0);
     MMX_CHECK_ARG(p.out_f32 || p.out_act);
@@ -402,6 +419,12 @@ static int launch_T(const GemmParams& p, hipStream_t s, int force_tile) {
     MMX_CHECK_ARG(p.act2 == ACT_NONE || (p.act2 == ACT_MISH && p.act == ACT_NONE));   // the only fused pair in use
     // largest tile that still gives every CU a workgroup (256 CUs); short-K GEMMs want many MFMAs per barrier
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch; };
+    if constexpr (NWP > 1) {                           // weight planes: two tiles (LDS: 4 or 6 operand planes per k-tile)
+        if (force_tile != 0 && force_tile != MMX_TILE_64x64 && force_tile != MMX_TILE_32x64) return MMX_EARG;
+        if (force_tile != MMX_TILE_32x64 && (force_tile == MMX_TILE_64x64 || blocks(64, 64) >= 64 || p.M > 32))
+            return launch_cfg<T, TA, NS, 64, 64, 2, 2, NWP>(p, s);
+        return launch_cfg<T, TA, NS, 32, 64, 1, 4, NWP>(p, s);
+    }
     switch (force_tile) {                              // mmx_gemm_win_tile: the tuning entry (tools/microbench.py)
         case 0: break;
         case MMX_TILE_128x128: return launch_cfg<T, TA, NS, 128, 128, 2, 2>(p, s);
@@ -426,6 +449,8 @@ extern "C" int mmx_gemm_win_tile(const GemmParams* p, int dtype, int tile, hipSt
     if (dtype == MMX_F32) return launch_T<float, float, 1>(*p, stream, tile);
     if (dtype == MMX_X2) return launch_T<bf16_t, float, 2>(*p, stream, tile);
     if (dtype == MMX_X3) return launch_T<bf16_t, float, 3>(*p, stream, tile);
+    if (dtype == MMX_X2W) return launch_T<bf16_t, float, 2, 2>(*p, stream, tile);
+    if (dtype == MMX_X3W) return launch_T<bf16_t, float, 3, 3>(*p, stream, tile);
     return MMX_EARG;
 }
 extern "C" int mmx_gemm_win(const GemmParams* p, int dtype, hipStream_t stream) {

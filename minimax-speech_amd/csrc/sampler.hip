@@ -68,34 +68,57 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return r;
 }
 
-constexpr int SAMP_THREADS = 256;
-constexpr int SAMP_MAXV = 26;        // V <= 6656 (speech_token_size + 3 = 6564)
+// 512 threads = 8 waves per sequence (two per SIMD): 13 logits per thread.  The kernel is ONE dependent chain per decode step
+// (it sits between the head projection and the next step's first launch), so what counts is its length, not its work:
+//   * the threshold of the candidate list comes from 64 GROUP maxima (8 consecutive lanes each, reduced with DPP), ranked by
+//     one wave - 64 x 64 comparisons instead of 256 x 256;
+//   * list ranks are counted by 8 lanes per entry (DPP sum), the running sum of the sorted prefix walks registers of one
+//     wave (v_readlane) instead of 25 dependent LDS reads, the nucleus draw is reduced inside wave 0;
+//   * the repetition window is read by 10 lanes at once.
+// Round 3's kernel (256 threads, 26 logits per thread, every thread ranking 256 local maxima) took 29 us per step.
+constexpr int SAMP_THREADS = 512;
+constexpr int SAMP_WAVES = SAMP_THREADS / 64;
+constexpr int SAMP_MAXV = 13;        // V <= 6656 (speech_token_size + 3 = 6564)
 constexpr int SAMP_MAXK = 64;
-constexpr int SAMP_LIST = 512;       // candidates >= the top_k-th local maximum (ties / clustered values included)
+constexpr int SAMP_GROUPS = SAMP_THREADS / 8;   // 64 group maxima
+constexpr int SAMP_LIST = 512;       // candidates >= the top_k-th group maximum (ties / clustered values included)
+
+// (value, index) of the better of two candidates across lanes with a DPP control (see common.h dpp_f32)
+template <int CTRL>
+__device__ __forceinline__ ArgMax dpp_better(ArgMax a) {
+    ArgMax o;
+    o.v = dpp_f32<CTRL>(a.v);
+    o.i = __builtin_amdgcn_update_dpp(0, a.i, CTRL, 0xf, 0xf, false);
+    return better(a, o);
+}
 
 __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     const float* __restrict__ logits, long ldl, int V, int eos_id, int top_k, float top_p, int win_size, float tau_r,
     unsigned long long seed, int32_t* __restrict__ state, int32_t* __restrict__ out_tokens, int max_out,
     int32_t* __restrict__ sampled, const int32_t* __restrict__ forced, const float* __restrict__ speech_emb, int E,
     float* __restrict__ next_x, long ldx, float* __restrict__ logp_out) {
-    __shared__ float shf[8];
-    __shared__ ArgMax sha[8];
+    __shared__ float shf[SAMP_WAVES];
+    __shared__ ArgMax sha[SAMP_WAVES];
     __shared__ float cand_p[SAMP_MAXK];
     __shared__ int cand_i[SAMP_MAXK];
-    __shared__ int sh_n, sh_top, sh_cnt, sh_thr_i;
+    __shared__ int sh_top, sh_cnt, sh_thr_i;
     __shared__ float sh_thr_v;
-    __shared__ __attribute__((aligned(16))) float lmax_p[SAMP_THREADS];
-    __shared__ __attribute__((aligned(16))) int lmax_i[SAMP_THREADS];
+    __shared__ __attribute__((aligned(16))) float gmax_p[SAMP_GROUPS];
+    __shared__ __attribute__((aligned(16))) int gmax_i[SAMP_GROUPS];
     __shared__ float p_lds[SAMP_THREADS * SAMP_MAXV];
     __shared__ float list_p[SAMP_LIST];
     __shared__ int list_i[SAMP_LIST];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = gridDim.x;                          // state is field-major: state[field * B + b]
     int32_t* st = state + b;
 #define ST(f) st[(f) * nb]
     const int pos = ST(0), step = ST(1), n_out = ST(2), finished = ST(3), min_len = ST(4), max_len = ST(5), seq = ST(6);
     if (finished) return;                              // uniform per block
     const float* lg = logits + (long)b * ldl;
+    // the repetition window (common.py:113: the last win_size accepted tokens), one token per lane, requested with the logits
+    const int wn = min(win_size, n_out);
+    int hist = -1;
+    if (lane < wn) hist = out_tokens[(long)b * max_out + n_out - wn + lane];
 
     // log_softmax, then softmax of it (the reference's two stages, common.py:122)
     float x[SAMP_MAXV];
@@ -139,33 +162,35 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
         }
 
     // nucleus candidates = prefix of the stable descending sort (value desc, index asc), found by RANK COUNTING
-    // rather than by repeated arg-max rounds (50 dependent wave reductions through ds_bpermute cost ~30 us per token):
-    // (1) every thread's local maximum; (2) each thread counts how many of the 256 maxima precede its own in the sort
-    // order - the one with rank top_k-1 is a threshold T with at least top_k elements >= T, so every global top_k
-    // element is >= T; (3) all elements >= T are pushed to a small LDS list; (4) each list entry's rank inside the list
-    // is its position in the sorted prefix; (5) the fp32 running sum walks that prefix in the reference's order
-    // (common.py:124-131).  Ranks are unique because indices are.
+    // rather than by repeated arg-max rounds: (1) the maximum of every group of 8 lanes (104 elements); (2) one wave counts,
+    // for each of the 64 group maxima, how many of the others precede it in the sort order - the one with rank top_k-1 is a
+    // threshold T with at least top_k elements >= T, so every global top_k element is >= T; (3) all elements >= T are pushed
+    // to a small LDS list; (4) each list entry's rank inside the list is its position in the sorted prefix; (5) the fp32
+    // running sum walks that prefix in the reference's order (common.py:124-131).  Ranks are unique because indices are.
     auto precedes = [](float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); };
     {
         ArgMax a{-2.f, 0x7fffffff};
 #pragma unroll
         for (int i = 0; i < SAMP_MAXV; ++i) a = better(a, ArgMax{x[i], tid + i * SAMP_THREADS});
-        lmax_p[tid] = a.v;
-        lmax_i[tid] = a.i;
+        a = dpp_better<0xB1>(a);                       // lanes xor 1, xor 2, then the other quad of the 8
+        a = dpp_better<0x4E>(a);
+        a = dpp_better<0x141>(a);
+        if ((lane & 7) == 0) { gmax_p[tid >> 3] = a.v; gmax_i[tid >> 3] = a.i; }
     }
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
-    {
-        const float mv = lmax_p[tid];
-        const int mi = lmax_i[tid];
+    if (wave == 0) {
+        const float mv = gmax_p[lane];
+        const int mi = gmax_i[lane];
         int rk = 0;
-        for (int j = 0; j < SAMP_THREADS; j += 4) {     // 16-byte broadcast reads: a quarter of the LDS instructions
-            const float4 pv = *reinterpret_cast<const float4*>(lmax_p + j);
-            const int4 iv = *reinterpret_cast<const int4*>(lmax_i + j);
+#pragma unroll
+        for (int j = 0; j < SAMP_GROUPS; j += 4) {     // 16-byte broadcast reads
+            const float4 pv = *reinterpret_cast<const float4*>(gmax_p + j);
+            const int4 iv = *reinterpret_cast<const int4*>(gmax_i + j);
             rk += (precedes(pv.x, iv.x, mv, mi) ? 1 : 0) + (precedes(pv.y, iv.y, mv, mi) ? 1 : 0) +
                   (precedes(pv.z, iv.z, mv, mi) ? 1 : 0) + (precedes(pv.w, iv.w, mv, mi) ? 1 : 0);
         }
-        if (rk == min(top_k, SAMP_THREADS) - 1) { sh_thr_v = mv; sh_thr_i = mi; }
+        if (rk == min(top_k, SAMP_GROUPS) - 1) { sh_thr_v = mv; sh_thr_i = mi; }
     }
     __syncthreads();
     {
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
             // recomputed from (value, index) below)
             const unsigned long long tm = __ballot(take);
             if (tm) {
-                const int lane = tid & 63, leader = __ffsll((long long)tm) - 1;
+                const int leader = __ffsll((long long)tm) - 1;
                 int base = 0;
                 if (lane == leader) base = atomicAdd(&sh_cnt, __popcll(tm));
                 base = __shfl(base, leader, 64);
@@ -192,38 +217,51 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
     }
     __syncthreads();
     const int cnt = min(sh_cnt, SAMP_LIST);
-    for (int id = tid; id < cnt; id += SAMP_THREADS) {
-        const float mv = list_p[id];
-        const int mi = list_i[id];
+    // rank of list entry `id` inside the list: 8 lanes share the comparisons of one entry (64 entries per round)
+    for (int id0 = 0; id0 < cnt; id0 += SAMP_THREADS / 8) {
+        const int id = id0 + (tid >> 3), part = tid & 7;
+        const bool live = id < cnt;
+        const float mv = live ? list_p[id] : 0.f;
+        const int mi = live ? list_i[id] : 0;
         int rk = 0;
-        for (int j = 0; j < cnt; ++j) rk += precedes(list_p[j], list_i[j], mv, mi) ? 1 : 0;
-        if (rk < SAMP_MAXK) { cand_p[rk] = mv; cand_i[rk] = mi; }
+        for (int j = part; j < cnt; j += 8) rk += precedes(list_p[j], list_i[j], mv, mi) ? 1 : 0;
+        rk += __builtin_amdgcn_update_dpp(0, rk, 0xB1, 0xf, 0xf, false);
+        rk += __builtin_amdgcn_update_dpp(0, rk, 0x4E, 0xf, 0xf, false);
+        rk += __builtin_amdgcn_update_dpp(0, rk, 0x141, 0xf, 0xf, false);
+        if (live && part == 0 && rk < SAMP_MAXK) { cand_p[rk] = mv; cand_i[rk] = mi; }
     }
     __syncthreads();
-    if (tid == 0) {
+    // every wave walks the sorted prefix on its own (no barrier, no broadcast): lane i holds candidate i, the fp32 running sum
+    // adds them in the reference's order (common.py:127)
+    const int lim = min(min(top_k, SAMP_MAXK), cnt);
+    const float cp = lane < lim ? cand_p[lane] : 0.f;
+    const int ci = lane < lim ? cand_i[lane] : 0;
+    int nc = 0;
+    {
         float cum = 0.f;
-        int nc = 0;
-        const int lim = min(min(top_k, SAMP_MAXK), cnt);
+#pragma unroll 1
         while (cum < top_p && nc < lim) {
-            cum += cand_p[nc];                         // fp32 running sum, same order as common.py:127
+            cum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cp), nc));
             nc++;
         }
-        sh_n = nc;
     }
-    __syncthreads();
-    const int nc = sh_n;
 
     const bool ignore_eos = step < min_len;
     int top = 0;
     for (int trial = 0;; ++trial) {
-        // nucleus draw: argmax_i cand_p[i] / e_i
+        // nucleus draw: argmax_i cand_p[i] / e_i, reduced inside every wave (the same values in each: no barrier)
         ArgMax a{-1.f, 0x7fffffff};
-        if (tid < nc) a = ArgMax{cand_p[tid] / exp_noise(seed, seq, step, trial, 0, tid), tid};
-        a = block_argmax(a, sha);
-        top = cand_i[a.i];
+        if (lane < nc) a = ArgMax{cp / exp_noise(seed, seq, step, trial, 0, lane), lane};
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ArgMax y;
+            y.v = __shfl_xor(a.v, o, 64);
+            y.i = __shfl_xor(a.i, o, 64);
+            a = better(a, y);
+        }
+        top = __builtin_amdgcn_readlane(ci, a.i);
         // repetition-aware fallback (common.py:113-115)
-        int rep = 0;
-        for (int j = max(0, n_out - win_size); j < n_out; ++j) rep += out_tokens[(long)b * max_out + j] == top;
+        const int rep = __popcll(__ballot(hist == top));
         if ((float)rep >= (float)win_size * tau_r) {
             ArgMax r{-1.f, 0x7fffffff};
 #pragma unroll 1
@@ -235,13 +273,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_step_kernel(
         if (!ignore_eos || top != eos_id) break;
         if (trial >= 100) { if (tid == 0) ST(7) = 1; break; }    // llm.py:271-273 raises here; flag + accept
     }
-    if (tid == 0) {
-        if (sampled) sampled[(long)b * max_out + step] = top;
-        if (forced) top = forced[(long)b * max_out + step];
-        sh_top = top;
-    }
-    __syncthreads();
-    top = sh_top;
+    if (tid == 0 && sampled) sampled[(long)b * max_out + step] = top;
+    if (forced) top = forced[(long)b * max_out + step];         // uniform: every thread reads the same word
     if (top == eos_id) {
         if (tid == 0) { ST(3) = 1; ST(1) = step + 1; }
         return;
@@ -263,7 +296,7 @@ extern "C" int mmx_sample_step(const float* logits, int64_t ldl, int V, int B, i
                                int32_t* sampled, const int32_t* forced, const float* speech_emb, int E, float* next_x,
                                int64_t ldx, float* logp_out, hipStream_t stream) {
     MMX_CHECK_ARG(logits && state && out_tokens && speech_emb && next_x && B > 0 && V > 0 && V <= SAMP_THREADS * SAMP_MAXV);
-    MMX_CHECK_ARG(top_k > 0 && top_k <= SAMP_MAXK && max_out > 0 && E > 0 && eos_id < V);
+    MMX_CHECK_ARG(top_k > 0 && top_k <= SAMP_MAXK && top_k <= SAMP_GROUPS && win_size >= 0 && win_size <= 64 && max_out > 0 && E > 0 && eos_id < V);
     hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(SAMP_THREADS), 0, stream, logits, ldl, V, eos_id, top_k, top_p, win_size,
                        tau_r, (unsigned long long)seed, state, out_tokens, max_out, sampled, forced, speech_emb, E, next_x, ldx, logp_out);
     MMX_LAUNCH_CHECK();

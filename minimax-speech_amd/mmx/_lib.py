@@ -9,15 +9,21 @@ F32, BF16 = 0, 1
 # and split into 2 / 3 bf16 terms inside every MFMA product.  X2 is what the flow and the DAC run (16 significant bits
 # per activation), X3 the LM (24 bits: its sampler turns a 1e-3 log-prob error into another token id).
 X2, X3 = 2, 3
+# weight planes (include/mmx_hip.h MMX_X2W / MMX_X3W; GEMM entry points only): the weights of an fp32 checkpoint as 2 / 3 bf16
+# planes hi + [mid +] lo = w.  Engines built with wplanes=True pack their weights this way (ops.pack_* with these codes return
+# ops.Planed tensors) and the GEMM wrappers switch the dtype code when they are handed a Planed weight; every other entry point
+# keeps seeing X2 / X3.
+X2W, X3W = 0x12, 0x13
 ACT = {"none": 0, "lrelu": 1, "gelu": 2, "silu": 3, "mish": 4, "tanh": 5}
-TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.float32, X3: torch.float32}       # activation storage
-WEIGHT_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.bfloat16, X3: torch.bfloat16}   # weight storage
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.float32, X3: torch.float32, X2W: torch.float32, X3W: torch.float32}       # activation storage
+WEIGHT_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.bfloat16, X3: torch.bfloat16, X2W: torch.bfloat16, X3W: torch.bfloat16}   # weight storage
 ESIZE = {F32: 4, BF16: 2, X2: 4, X3: 4}
+WPLANES = {X2W: 2, X3W: 3}                               # bf16 planes per weight
 DTYPE_NAMES = {"f32": F32, "bf16": BF16, "x": X2, "x2": X2, "x3": X3}
 
 
 def is_split(dtype):
-    return dtype in (X2, X3)
+    return dtype in (X2, X3, X2W, X3W)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmmx_hip.so")   # MMX_LIB: A/B of two builds

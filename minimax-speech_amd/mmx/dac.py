@@ -15,17 +15,22 @@ from typing import Dict, List
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT, X2
+from ._lib import BF16, F32, TORCH_DT, X2, X2W
 
 
 class DacDecoderEngine:
     FUSED_RU_MAX_C = 192          # ResidualUnits of at most this many channels run as ONE kernel (mmx_dac_ru: 48 / 96 / 192)
 
     def __init__(self, sd: Dict[str, torch.Tensor], rates: List[int], dtype=BF16, device="cuda", use_tanh=True,
-                 with_pre=True, fuse_ru=True):
+                 with_pre=True, fuse_ru=True, wplanes=False):
+        """wplanes (split build only): the checkpoint's folded fp32 weights are carried as two bf16 planes (MMX_X2W) instead of
+        being rounded to bf16 - for checkpoints whose weights are not bf16-representable (any trained weight norm)."""
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.wplanes = bool(wplanes) and dtype == X2
         # the fused ResidualUnit kernel exists for the bf16 and split builds; the fp32 build keeps two GEMM launches per unit
-        self.fuse_ru = bool(fuse_ru) and dtype in (BF16, X2)
+        # (and so does the weight-plane mode, which lives in the windowed GEMM)
+        self.fuse_ru = bool(fuse_ru) and dtype in (BF16, X2) and not self.wplanes
+        dtype = X2W if self.wplanes else dtype                         # `dtype` below: the code the weights are packed for
         self.rates = list(rates)
         self.hop = int(math.prod(rates))
         self.use_tanh = use_tanh

@@ -18,7 +18,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, X2, is_split
+from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, X2, X2W, is_split
 
 
 def espnet_rel_pe(T: int, d: int) -> torch.Tensor:
@@ -121,8 +121,16 @@ class Graphed:
 class FlowEngine:
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", n_timesteps=10, cfg_rate=0.7,
                  enc_chunk=25, est_chunk=50, pre_lookahead_len=3, use_graphs=True, parts=("encoder", "estimator"),
-                 fused=None, attn="bf16"):
+                 fused=None, attn="bf16", wplanes=False):
+        """wplanes (split build only): every GEMM weight is carried as two bf16 planes hi + lo of the checkpoint's fp32 value
+        (MMX_X2W, csrc/gemm.hip) instead of being rounded to bf16 - for checkpoints whose weights are not bf16-representable
+        (the reference loads fp32 flow.pt, cli/model.py:67-75).  The estimator then runs one launch per Linear / Conv1d
+        (fused=False): the weight-plane products live in the windowed GEMM."""
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.wplanes = bool(wplanes) and dtype == X2
+        self.pdt = X2W if self.wplanes else dtype            # the code weights are packed for
+        if self.wplanes:
+            fused = False
         self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
         self.enc_chunk, self.est_chunk = enc_chunk, est_chunk
         self.use_graphs = use_graphs
@@ -138,7 +146,7 @@ class FlowEngine:
         # config 5).  The split-key launches of streaming hops stay bf16.
         assert attn in ("bf16", "fp8")
         self.attn_fp8 = attn == "fp8" and dtype == BF16
-        dt = dtype
+        dt = self.pdt
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         lin = lambda k: ops.pack_linear(f(k), dt)
         cv = lambda k: ops.pack_conv1d(f(k), dt)
@@ -161,7 +169,7 @@ class FlowEngine:
         self.spk_enc = None
         if "speaker_encoder.init.weight" in sd:
             from .spk import SpeakerEncoderEngine
-            self.spk_enc = SpeakerEncoderEngine(sd, dtype=dtype, device=device)
+            self.spk_enc = SpeakerEncoderEngine(sd, dtype=dtype, device=device, pack_dtype=self.pdt)
         if "encoder" in parts:
             self._init_encoder(sd, f, lin, cv)
         if "estimator" in parts:
@@ -201,7 +209,7 @@ class FlowEngine:
             a = p + ".self_attn"
             return dict(
                 n1g=f(p + ".norm_mha.weight"), n1b=f(p + ".norm_mha.bias"),
-                wqkv=ops.pack_linear(torch.cat([f(a + ".linear_q.weight"), f(a + ".linear_k.weight"), f(a + ".linear_v.weight")], 0), dt),
+                wqkv=ops.pack_linear(torch.cat([f(a + ".linear_q.weight"), f(a + ".linear_k.weight"), f(a + ".linear_v.weight")], 0), self.pdt),
                 bqkv=torch.cat([f(a + ".linear_q.bias"), f(a + ".linear_k.bias"), f(a + ".linear_v.bias")], 0).contiguous(),
                 wpos=lin(a + ".linear_pos.weight"), pu=f(a + ".pos_bias_u"), pv=f(a + ".pos_bias_v"),
                 wo=lin(a + ".linear_out.weight"), bo=f(a + ".linear_out.bias"),
@@ -245,7 +253,7 @@ class FlowEngine:
                 d["wqk"] = ops.pack_linear(torch.cat([wq, wk], 0), dt)       # [1024, 256]
                 d["wv"] = ops.pack_linear(wv, dt)                            # A operand of the V^T GEMM
             else:
-                d["wqkv"] = ops.pack_linear(torch.cat([wq, wk, wv], 0), dt)
+                d["wqkv"] = ops.pack_linear(torch.cat([wq, wk, wv], 0), self.pdt)
             return d
 
         self.resnets, mlp_w, mlp_b = [], [], []
@@ -278,7 +286,7 @@ class FlowEngine:
         self.fin_w, self.fin_b = cv(q + ".final_block.block.0.weight"), f(q + ".final_block.block.0.bias")
         self.fin_g, self.fin_be = f(q + ".final_block.block.2.weight"), f(q + ".final_block.block.2.bias")
         self.proj_w, self.proj_b = cv(q + ".final_proj.weight"), f(q + ".final_proj.bias")
-        self.mlp_w = ops.pack_linear(torch.cat(mlp_w, 0), dt)                # [14*256, 1024]
+        self.mlp_w = ops.pack_linear(torch.cat(mlp_w, 0), self.pdt)          # [14*256, 1024]
         self.mlp_b = torch.cat(mlp_b, 0).contiguous()
         self.C = sd[q + ".final_proj.weight"].shape[1]
 

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, is_split
+from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, X3, X3W, is_split
 from .flow import Graphed
 
 ST_POS, ST_STEP, ST_NOUT, ST_FIN, ST_MINLEN, ST_MAXLEN, ST_SEQ, ST_ERR = range(8)
@@ -55,8 +55,15 @@ class LlmEngine:
 
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
-                 prefix="llm.model.model", share_from=None, kv_pages=None):
+                 prefix="llm.model.model", share_from=None, kv_pages=None, wplanes=False):
+        """wplanes (split build X3 only): every projection weight is carried as THREE bf16 planes hi + mid + lo = the checkpoint's
+        fp32 value (MMX_X3W: csrc/decode.hip for the decode step, csrc/gemm.hip for the prompt pass) instead of being rounded to
+        bf16 - for checkpoints whose weights are not bf16-representable (the reference loads an fp32 llm.pt, cli/model.py:67-75).
+        Costs 3 x the weight bytes and 2 x the MFMAs of the plain split build."""
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
+        self.wplanes = (bool(wplanes) and dtype == X3) if share_from is None else share_from.wplanes
+        if self.wplanes:                                  # three weight planes in registers: one output tile per workgroup
+            self.v2_cfg = dict(qkv=(1, 1), o=(1, 1), gu=(1, 1), down=(1, 8), head=(1, 1))
         self.split = is_split(dtype)                      # bf16 weights, fp32 activations split inside the MFMA products
         self.Hq, self.Hkv, self.D, self.eps = heads, kv_heads, head_dim, eps
         self.page, self.use_graphs = page, use_graphs
@@ -76,7 +83,9 @@ class LlmEngine:
             self._alloc_state()
             return
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
-        c = lambda t: t.to(WEIGHT_DT[dtype]).contiguous()
+        c = (lambda t: t.float().contiguous()) if self.wplanes else (lambda t: t.to(WEIGHT_DT[dtype]).contiguous())
+        if self.wplanes:
+            dt = X3W                                      # the code the weights are packed for (ops.Planed packs)
         # The RMSNorm gain is folded into the packed weights only in the fp32 build.  The bf16 and split builds keep the
         # checkpoint's bf16 weights as they are and apply the gain to the activations: in the producer's epilogue on the
         # decode step (csrc/decode.hip), in the kernel for prompt chunks (kgamma).
@@ -92,7 +101,7 @@ class LlmEngine:
             wqkv = torch.cat([f(a + ".q_proj.weight"), f(a + ".k_proj.weight"), f(a + ".v_proj.weight")], 0)
             bqkv = torch.cat([f(a + ".q_proj.bias"), f(a + ".k_proj.bias"), f(a + ".v_proj.bias")], 0).contiguous()
             wgu = torch.cat([f(p + ".mlp.gate_proj.weight"), f(p + ".mlp.up_proj.weight")], 0)
-            if max_batch >= 4:
+            if max_batch >= 4 or self.wplanes:
                 # row-major copies for the batched prompt pass (_prefill_batch): many prompts at once are an ordinary
                 # tall GEMM over weights read once, not max_batch passes of the weight-streaming decode kernels
                 self.pf_layers.append(dict(
@@ -361,6 +370,9 @@ class LlmEngine:
         self.release(slot)
         self._set_pages(slot, L + (max_len if ahead is None else min(ahead, max_len)))
         x = x.to(self.dev, torch.float32).contiguous()
+        if self.wplanes:
+            raise NotImplementedError("admit() with weight planes: the prompt chunks run on the round-2 projection kernel, which has no "
+                                      "weight-plane form; start() (the windowed-GEMM prompt pass) does")
         for c0 in range(0, L - 1, 64):
             self._prefill_chunk(x[c0:min(L - 1, c0 + 64)], c0, slot)
         self.x_in[slot].copy_(x[L - 1])
@@ -392,7 +404,7 @@ class LlmEngine:
             assert x.shape[0] + max_lens[b] <= self.max_pages * self.page, "sequence exceeds the KV cache"
             self.release(b)
             self._set_pages(b, x.shape[0] + min(max_lens[b], self.reserve_ahead))
-        if B >= 4 and self.pf_layers:
+        if (B >= 4 or self.wplanes) and self.pf_layers:
             self._prefill_batch(lm_inputs)
             lm_inputs = []
         for b, x in enumerate(lm_inputs):

@@ -17,12 +17,35 @@ def round_up(x, m):
 
 
 # ----------------------------------------------------------------------------- weight packing (load time)
-def pack_linear(w: torch.Tensor, dtype) -> torch.Tensor:
-    """[N, K] -> [N, Kpad] (K contiguous, zero padded to a multiple of 32) in the compute dtype."""
-    N, K = w.shape
-    out = torch.zeros(N, round_up(K, 32), dtype=L.WEIGHT_DT[dtype], device=w.device)
-    out[:, :K] = w
+class Planed(torch.Tensor):
+    """A packed weight held as bf16 PLANES hi + [mid +] lo = w of an fp32 checkpoint's values (include/mmx_hip.h MMX_X2W / MMX_X3W).
+    The type is the marker: gemm() / skinny2() switch to the weight-plane dtype code when they are handed one; views and row
+    slices keep the type (torch's default __torch_function__)."""
+
+
+def weight_planes(w: torch.Tensor, n: int):
+    """fp32 -> n bf16 terms, round to nearest each: hi = bf16(w), mid = bf16(w - hi), ... (the remainders are exact in fp32)."""
+    out, r = [], w.float()
+    for _ in range(n):
+        t = r.to(torch.bfloat16)
+        out.append(t)
+        r = r - t.float()
     return out
+
+
+def pack_linear(w: torch.Tensor, dtype) -> torch.Tensor:
+    """[N, K] -> [N, Kpad] (K contiguous, zero padded to a multiple of 32) in the compute dtype.
+    dtype X2W / X3W: w fp32 -> Planed [N, planes * Kpad], the planes side by side in every row."""
+    N, K = w.shape
+    Kp = round_up(K, 32)
+    planes = L.WPLANES.get(dtype, 1)
+    out = torch.zeros(N, planes * Kp, dtype=L.WEIGHT_DT[dtype], device=w.device)
+    if planes == 1:
+        out[:, :K] = w
+        return out
+    for i, t in enumerate(weight_planes(w, planes)):
+        out[:, i * Kp:i * Kp + K] = t
+    return out.as_subclass(Planed)
 
 
 def pack_conv1d(w: torch.Tensor, dtype) -> torch.Tensor:
@@ -58,6 +81,10 @@ def gemm(A, W, M, N, *, dtype, lda=None, cin=None, ntaps=1, dil=1, row_off=0, ro
     """Launches mmx_gemm_win. A/W/out_* may be tensors or raw device addresses (ints)."""
     ldw = W.shape[-1] if hasattr(W, "shape") else None
     assert ldw is not None
+    if isinstance(W, Planed):                            # weight planes of an fp32 checkpoint
+        dtype = {L.X2: L.X2W, L.X3: L.X3W, L.X2W: L.X2W, L.X3W: L.X3W}[dtype]
+    elif dtype in L.WPLANES:
+        raise L.MmxError("a weight-plane dtype needs a Planed weight (ops.pack_linear with X2W / X3W)")
     p = L.gemm_params(A=A, W=W, bias=bias, residual=residual, rowmask=rowmask, alpha=alpha, out_f32=out_f32,
                       out_act=out_act, lda=lda, ldw=ldw, ldr=ldr, ldo_f=ldo_f, ldo_a=ldo_a,
                       a_bstride=a_bstride, w_bstride=w_bstride, r_bstride=r_bstride, rm_bstride=rm_bstride,
@@ -271,8 +298,14 @@ def attn_flash_xs(qk, vt, out, *, B, H, T, ldqk, ldvt, ldo, qk_bs, vt_bs, o_bs, 
 
 # ----------------------------------------------------------------------------- LM decode
 def pack_skinny(w, *, dtype, kscale=None, interleave_half=0):
-    """w: [N, K] tensor in the weight dtype -> MFMA-fragment-ordered copy (see csrc/llm.hip)."""
+    """w: [N, K] tensor in the weight dtype -> MFMA-fragment-ordered copy (see csrc/llm.hip).
+    dtype X3W (mmx_skinny2 only): w fp32 -> the packs of its three bf16 planes one after the other (Planed)."""
     N, K = w.shape
+    if dtype in L.WPLANES:
+        assert w.dtype == torch.float32 and kscale is None
+        base = {L.X2W: L.X2, L.X3W: L.X3}[dtype]
+        return torch.cat([pack_skinny(t.contiguous(), dtype=base, interleave_half=interleave_half)
+                          for t in weight_planes(w, L.WPLANES[dtype])]).as_subclass(Planed)
     assert w.dtype == L.WEIGHT_DT[dtype]
     KB = 32 if L.WEIGHT_DT[dtype] == torch.bfloat16 else 16
     tiles = (N + 15) // 16
@@ -350,6 +383,8 @@ def decode_prep(x, xs, ssq, *, B, K, gamma=None, h=None, dtype=L.X3):
 def skinny2(xs, wp, *, B, K, N, dtype, bias=None, ssq_in=None, eps=1e-6, epi=0, out=None, ldo=None, xs_out=None, gamma_next=None,
             ssq_out=None, tiles_per_wg=1, ksplit=1, part=None, tickets=None):
     """The split build's decode-step projection on split-plane activations (include/mmx_hip.h mmx_skinny2)."""
+    if isinstance(wp, Planed):
+        dtype = L.X3W
     check(load().mmx_skinny2(_p(xs), B, K, N, _p(wp), _p(bias), _p(ssq_in), C.c_float(eps), epi, _p(out),
                              i64(ldo if ldo is not None else N), _p(xs_out), _p(gamma_next), _p(ssq_out), tiles_per_wg, ksplit,
                              _p(part), i64(part.numel() if part is not None else 0), _p(tickets), dtype, stream()), "mmx_skinny2")

@@ -32,21 +32,29 @@ def fade_in_out(fade_in, fade_out, window):
 
 class TtsEngine:
     def __init__(self, llm_sd, flow_sd, dac_sd, dtype=BF16, device="cuda", max_batch=1, max_ctx=2048,
-                 dac_rates=(5, 4, 4, 3, 2), use_graphs=True, attn="bf16"):
+                 dac_rates=(5, 4, 4, 3, 2), use_graphs=True, attn="bf16", wplanes=False):
+        """wplanes (split build only): the weight-plane mode for checkpoints whose weights are NOT bf16-representable - what the
+        reference's loaders hand over (fp32 llm.pt / flow.pt, cli/model.py:67-75; trained weight norms, dac-vae/inference.py:42-46).
+        Every GEMM weight is carried as bf16 planes of its fp32 value (3 in the LM, 2 in the flow and the DAC: include/mmx_hip.h
+        MMX_X3W / MMX_X2W) and the products keep every term above the last kept bit, so ids identical / waveform <= 1e-3 hold on
+        such checkpoints too (tests/test_gpu_split.py::test_weight_planes_*).  The flow and the DAC then run one launch per
+        Linear / Conv1d (the weight-plane products live in the windowed GEMM, not yet in the fused row-tile kernels)."""
         self.dtype, self.dev = dtype, torch.device(device)
+        self.wplanes = bool(wplanes) and is_split(dtype)
         if self.dev.type == "cuda" and self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())
         device = self.dev
         # the split build: the flow and the DAC keep 16 significant bits of every activation (X2: waveform error ~1e-4),
         # the LM 24 (X3): its sampler turns a log-prob error into a different token id, and the AR loop feeds that back
         ldt = X3 if is_split(dtype) else dtype
-        self.llm = LlmEngine(llm_sd, dtype=ldt, device=device, max_batch=max_batch, max_ctx=max_ctx, use_graphs=use_graphs)
+        self.llm = LlmEngine(llm_sd, dtype=ldt, device=device, max_batch=max_batch, max_ctx=max_ctx, use_graphs=use_graphs,
+                             wplanes=self.wplanes)
         # the decode step costs ~40 % more at 17..32 rows than at <= 16 (two MFMA row tiles): once at most 16
         # sequences are still running the batch continues in a 16-slot engine over the same weights and KV pages
         self.llm_small = (LlmEngine(None, dtype=ldt, device=device, max_batch=16, max_ctx=max_ctx, use_graphs=use_graphs,
                                     share_from=self.llm) if max_batch > 16 else None)
-        self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs, attn=attn)
-        self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device)
+        self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs, attn=attn, wplanes=self.wplanes)
+        self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device, wplanes=self.wplanes)
         self.hop = self.dac.hop
 
     # auxiliary streams per flow group for its per-utterance stages (conformer encoder, DAC decode); 1 = off.  Off by default:
@@ -170,6 +178,7 @@ class TtsEngine:
         their new frames (FlowEngine.StreamState); cache=False recomputes all frames at every hop, as the reference does."""
         from .llm import ST_FIN, ST_NOUT
         assert self.llm.B == 1
+        cache = cache and not self.wplanes                  # the cached hops run on the fused kernels (no weight-plane form yet)
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
         pt = prompt_text if prompt_text is not None else z

@@ -12,8 +12,9 @@ from ._lib import BF16, F32, TORCH_DT
 
 
 class SpeakerEncoderEngine:
-    def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", prefix="speaker_encoder", heads=8):
+    def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", prefix="speaker_encoder", heads=8, pack_dtype=None):
         self.dtype, self.tdt, self.dev, self.heads = dtype, TORCH_DT[dtype], torch.device(device), heads
+        dtype = dtype if pack_dtype is None else pack_dtype     # the code the weights are packed for (X2W: weight planes)
         f = lambda k: sd[k].detach().to(self.dev, torch.float32).contiguous()
         self.w_init, self.b_init = ops.pack_conv1d(f(prefix + ".init.weight"), dtype), f(prefix + ".init.bias")
         self.C = sd[prefix + ".init.weight"].shape[0]

@@ -495,3 +495,102 @@ def test_split_build_on_an_fp32_checkpoint_measured(case_fp32):
           f"(first divergence at step {first}); teacher forced {agree * 100:.1f} % of the draws equal; same-ids waveform max abs err "
           f"{err:.3e}, SNR {snr:.1f} dB")
     assert agree >= TP.BF16_MIN_TF_AGREEMENT and snr >= TP.BF16_MIN_SNR_DB, (agree, snr)
+
+
+# ------------------------------------------------------------------------------------------------ weight planes (fp32 checkpoints)
+def test_weight_planes_gemm_vs_float64():
+    """mmx_gemm_win with MMX_X2W / MMX_X3W: GENERAL fp32 weights as 2 / 3 bf16 planes, every term above the last kept bit
+    (3 / 6 MFMAs per fragment pair) against float64 on the same values.  Bounds as for bf16-exact weights: 2^-17 per operand
+    (X2W: 4e-5 of the output range stated, half of it expected), fp32 level (X3W).  The plain X2 / X3 codes on the same weights
+    ROUND them to bf16: their error (printed) is the 2^-9 the weight planes remove.  Also a 3-tap dilated conv (windowed rows)."""
+    from mmx import ops
+    from mmx._lib import X2W, X3W
+    g = torch.Generator().manual_seed(15)
+    M, N, K = 300, 200, 1000                              # ragged tiles, K padded to 1024 inside every plane
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    ref = x.double() @ w.double().t()
+    errs = {}
+    for name, dt, pdt in (("X2", X2, X2), ("X3", X3, X3), ("X2W", X2, X2W), ("X3W", X3, X3W)):
+        out = torch.zeros(M, N, device="cuda")
+        wp = ops.pack_linear(w, pdt)
+        assert isinstance(wp, ops.Planed) == (pdt in (X2W, X3W)) and wp.shape == (N, 1024 * (1 if pdt in (X2, X3) else (2 if pdt == X2W else 3)))
+        ops.linear(x, wp, K, dtype=dt, out_f32=out)
+        errs[name] = rel_err(out, ref)
+    print("gemm on general fp32 weights vs float64: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert errs["X2W"] < 4e-5 and errs["X3W"] < 3e-6 and errs["X2"] > 20 * errs["X2W"]
+    B, T, C = 2, 77, 96
+    xc = torch.randn(B, T, C, generator=g).cuda()
+    wc = (torch.randn(64, C, 3, generator=g) / math.sqrt(3 * C)).cuda()
+    bias = torch.randn(64, generator=g).cuda()
+    want = F.conv1d(F.pad(xc.double().transpose(1, 2), (2, 2)), wc.double(), bias.double(), dilation=2).transpose(1, 2)
+    out = torch.zeros(B, T, 64, device="cuda")
+    ops.conv1d(xc, ops.pack_conv1d(wc, X2W), T=T, Cin=C, k=3, dil=2, pad_left=2, dtype=X2, batch=B, bias=bias, out_f32=out)
+    assert rel_err(out, want) < 4e-5
+
+
+@pytest.mark.parametrize("B,K,N,epi,rs,J", [(1, 896, 1152, 0, True, 1), (32, 896, 1152, 0, True, 1), (17, 896, 896, 2, False, 1),
+                                            (32, 896, 4864, 1, True, 1), (32, 4864, 896, 2, False, 8), (3, 4864, 896, 2, False, 8),
+                                            (16, 896, 6564, 0, True, 1)])
+def test_weight_planes_skinny2_vs_float64(B, K, N, epi, rs, J):
+    """The decode-step projection with MMX_X3W: general fp32 weights as three bf16 planes, six MFMAs per fragment, against
+    float64 on the same values - fp32 level, as for bf16-exact weights (test_skinny2_vs_float64)."""
+    from mmx import ops
+    from mmx._lib import X3W
+    g = torch.Generator().manual_seed(B * 31 + N + J)
+    x = (torch.randn(B, K, generator=g) * 3).cuda()
+    w = (torch.randn((2 * N if epi == 1 else N), K, generator=g) / math.sqrt(K)).cuda()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).cuda() if rs else None
+    bias = torch.randn(N, generator=g).cuda() if epi == 0 else None
+    wp = ops.pack_skinny(w.contiguous(), dtype=X3W, interleave_half=(N if epi == 1 else 0))
+    assert isinstance(wp, ops.Planed)
+    xg = x * gam if rs else x
+    xs = ops.split_planes(xg)
+    ssq = _ssq_table(x) if rs else None
+    acc = xg.double() @ w.double().t()
+    if rs:
+        acc = acc * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-6)
+    res = torch.randn(B, N, generator=g).cuda()
+    ref = acc + bias.double() if epi == 0 else (F.silu(acc[:, :N]) * acc[:, N:] if epi == 1 else res.double() + acc)
+    nt = (N + 15) // 16
+    part = torch.full((J * nt * ops.packed_rows(B) // 4 * 64,), float("nan"), device="cuda") if J > 1 else None
+    tickets = torch.zeros(nt, dtype=torch.int32, device="cuda") if J > 1 else None
+    out = res.clone() if epi == 2 else (torch.full((B, N), float("nan"), device="cuda") if epi == 0 else None)
+    xs_out = torch.zeros(3, ops.plane_elems(B, N), dtype=torch.bfloat16, device="cuda") if epi != 0 and N % 32 == 0 else None
+    ops.skinny2(xs, wp, B=B, K=K, N=N, dtype=X3, bias=bias, ssq_in=ssq, eps=1e-6, epi=epi, out=out, xs_out=xs_out,
+                ssq_out=(torch.zeros(32, 64, device="cuda") if epi == 2 else None), tiles_per_wg=1, ksplit=J, part=part, tickets=tickets)
+    got = ops.merge_planes(xs_out, B, N) if epi == 1 else out
+    assert rel_err(got, ref) < 3e-6, rel_err(got, ref)
+
+
+def test_weight_planes_dac_trained_weight_norm_vs_reference_golden(golden_dir):
+    """The DAC decoder on a trained-like weight norm (dac80_fp32.npz, folded weights that are general fp32 values) in the
+    weight-plane mode: the split build's own bound for bf16-exact weights (2.5e-4), where rounding the weights gave 1.8e-2."""
+    from mmx.dac import DacDecoderEngine
+    from oracle import weights as W
+    sd = W.synth_state_dict(W.load_manifest(os.path.join(golden_dir, "manifest_dac80.json")), SEED, kind="fp32")
+    g = np.load(os.path.join(golden_dir, "dac80_fp32.npz"))
+    eng = DacDecoderEngine(sd, [5, 4, 4, 3, 2], dtype=X2, wplanes=True)
+    for T in (8, 50):
+        wav = eng.decode(torch.from_numpy(g[f"z_T{T}"]).cuda()).cpu()
+        err = (wav - torch.from_numpy(g[f"wav_T{T}"])).abs().max().item()
+        print(f"DAC on a trained-like weight norm, weight planes, T={T}: max abs err {err:.3e}")
+        assert err < 2.5e-4, (T, err)
+
+
+def test_weight_planes_composed_pipeline_on_an_fp32_checkpoint(case_fp32):
+    """The north star on a checkpoint whose weights are NOT bf16-representable (general fp32 LM / flow weights, trained-like DAC
+    weight norms): TtsEngine(dtype=split, wplanes=True) at config-3 size, free running, against the oracle on the same
+    unrounded weights - the same 250 ids, the waveform within 1e-3."""
+    import test_gpu_pipeline as TP
+    from mmx.pipeline import TtsEngine
+    case = case_fp32
+    eng = TtsEngine(case["llm_sd"], case["flow_sd"], case["dac_sd"], dtype=X2, max_batch=1, max_ctx=640, wplanes=True)
+    for rep in range(2):
+        wav = eng.tts(case["text"].cuda(), case["emb"].cuda(), seed=TP.SEED, exact_steps=TP.N_STEPS)
+        got = eng.llm.tokens()[0]
+        assert got == case["toks"], ("token ids differ from the oracle", rep, next(i for i, (a, b) in enumerate(zip(got, case["toks"])) if a != b))
+        err = (wav.cpu() - case["wav"]).abs().max().item()
+        print(f"weight planes, fp32 checkpoint, composed: {len(got)} ids identical, waveform max abs err {err:.3e} "
+              f"(SNR {TP._snr_db(case['wav'], wav.cpu()):.1f} dB)")
+        assert wav.shape == case["wav"].shape and err <= 1e-3, err
