@@ -12,6 +12,7 @@
 // distinct 16-byte bank slots, and the tile needs no pad columns (hi + lo planes of K, V^T and P: 96 KB at MF = 2).
 #include "common.h"
 #include "../../include/mmx_hip.h"
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -393,6 +394,17 @@ extern "C" int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, co
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
     const bf16_t* q = (const bf16_t*)qk;
+    if constexpr (LAB) {                               // lab build only: MMX_LAB_FLASHX=mf2 -> 8 waves x 32 queries (256 per workgroup)
+        const char* e = getenv("MMX_LAB_FLASHX");
+        if (e && e[0] == 'm' && !small) {
+            const int nq2 = (Tq + 255) / 256;
+            dim3 grid2(8 * ((npairs + 7) / 8) * nq2);
+            return launch_flash_x<2, true, 8>(grid2, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq2, H, npairs, q_begin, klen);
+        }
+        if (e && e[0] == 'w' && !small) {              // MMX_LAB_FLASHX=w4: 4 waves x 32 queries (128 per workgroup, one wave per SIMD)
+            return launch_flash_x<2, true, 4>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
+        }
+    }
     if (small) return launch_flash_x<1, true, 4>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     return launch_flash_x<1, true, 8>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
 }

@@ -156,6 +156,22 @@ __device__ __forceinline__ void stage_run(WRing<T, RW, PF>& ring, const char* a_
     group(nk - PF, std::true_type{});
 }
 
+// Weight planes (MMX_X2W: the weights of an fp32 checkpoint as bf16 hi + lo, the two packs one after the other, `wlo` elements
+// apart): a stage runs TWICE - the hi pack against both activation planes, then the lo pack against the activation's hi plane
+// (NS = 1 over plane 0) - into the same accumulator: hi*hi + lo_a*hi_w + hi_a*lo_w, three MFMAs per fragment pair; the term
+// dropped (lo*lo) is below the last kept bit of either operand.  The ring chains hi -> lo -> the next stage's hi.
+template <typename T, int MF, int NF, int PF, int NS, int RW, bool WP>
+__device__ __forceinline__ void stage_run_w(WRing<T, RW, PF>& ring, const char* a_lane, int pitch, int cin_steps,
+                                            const T* wb, long ns, int nk, long wlo, const T* wbn, long nsn, int nkn, int nfn,
+                                            float4_t (&acc)[MF][NF], int plane = 0, int tap_pitch = 0) {
+    if constexpr (!WP) {
+        stage_run<T, MF, NF, PF, NS, RW>(ring, a_lane, pitch, cin_steps, wb, ns, nk, wbn, nsn, nkn, nfn, acc, plane, tap_pitch);
+    } else {
+        stage_run<T, MF, NF, PF, NS, RW>(ring, a_lane, pitch, cin_steps, wb, ns, nk, wb + wlo, ns, nk, NF, acc, plane, tap_pitch);
+        stage_run<T, MF, NF, PF, 1, RW>(ring, a_lane, pitch, cin_steps, wb + wlo, ns, nk, wbn, nsn, nkn, nfn, acc, 0, tap_pitch);
+    }
+}
+
 template <int MF, int NF>
 __device__ __forceinline__ void zero_acc(float4_t (&acc)[MF][NF]) {
 #pragma unroll
@@ -376,7 +392,7 @@ __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lan
 }
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
-template <typename T, int MF, int PF, int NW, int NS = 1, int PW = 4>
+template <typename T, int MF, int PF, int NW, int NS = 1, int PW = 4, bool WP = false>
 __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n1g)[64 / NW], const float (&n1b)[64 / NW],
                                        const MmxEstNext& nx, float eps, char* a1, float* patch, float* stats,
                                        WRing<T, PW, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0,
@@ -406,7 +422,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
         float4_t acc[MF][PW];
         zero_acc(acc);
         const T* wn = p + 1 < NP ? qkv_pass<T, NW, PW>(nx.wqkv, wave, lane, p + 1) : nullptr;
-        stage_run<T, MF, PW, PF, NS, PW>(ring, a_lane, P1, NK, qkv_pass<T, NW, PW>(nx.wqkv, wave, lane, p), ns, NK, wn, ns, NK, PW, acc, plane);
+        stage_run_w<T, MF, PW, PF, NS, PW, WP>(ring, a_lane, P1, NK, qkv_pass<T, NW, PW>(nx.wqkv, wave, lane, p), ns, NK, 1536L * C, wn, ns, NK, PW, acc, plane);
         TSTAMP(33 + 2 * p);
         const int kind = p / PPK, cw = (wave * PPK + p % PPK) * PC;     // PC columns at cw inside the 512-wide Q / K / V
         if (vt_path && kind == 2) {
@@ -492,14 +508,17 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 // spilling (the 64-column-pass version spilled 400 bytes per lane), with a ring 4 k-steps deep: 8 waves x 8 KB of weight
 // fragments in flight per CU instead of 4 x 8 KB.  At depth 2 a fragment is requested two k-steps (0.25 us of MFMAs) before
 // its use, less than an L2 hit takes, so the one-wave-per-SIMD kernel waits in every k-step (tools/tail_lab.py --stamps).
-template <typename T, int BM, int PF, int NW, int NS, int PW>
+template <typename T, int BM, int PF, int NW, int NS, int PW, bool WP = false>
 __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const int tile) {
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PC = 16 * PW, PPC = CH / (PC * NW);
     static_assert(NFN <= PW, "the ring is PW fragments wide");
     constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
     constexpr int PL0 = BM * P0, PL1 = BM * P1;        // bytes between the planes of a tile (split build)
-    constexpr bool PRECISE = sizeof(T) == 4 || NS > 1;
+    // GELU: the fp32 build takes libm's erff; the split build erf_fast (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 absolute -
+    // two orders below the 2^-17 its products keep; erff was 3.96 us of every FF1 epilogue, 15 % of the kernel:
+    // profiles/r04_tail_stamps_x.txt); the bf16 build the degree-17 polynomial
+    constexpr bool PRECISE = sizeof(T) == 4;
     constexpr bool PARK = PW == 2;
     typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -576,7 +595,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         TSTAMP(2);
         float4_t acc[MF][NFN];
         zero_acc(acc);
-        stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, w1_pass(0), ns1, NK1, PW, acc, PL0);
+        stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, (long)C * CI, w1_pass(0), ns1, NK1, PW, acc, PL0);
         TSTAMP(3);
         float bo[CW];
         loadn<CW>(prm + PRM_BO + col0, bo);
@@ -625,8 +644,8 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             zero_acc(acc);
             const bool more = h + 1 < PPC;
             const T* wn = more ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
-            stage_run<T, MF, PW, PF, NS, PW>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, wn, more ? ns1 : ns2,
-                                             more ? NK1 : NK2, more ? PW : NFN, acc, PL1);
+            stage_run_w<T, MF, PW, PF, NS, PW, WP>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, (long)CF * C, wn, more ? ns1 : ns2,
+                                                   more ? NK1 : NK2, more ? PW : NFN, acc, PL1);
             TSTAMP(6 + ch * 12 + h * 2);
             float b1[4 * PW];
             loadn<4 * PW>(prm + PRM_B1 + ch * CH + hc, b1);
@@ -635,7 +654,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
                 float v[4 * PW];
                 to_rows<PW>(acc[i], patch, lane, v);
 #pragma unroll
-                for (int c = 0; c < 4 * PW; ++c) v[c] = act_c<(PRECISE ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
+                for (int c = 0; c < 4 * PW; ++c) v[c] = act_c<((PRECISE || NS > 1) ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
                 store_tile<T, NS, 4 * PW>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
             }
             TSTAMP(7 + ch * 12 + h * 2);
@@ -654,7 +673,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             }
         }
         const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW, PW>(p.next.wqkv, wave, lane, 0) : nullptr);
-        stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, wn, ns1, NK1, PW, acc2, PL0);
+        stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, (long)C * CF, wn, ns1, NK1, PW, acc2, PL0);
         TSTAMP(15 + ch * 12);
         __syncthreads();                               // every wave is done reading the chunk
         TSTAMP(16 + ch * 12);
@@ -683,7 +702,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         float n1g[CW], n1b[CW];
         loadn<CW>(prm + PRM_N1G + col0, n1g);
         loadn<CW>(prm + PRM_N1B + col0, n1b);
-        ln_qkv<T, MF, PF, NW, NS, PW>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
+        ln_qkv<T, MF, PF, NW, NS, PW, WP>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
     }
     TSTAMP(63);
 }
@@ -691,10 +710,11 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
 // TPW row tiles per workgroup, one after the other (compile-time: TPW = 1 is the plain kernel).  TPW = 2 halves the number of
 // workgroups of a launch at the same work: the flow groups that run beside the LM decode loop then leave more CUs to it
 // (tools/contention_lab.py: the decode step takes 1.6 x beside 160 resident workgroups of this kernel, 2.4 x beside 320).
-template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1, int PW = 4, int TPW = 1>
+template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1, int PW = 4, int TPW = 1, bool WP = false>
 __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams p) {
+    static_assert(!WP || TPW == 1, "weight planes: one tile per workgroup");
     if constexpr (TPW == 1) {
-        est_tail_tile<T, BM, PF, NW, NS, PW>(p, blockIdx.x);
+        est_tail_tile<T, BM, PF, NW, NS, PW, WP>(p, blockIdx.x);
     } else {
         const int ntiles = (p.T - p.t_begin + BM - 1) / BM;
         // (two inlined copies: as a rolled loop the compiler spilled 300 - 1700 bytes per lane)
@@ -710,13 +730,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int PF, int NW, int NS = 1>
+template <typename T, int BM, int PF, int NW, int NS = 1, bool WP = false>
 __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams p) {
     constexpr int MF = BM / 16, MH = MF + 1, E = FT<T>::E, KB = FT<T>::KB, C = 256;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16;
     constexpr int P1 = tile_pitch(C, sizeof(T));
     constexpr int PLH = (BM + 16) * P1;                // bytes between the planes of h1 (split build)
-    constexpr bool PRECISE = sizeof(T) == 4 || NS > 1;
+    constexpr bool PRECISE = sizeof(T) == 4;           // Mish through expf (fp32 build) or v_exp_f32 (1e-6 relative: bf16 and split builds)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cin = p.cin;
     const int PA = tile_pitch(cin, sizeof(T));
@@ -762,7 +782,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
     {
         float4_t acc[MH][NFN];
         zero_acc(acc);
-        stage_run<T, MH, NFN, PF, NS>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, w2_w, ns2, nk2, NFN, acc, PLA);
+        stage_run_w<T, MH, NFN, PF, NS, 4, WP>(ring, ain + l16 * PA + g * 16, PA, cs, w1_w, ns1, nk1, (long)C * 3 * cin, w2_w, ns2, nk2, NFN, acc, PLA);
         float hv[MH][CW];
 #pragma unroll
         for (int i = 0; i < MH; ++i) {
@@ -795,7 +815,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
     {
         float4_t acc[MF][NFN];
         zero_acc(acc);
-        stage_run<T, MF, NFN, PF, NS>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, wr_w, nsr, nkr, NFN, acc, PLH);
+        stage_run_w<T, MF, NFN, PF, NS, 4, WP>(ring, h1 + (14 + l16) * P1 + g * 16, P1, C / KB, w2_w, ns2, nk2, (long)C * 3 * C, wr_w, nsr, nkr, NFN, acc, PLH);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             to_rows<NFN>(acc[i], patch, lane, h2[i]);
@@ -814,7 +834,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
         float4_t acc[MF][NFN];
         zero_acc(acc);
         const T* wq0 = p.next.wqkv ? qkv_pass<T, NW>(p.next.wqkv, wave, lane, 0) : nullptr;
-        stage_run<T, MF, NFN, PF, NS>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, wq0, (long)(C / KB) * 64 * E, C / KB, 4, acc, PLA);
+        stage_run_w<T, MF, NFN, PF, NS, 4, WP>(ring, ain + (18 + l16) * PA + g * 16, PA, cs, wr_w, nsr, nkr, (long)C * cin, wq0, (long)(C / KB) * 64 * E, C / KB, 4, acc, PLA);
         float* xw = p.x + (long)b * p.x_bs;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -827,7 +847,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
         }
     }
     __syncthreads();                                   // every wave is done with ain / h1 (h1 is reused by ln_qkv)
-    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS>(h2, gg, be, p.next, p.eps, h1, patch, stats, ring, b, t0, Tn, wave, lane, PLH);
+    if (p.next.wqkv) ln_qkv<T, MF, PF, NW, NS, 4, WP>(h2, gg, be, p.next, p.eps, h1, patch, stats, ring, b, t0, Tn, wave, lane, PLH);
 }
 
 
@@ -851,7 +871,7 @@ __global__ __launch_bounds__(64 * NW) void est_resnet_kernel(MmxEstResnetParams 
 __host__ __device__ constexpr int dac_pitch(int cp) { return (((cp * 2 + 31) / 32) | 1) * 32; }
 constexpr int DAC_PATCH_FLOATS = 16 * 52;              // per wave: 48 columns + 4
 
-template <int C, int BM, int WR, int WC, int NS, int PF>
+template <int C, int BM, int WR, int WC, int NS, int PF, bool WP = false>
 __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
     typedef bf16_t T;
     constexpr int E = 8, KB = 32, NF = 3, CP = (C + 31) / 32 * 32, PA = dac_pitch(CP);
@@ -949,7 +969,7 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
     {
         float4_t acc[MF][NF];
         zero_acc(acc);
-        stage_run<T, MF, NF, PF, NS, NF>(ring, ain + (wr * BMW + l16) * PA + g * 16, PA, CP / KB, w7_w, ns7, NK7, w1_w, ns1, NK1, NF, acc, PLA, d * PA);
+        stage_run_w<T, MF, NF, PF, NS, NF, WP>(ring, ain + (wr * BMW + l16) * PA + g * 16, PA, CP / KB, w7_w, ns7, NK7, (long)C * 7 * CP, w1_w, ns1, NK1, NF, acc, PLA, d * PA);
         // + bias -> LeakyReLU -> Snake(a2) -> mid (row layout through the wave's patch: 12 consecutive columns per lane)
         const int col = wc * 48 + (lane & 3) * 12;
         float b7[12], a2[12], i2[12];
@@ -999,7 +1019,7 @@ __global__ __launch_bounds__(256) void dac_ru_kernel(MmxDacRuParams p) {
     {
         float4_t acc[MF][NF];
         zero_acc(acc);
-        stage_run<T, MF, NF, PF, NS, NF>(ring, mid + (wr * BMW + l16) * PA + g * 16, PA, NK1, w1_w, ns1, NK1, (const T*)nullptr, 0, 0, NF, acc, PLM);
+        stage_run_w<T, MF, NF, PF, NS, NF, WP>(ring, mid + (wr * BMW + l16) * PA + g * 16, PA, NK1, w1_w, ns1, NK1, (long)C * CP, (const T*)nullptr, 0, 0, NF, acc, PLM);
         float b1[12], an[12], in[12];
         loadn<12>(prm + 3 * CP + col, b1);
         loadn<12>(prm + 4 * CP + col, an);
@@ -1093,6 +1113,8 @@ extern "C" int mmx_lab_tail_stamps(void* buf) {
 extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int cfg, hipStream_t stream) {
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstTailParams& p = *pp;
+    const bool wplanes = dtype == MMX_X2W;             // every packed weight (wo, w1, w2, next.wqkv) is [hi pack | lo pack]
+    if (wplanes) dtype = MMX_X2;
     MMX_CHECK_ARG(p.ao && p.x && p.wo && p.w1 && p.w2 && p.bo && p.b1 && p.b2 && p.n3g && p.n3b && p.B > 0 && p.T > 0);
     MMX_CHECK_ARG(p.t_begin >= 0 && p.t_begin < p.T && p.t_begin % 16 == 0);
     MMX_CHECK_ARG(p.ldao >= 512 && p.ldao % (dtype == MMX_X2 ? 4 : 8) == 0 && p.ao_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && p.x_bs % 4 == 0);
@@ -1100,12 +1122,12 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % (dtype == MMX_X2 ? 4 : 8) == 0 && p.act_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
     const int nw = (cfg >> 4) & 15, occ2 = (cfg >> 8) & 1;
-#define TAILT(TT, BM, PF, NW, NS, OCC, PW, TPW)                                                           \
+#define TAILT(TT, BM, PF, NW, NS, OCC, PW, TPW, ...)                                                      \
     do {                                                                                                   \
         const size_t lds = tail_lds<TT, BM, NW, NS>();                                                     \
         MMX_CHECK_ARG(lds * OCC <= 160 * 1024);                                                            \
-        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW>), lds);                          \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW>), dim3(((p.T - p.t_begin + BM - 1) / BM + TPW - 1) / TPW, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW __VA_OPT__(,) __VA_ARGS__>), lds); \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW __VA_OPT__(,) __VA_ARGS__>), dim3(((p.T - p.t_begin + BM - 1) / BM + TPW - 1) / TPW, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
 #define TAILP(TT, BM, PF, NW, NS, OCC, PW) TAILT(TT, BM, PF, NW, NS, OCC, PW, 1)
 #define TAILO(TT, BM, PF, NW, NS, OCC) TAILP(TT, BM, PF, NW, NS, OCC, 4)
@@ -1113,6 +1135,13 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
 #define TAIL(TT, BM, PF, NW) TAILN(TT, BM, PF, NW, 1)
     int narrow = (cfg >> 9) & 1;
     int pf = cfg & 15;
+    if (wplanes) {                                     // weight planes: the split build's default tiles, one tile per workgroup
+        if (bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 1, true);
+        else if (bm == 16) TAILT(bf16_t, 16, 4, 8, 2, 1, 4, 1, true);
+        else return MMX_EARG;
+        MMX_LAUNCH_CHECK();
+        return MMX_OK;
+    }
     if ((cfg >> 10) & 1) {                             // two row tiles per workgroup: the tile defaults of the two fast builds only
         if (dtype == MMX_BF16 && bm == 64) TAILT(bf16_t, 64, 2, 8, 1, 1, 2, 2);
         else if (dtype == MMX_BF16 && bm == 32) TAILT(bf16_t, 32, 8, 8, 1, 1, 2, 2);
@@ -1171,6 +1200,8 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
 extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, int cfg, hipStream_t stream) {
     MMX_CHECK_ARG(pp != nullptr);
     const MmxEstResnetParams& p = *pp;
+    const bool wplanes = dtype == MMX_X2W;             // every packed weight (w1, w2, wr, next.wqkv) is [hi pack | lo pack]
+    if (wplanes) dtype = MMX_X2;
     MMX_CHECK_ARG(p.a_in && p.x && p.w1 && p.w2 && p.wr && p.b1 && p.b2 && p.br && p.g1 && p.be1 && p.g2 && p.be2 && p.tv);
     MMX_CHECK_ARG(p.t_begin >= 0 && p.t_begin < p.T && p.t_begin % 16 == 0);
     MMX_CHECK_ARG(p.B > 0 && p.T > 0 && p.cin >= 64 && p.cin % 32 == 0 && p.cin <= 512 && p.lda >= p.cin);
@@ -1178,12 +1209,12 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
     MMX_CHECK_ARG(((uintptr_t)p.a_in % 16) == 0 && ((uintptr_t)p.x % 16) == 0 && p.x_bs % 4 == 0 && p.tv_bs % 4 == 0 && ((uintptr_t)p.tv % 16) == 0);
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
     const int pf_req = cfg & 15, nw = cfg >> 4;
-#define RESNN(TT, BM, PF, NW, NS)                                                                         \
+#define RESNN(TT, BM, PF, NW, NS, ...)                                                                    \
     do {                                                                                                   \
         const size_t lds = resnet_lds<TT, BM, NW, NS>(p.cin);                                              \
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        MMX_LDS_OPT_IN((est_resnet_kernel<TT, BM, PF, NW, NS>), lds);                                      \
-        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF, NW, NS>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_LDS_OPT_IN((est_resnet_kernel<TT, BM, PF, NW, NS __VA_OPT__(,) __VA_ARGS__>), lds);            \
+        hipLaunchKernelGGL((est_resnet_kernel<TT, BM, PF, NW, NS __VA_OPT__(,) __VA_ARGS__>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
 #define RESN(TT, BM, PF, NW) RESNN(TT, BM, PF, NW, 1)
     // ring depth: the deepest of 8 / 4 / 2 the tile height wants that divides every stage's k-step count
@@ -1197,9 +1228,11 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
         MMX_CHECK_ARG((p.cin / kb) % 2 == 0);
         if (bm == 32) {
             MMX_CHECK_ARG((resnet_lds<bf16_t, 32, 4, 2>(p.cin)) <= 160 * 1024);
-            if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2); else RESNN(bf16_t, 32, 2, 4, 2);
+            if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2, true); else RESNN(bf16_t, 32, 2, 4, 2, true); }
+            else if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2); else RESNN(bf16_t, 32, 2, 4, 2);
         } else if (bm == 16) {
-            if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2); else RESNN(bf16_t, 16, 2, 4, 2);
+            if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2, true); else RESNN(bf16_t, 16, 2, 4, 2, true); }
+            else if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2); else RESNN(bf16_t, 16, 2, 4, 2);
         } else return MMX_EARG;
         MMX_LAUNCH_CHECK();
         return MMX_OK;
@@ -1243,14 +1276,23 @@ extern "C" int mmx_dac_ru(const MmxDacRuParams* pp, int dtype, int bm, hipStream
     MMX_CHECK_ARG(p.dil >= 1 && p.dil <= 9 && (p.C == 48 || p.C == 96 || p.C == 192) && p.x_bs % 4 == 0 && p.x_bs >= (int64_t)p.T * p.C);
     MMX_CHECK_ARG(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.x_out % 16) == 0 && ((uintptr_t)p.act_out % 16) == 0 && ((uintptr_t)p.a0 % 16) == 0);
     MMX_CHECK_ARG(!p.act_out || p.alpha_next);
+    const bool wplanes = dtype == MMX_X2W;             // w7 / w1 are [hi pack | lo pack]
+    if (wplanes) dtype = MMX_X2;
     MMX_CHECK_ARG(dtype == MMX_BF16 || dtype == MMX_X2);
-#define DACRU(C_, BM_, WR_, WC_, NS_, PF_)                                                                 \
+#define DACRU(C_, BM_, WR_, WC_, NS_, PF_, ...)                                                            \
     do {                                                                                                   \
         const size_t lds = dac_ru_lds<C_, BM_, NS_>(p.dil);                                                \
         MMX_CHECK_ARG(lds <= 160 * 1024);                                                                  \
-        MMX_LDS_OPT_IN((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_>), lds);                                 \
-        hipLaunchKernelGGL((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_>), dim3((p.T + BM_ - 1) / BM_, p.B), dim3(256), lds, stream, p); \
+        MMX_LDS_OPT_IN((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_ __VA_OPT__(,) __VA_ARGS__>), lds);       \
+        hipLaunchKernelGGL((dac_ru_kernel<C_, BM_, WR_, WC_, NS_, PF_ __VA_OPT__(,) __VA_ARGS__>), dim3((p.T + BM_ - 1) / BM_, p.B), dim3(256), lds, stream, p); \
     } while (0)
+    if (wplanes) {                                     // weight planes: the split build's default tile per stage
+        if (p.C == 48) DACRU(48, 64, 4, 1, 2, 2, true);
+        else if (p.C == 96) { if (p.dil > 3) DACRU(96, 128, 2, 2, 2, 3, true); else DACRU(96, 64, 2, 2, 2, 3, true); }
+        else DACRU(192, 32, 1, 4, 2, 2, true);
+        MMX_LAUNCH_CHECK();
+        return MMX_OK;
+    }
     // tile heights: default = the measured best of tools/dac_lab.py for (C, dtype); smaller tiles let two workgroups share a
     // CU (LDS, 256 registers), which overlaps one's load / epilogue phases with the other's MFMA stages
     if (dtype == MMX_BF16) {

@@ -28,8 +28,7 @@ class DacDecoderEngine:
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.wplanes = bool(wplanes) and dtype == X2
         # the fused ResidualUnit kernel exists for the bf16 and split builds; the fp32 build keeps two GEMM launches per unit
-        # (and so does the weight-plane mode, which lives in the windowed GEMM)
-        self.fuse_ru = bool(fuse_ru) and dtype in (BF16, X2) and not self.wplanes
+        self.fuse_ru = bool(fuse_ru) and dtype in (BF16, X2)
         dtype = X2W if self.wplanes else dtype                         # `dtype` below: the code the weights are packed for
         self.rates = list(rates)
         self.hop = int(math.prod(rates))

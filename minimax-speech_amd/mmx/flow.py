@@ -124,13 +124,11 @@ class FlowEngine:
                  fused=None, attn="bf16", wplanes=False):
         """wplanes (split build only): every GEMM weight is carried as two bf16 planes hi + lo of the checkpoint's fp32 value
         (MMX_X2W, csrc/gemm.hip) instead of being rounded to bf16 - for checkpoints whose weights are not bf16-representable
-        (the reference loads fp32 flow.pt, cli/model.py:67-75).  The estimator then runs one launch per Linear / Conv1d
-        (fused=False): the weight-plane products live in the windowed GEMM."""
+        (the reference loads fp32 flow.pt, cli/model.py:67-75).  Three MFMAs per fragment pair (hi*hi + lo*hi + hi*lo) and twice
+        the weight stream, in the windowed GEMM and in the fused row-tile kernels alike."""
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.wplanes = bool(wplanes) and dtype == X2
         self.pdt = X2W if self.wplanes else dtype            # the code weights are packed for
-        if self.wplanes:
-            fused = False
         self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
         self.enc_chunk, self.est_chunk = enc_chunk, est_chunk
         self.use_graphs = use_graphs
@@ -246,7 +244,8 @@ class FlowEngine:
                      w2=lin(p + ".ff.net.2.weight"), b2=f(p + ".ff.net.2.bias"))
             wq, wk, wv = f(a + ".to_q.weight"), f(a + ".to_k.weight"), f(a + ".to_v.weight")
             if self.fused is not False:
-                pk = lambda w: ops.pack_skinny(w.to(WEIGHT_DT[dt]).contiguous(), dtype=dt)
+                pk = (lambda w: ops.pack_skinny(w.float().contiguous(), dtype=X2W)) if self.wplanes else \
+                     (lambda w: ops.pack_skinny(w.to(WEIGHT_DT[dt]).contiguous(), dtype=dt))
                 d.update(wo_p=pk(f(a + ".to_out.0.weight")), w1_p=pk(f(p + ".ff.net.0.proj.weight")),
                          w2_p=pk(f(p + ".ff.net.2.weight")), wqkv_p=pk(torch.cat([wq, wk, wv], 0)))
             if dt == BF16:
@@ -267,7 +266,8 @@ class FlowEngine:
                      g2=f(p + ".block2.block.2.weight"), be2=f(p + ".block2.block.2.bias"),
                      wr=cv(p + ".res_conv.weight"), br=f(p + ".res_conv.bias"))
             if self.fused is not False:
-                pc = lambda k: ops.pack_skinny(ops.pack_conv1d(f(k), dt), dtype=dt)
+                pc = (lambda k: ops.pack_skinny(ops.conv1d_matrix(f(k)).contiguous(), dtype=X2W)) if self.wplanes else \
+                     (lambda k: ops.pack_skinny(ops.pack_conv1d(f(k), dt), dtype=dt))
                 r.update(w1_p=pc(p + ".block1.block.0.weight"), w2_p=pc(p + ".block2.block.0.weight"), wr_p=pc(p + ".res_conv.weight"))
             mlp_w.append(f(p + ".mlp.1.weight"))
             mlp_b.append(f(p + ".mlp.1.bias"))

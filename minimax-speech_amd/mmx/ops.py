@@ -48,10 +48,15 @@ def pack_linear(w: torch.Tensor, dtype) -> torch.Tensor:
     return out.as_subclass(Planed)
 
 
+def conv1d_matrix(w: torch.Tensor) -> torch.Tensor:
+    """Conv1d weight [Cout, Cin, k] -> the GEMM's weight matrix [Cout, k*Cin] (tap-major, then channel), same dtype."""
+    Cout, Cin, k = w.shape
+    return w.permute(0, 2, 1).reshape(Cout, k * Cin)
+
+
 def pack_conv1d(w: torch.Tensor, dtype) -> torch.Tensor:
     """Conv1d weight [Cout, Cin, k] -> GEMM weight [Cout, k*Cin] (tap-major, then channel)."""
-    Cout, Cin, k = w.shape
-    return pack_linear(w.permute(0, 2, 1).reshape(Cout, k * Cin), dtype)
+    return pack_linear(conv1d_matrix(w), dtype)
 
 
 def pack_convtranspose1d(w: torch.Tensor, stride: int, dtype) -> torch.Tensor:
@@ -205,6 +210,8 @@ def est_tail(ao, x, w, *, B, T, dtype, bm, rowmask=None, act_out=None, act_ld=0,
                       x_bs=Tc * 256, rm_bs=Tc, act_bs=Tc * act_ld, ldao=512, act_ld=act_ld, B=B, T=T, t_begin=t_begin, eps=eps)
     if nxt is not None:
         p.next = nxt
+    if isinstance(w["wo_p"], Planed):                   # [hi pack | lo pack] weights (pack_skinny with X2W), the next block's too
+        dtype = L.X2W
     check(load().mmx_est_tail(C.byref(p), C.c_int(dtype), C.c_int(bm), C.c_int(pf + 16 * waves + (256 if occ2 else 0) + (512 if narrow else 0) + (1024 if tpw2 else 0)), stream()),
           "mmx_est_tail")
 
@@ -217,6 +224,8 @@ def est_resnet(a_in, lda, cin, x, r, tv, tv_bs, *, B, T, dtype, bm, rowmask=None
                       a_bs=Tc * lda, x_bs=Tc * 256, tv_bs=tv_bs, rm_bs=Tc, lda=lda, cin=cin, B=B, T=T, t_begin=t_begin, eps=eps)
     if nxt is not None:
         p.next = nxt
+    if isinstance(r["w1_p"], Planed):
+        dtype = L.X2W
     check(load().mmx_est_resnet(C.byref(p), C.c_int(dtype), C.c_int(bm), C.c_int(pf + 16 * waves), stream()), "mmx_est_resnet")
 
 
@@ -226,7 +235,7 @@ def pack_dac_ru(w7: torch.Tensor, w1: torch.Tensor, dtype):
     [C][7 * CP] tap-major with each tap's input channels zero-padded to CP = 32 * ceil(C / 32), and [C][CP]."""
     C_ = w7.shape[0]
     CP = (C_ + 31) // 32 * 32
-    wd = L.WEIGHT_DT[dtype]
+    wd = torch.float32 if dtype in L.WPLANES else L.WEIGHT_DT[dtype]     # weight planes: pack_skinny splits the fp32 values
     a = torch.zeros(C_, 7, CP, dtype=torch.float32, device=w7.device)
     a[:, :, :C_] = w7.permute(0, 2, 1)
     b = torch.zeros(C_, CP, dtype=torch.float32, device=w7.device)
@@ -239,6 +248,8 @@ def dac_ru(x, x_out, ru, *, B, T, C_, dil, dtype, act_out=None, alpha_next=None,
     p = L.fill_struct(L.DacRuParams(), x=x, x_out=x_out, act_out=act_out, w7=ru["w7_p"], w1=ru["w1_p"], b7=ru["b7"], b1=ru["b1"],
                       a0=ru["a0"], a2=ru["a2"], alpha_next=alpha_next, lens=lens, x_bs=(T * C_ if x_bs is None else x_bs),
                       B=B, T=T, C=C_, dil=dil, slope=slope)
+    if isinstance(ru["w7_p"], Planed):
+        dtype = L.X2W
     check(load().mmx_dac_ru(C.byref(p), C.c_int(dtype), C.c_int(bm), stream()), "mmx_dac_ru")
 
 

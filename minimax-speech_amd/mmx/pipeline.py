@@ -37,8 +37,7 @@ class TtsEngine:
         reference's loaders hand over (fp32 llm.pt / flow.pt, cli/model.py:67-75; trained weight norms, dac-vae/inference.py:42-46).
         Every GEMM weight is carried as bf16 planes of its fp32 value (3 in the LM, 2 in the flow and the DAC: include/mmx_hip.h
         MMX_X3W / MMX_X2W) and the products keep every term above the last kept bit, so ids identical / waveform <= 1e-3 hold on
-        such checkpoints too (tests/test_gpu_split.py::test_weight_planes_*).  The flow and the DAC then run one launch per
-        Linear / Conv1d (the weight-plane products live in the windowed GEMM, not yet in the fused row-tile kernels)."""
+        such checkpoints too (tests/test_gpu_split.py::test_weight_planes_*)."""
         self.dtype, self.dev = dtype, torch.device(device)
         self.wplanes = bool(wplanes) and is_split(dtype)
         if self.dev.type == "cuda" and self.dev.index is None:
@@ -178,7 +177,6 @@ class TtsEngine:
         their new frames (FlowEngine.StreamState); cache=False recomputes all frames at every hop, as the reference does."""
         from .llm import ST_FIN, ST_NOUT
         assert self.llm.B == 1
-        cache = cache and not self.wplanes                  # the cached hops run on the fused kernels (no weight-plane form yet)
         z = torch.zeros(1, 0, dtype=torch.long, device=self.dev)
         zf = torch.zeros(1, 0, 80, device=self.dev)
         pt = prompt_text if prompt_text is not None else z

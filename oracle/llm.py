@@ -165,10 +165,13 @@ def build_lm_input(sd, text, prompt_text, prompt_speech_token):
 def lm_inference(sd, cfg: QwenCfg, text, prompt_text, prompt_speech_token, seed: int = 0, seq: int = 0,
                  speech_token_size=6561, max_token_text_ratio=20, min_token_text_ratio=2,
                  forced: Optional[List[int]] = None, max_steps: Optional[int] = None,
-                 ignore_eos_always=False, record: Optional[list] = None) -> List[int]:
+                 ignore_eos_always=False, record: Optional[list] = None, unstable: Optional[list] = None,
+                 sampled_out: Optional[list] = None) -> List[int]:
     """Qwen2LM.inference + inference_wrapper; sampling noise = philox(seed, seq, step, trial).
     `forced`: teacher forcing — step i feeds forced[i] as the accepted token (ids are still sampled
-    and returned, so they can be compared step by step).  `record` collects per-step logp."""
+    and returned, so they can be compared step by step).  `record` collects per-step logp, `sampled_out` the id drawn at
+    every step (ids above EOS included), `unstable` the steps whose draw a 6e-5 log-prob perturbation can flip
+    (decision_unstable)."""
     lm_input = build_lm_input(sd, text, prompt_text, prompt_speech_token)
     tl = text.shape[1]
     min_len, max_len = int(tl * min_token_text_ratio), int(tl * max_token_text_ratio)
@@ -182,7 +185,12 @@ def lm_inference(sd, cfg: QwenCfg, text, prompt_text, prompt_speech_token, seed:
             record.append(logp.clone())
         top = sampling_ids_e(logp, out, lambda k, i=i: philox_noise(seed, seq, i, k),
                              ignore_eos=(ignore_eos_always or i < min_len), eos=speech_token_size)
+        if unstable is not None and decision_unstable(logp, out, lambda k, i=i: philox_noise(seed, seq, i, k),
+                                                      ignore_eos_always or i < min_len, speech_token_size):
+            unstable.append(i)
         sampled.append(top)
+        if sampled_out is not None:
+            sampled_out.append(top)
         if forced is not None:
             top = forced[i]
         if top == speech_token_size:
@@ -192,6 +200,49 @@ def lm_inference(sd, cfg: QwenCfg, text, prompt_text, prompt_speech_token, seed:
         out.append(top)
         lm_input = sd["speech_embedding.weight"][top].reshape(1, 1, -1)
     return sampled if forced is not None else out
+
+
+def decision_unstable(logp: torch.Tensor, decoded: List[int], noise_for_trial: Callable[[int], Callable], ignore_eos: bool, eos: int,
+                      tol: float = 6e-5, top_p=0.8, top_k=25) -> bool:
+    """Is the reference's draw at this step decided by a near-tie that a log-prob perturbation of `tol` can flip?  (Any two
+    fp32 implementations of the LM differ by ~1e-5 in log-prob - the reference on another BLAS included - so over a long
+    utterance such steps are where token ids can legitimately part.)  The reference's sampler (common.py:111-139) has three
+    kinds of decision: the ORDER of the stable descending sort (the multinomial noise e_i goes by sorted position, so
+    swapping two nearly equal candidates hands each the other's noise), the nucleus CUT (cum < top_p), and the RACES
+    argmax p_i / e_i (nucleus and, on repetition, full vocabulary).  Unstable = the sampled id changes when two adjacent
+    sorted candidates closer than tol swap their values, or the running sum passes top_p within tol, or a race's two
+    largest ratios are within 2 tol (relative)."""
+    base = sampling_ids_e(logp, decoded, noise_for_trial, ignore_eos, eos)
+    sv, si = logp.sort(descending=True, stable=True)
+    p = logp.softmax(0)
+    prob, idx = nucleus_candidates(logp, top_p, top_k)
+    n = prob.numel()
+    cum = torch.cumsum(p[si[:n + 1]], 0)
+    if min(abs(float(cum[n - 1]) - top_p), abs(float(cum[n - 2]) - top_p) if n > 1 else 1.0) < tol and n < top_k:
+        return True
+    for i in range(min(n, logp.numel() - 1)):            # adjacent pairs (i, i + 1) of the sorted prefix, boundary element included
+        if float(sv[i] - sv[i + 1]) < tol:
+            q = logp.clone()
+            q[si[i]], q[si[i + 1]] = logp[si[i + 1]], logp[si[i]]
+            if sampling_ids_e(q, decoded, noise_for_trial, ignore_eos, eos) != base:
+                return True
+    trial = 0
+    while True:                                           # the races of every trial the draw went through
+        noise = noise_for_trial(trial)
+        r = (prob / noise(0, n)).sort(descending=True)
+        if n > 1 and float((r.values[0] - r.values[1]) / r.values[0]) < 2 * tol:
+            return True
+        top = int(idx[r.indices[0]])
+        if sum(1 for t in decoded[-10:] if t == top) >= 1:
+            rr = (p / noise(1, p.numel())).sort(descending=True)
+            if float((rr.values[0] - rr.values[1]) / rr.values[0]) < 2 * tol:
+                return True
+            top = int(rr.indices[0])
+        if not ignore_eos or top != eos:
+            return False
+        trial += 1
+        if trial > 100:
+            return True
 
 
 def lm_inference_bistream(sd, cfg: QwenCfg, text_chunks, prompt_text, prompt_speech_token,

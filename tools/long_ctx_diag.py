@@ -30,12 +30,21 @@ with torch.no_grad():
     toks = OLLM.lm_inference(sd, OLLM.QwenCfg(), text, z, z, seed=SEED, seq=0, max_steps=N, ignore_eos_always=True, record=rec)
 print(f"oracle: {len(rec)} steps, {len(toks)} accepted ids", flush=True)
 # the sampled id of every step (ids above EOS are skipped, not accepted): re-run the sampler on the recorded log-probs
-out, sampled, margins, cutm = [], [], [], []
+out, sampled, margins, cutm, fallback = [], [], [], [], []
 for i, lp in enumerate(rec):
     prob, idx = OLLM.nucleus_candidates(lp)
     e = torch.from_numpy(exp_noise(SEED, 0, i, 0, 0, prob.numel()))
-    r = (prob / e).sort(descending=True).values
-    margins.append(float((r[0] - r[1]) / r[0]) if r.numel() > 1 else 1.0)
+    r = (prob / e).sort(descending=True)
+    m0 = float((r.values[0] - r.values[1]) / r.values[0]) if prob.numel() > 1 else 1.0
+    # the repetition-aware fallback (common.py:113-115): a full-vocabulary race decides the step; its margin is what counts there
+    nuc_top = int(idx[r.indices[0]])
+    fb = sum(1 for t in out[-10:] if t == nuc_top) >= 1
+    fallback.append(fb)
+    if fb:
+        p_all = lp.softmax(0)
+        rr = (p_all / torch.from_numpy(exp_noise(SEED, 0, i, 0, 1, p_all.numel()))).sort(descending=True).values
+        m0 = min(m0, float((rr[0] - rr[1]) / rr[0]))
+    margins.append(m0)
     sv = lp.softmax(0).sort(descending=True, stable=True).values
     cum = torch.cumsum(sv[:26], 0)
     k = prob.numel()
@@ -56,15 +65,16 @@ for name, dt in (("split X3", 3), ("fp32", 0)):
         eng.step()
         lps.append(eng.logp[0].cpu().clone())
     drawn = eng.sampled[0, :len(rec)].tolist()
-    d = []
+    d, dall = [], []
     for i, (a, b) in enumerate(zip(lps, rec)):
         _, idx = OLLM.nucleus_candidates(b)
         d.append(float((a[idx] - b[idx]).abs().max()))
-    res[name] = (d, drawn)
+        dall.append(float((a - b).abs().max()))
+    res[name] = (d, drawn, dall, lps)
     eng.close()
     del eng
     torch.cuda.empty_cache()
-for name, (d, drawn) in res.items():
+for name, (d, drawn, dall, lps) in res.items():
     t = torch.tensor(d)
     print(f"\n{name}: max |dlogp| over the oracle's nucleus candidates, teacher forced")
     for lo in range(0, len(d), 200):
@@ -72,8 +82,12 @@ for name, (d, drawn) in res.items():
         print(f"   steps {lo:4d}..{lo + len(seg) - 1:4d} (context {292 + lo}..): mean {seg.mean():.2e}  max {seg.max():.2e}")
     flips = [i for i, (a, b) in enumerate(zip(drawn, sampled)) if a != b]
     print(f"   draws that differ from the oracle's: {len(flips)} of {len(d)} at steps {flips[:10]}")
+    print(f"   max |dlogp| over ALL {len(rec[0])} ids, all steps: {max(dall):.2e}")
     for i in flips[:10]:
-        print(f"      step {i}: oracle race margin {margins[i]:.2e}, nucleus-cut margin {cutm[i]:.2e}, |dlogp| {d[i]:.2e}")
+        print(f"      step {i}: oracle drew {sampled[i]}, this build {drawn[i]}; fallback (full-vocabulary race) {fallback[i]}; smallest race margin "
+              f"{margins[i]:.2e}, nucleus-cut margin {cutm[i]:.2e}, |dlogp| candidates {d[i]:.2e} / all ids {dall[i]:.2e}; "
+              f"logp of the two ids: oracle {float(rec[i][sampled[i]]):.6f} {float(rec[i][drawn[i]]):.6f}, build {float(lps[i][sampled[i]]):.6f} {float(lps[i][drawn[i]]):.6f}")
 m = torch.tensor(margins)
-print(f"\noracle decision margins over {len(m)} steps: race margin min {m.min():.2e} (step {int(m.argmin())}), "
+print(f"\nfallback steps: {sum(fallback)} of {len(fallback)}")
+print(f"oracle decision margins over {len(m)} steps: race margin min {m.min():.2e} (step {int(m.argmin())}), "
       f"steps with margin < 1e-4: {int((m < 1e-4).sum())}, < 1e-3: {int((m < 1e-3).sum())}; nucleus-cut margin min {min(cutm):.2e}")
