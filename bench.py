@@ -387,12 +387,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    host = {"cores": None, "pinned": False}
     if world > 1:                                          # N ranks share one host: no rank may take every core for torch's CPU pools
         try:
-            ncpu = len(os.sched_getaffinity(0))
+            cpus = sorted(os.sched_getaffinity(0))
         except AttributeError:
-            ncpu = os.cpu_count() or world
-        torch.set_num_threads(max(1, ncpu // world))
+            cpus = list(range(os.cpu_count() or world))
+        share = max(1, len(cpus) // world)
+        torch.set_num_threads(share)
+        # every rank runs a decode thread and two flow workers: pin them to this rank's own share of the cores (contiguous, in
+        # local-rank order) so that eight ranks do not migrate over each other's cores
+        if len(cpus) >= 3 * world and hasattr(os, "sched_setaffinity") and not os.environ.get("MMX_NO_PIN"):
+            mine_c = cpus[local * share:(local + 1) * share]
+            try:
+                os.sched_setaffinity(0, mine_c)
+                host["pinned"] = True
+            except OSError:
+                pass
+        host["cores"] = share
     # MMX_BENCH_REHEARSE=1: multi-rank rehearsal on a ONE-GPU box - every rank uses cuda:0, collectives run on gloo
     # over host copies.  Exercises the launch contract, sharding, barriers and the gather; never use it for numbers.
     rehearse = bool(os.environ.get("MMX_BENCH_REHEARSE")) and world > 1
@@ -436,7 +448,6 @@ def main():
     g = torch.Generator().manual_seed(2)
     all_text = [torch.randint(0, 151936, (1, 290 if a.workload == "longform" else 48), generator=g) for _ in range(len(lens_all))]
     texts = [all_text[i].to(dev) for i in mine]
-    max_samples = 2 * max(lens_all) * eng.hop
 
     first_chunk_ms = []
 
@@ -455,7 +466,7 @@ def main():
             return n
         wavs = eng.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens, group_size=[int(v) for v in str(a.flow_group).split(',')], overlap=not a.no_overlap, max_pad_ratio=a.pad_ratio, flow_workers=a.flow_workers, hold_steps=a.hold_steps, poll_every=a.poll_every, tail_active=a.tail_active, polite=not a.no_polite)
         if world > 1:                                              # the path's one exchange step (RCCL all-gather)
-            gather_audio([w.cpu() for w in wavs] if rehearse else wavs, mine, len(lens_all), max_samples)
+            gather_audio([w.cpu() for w in wavs] if rehearse else wavs, mine, len(lens_all))
         return sum(w.shape[-1] for w in wavs)
 
     def fence():
@@ -513,6 +524,9 @@ def main():
                "config": {"workload": wl, "utterances_per_gpu": PER_GPU, "audio_s_per_step": round(audio_s / a.steps, 2),
                           "parallelism": f"dp{world} (replica per GPU, all_gather of audio)"}}
         out["collective"] = {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None)}
+        lh = getattr(eng, "last_host", None)
+        if lh:                                             # rank 0's last timed step: host issue time of the decode loop, when it ended, the whole call
+            out["host"] = dict(host, **lh, lm_issue_us_per_decode_step=round(lh["lm_issue_ms"] * 1e3 / max(1, lh["decode_steps"]), 1))
         BUILD = {2: "split (bf16 weight stream; fp32 activations carried as 2 (flow, DAC) / 3 (LM) bf16 terms inside the MFMA products)",
                  1: "bf16 (bf16 GEMM inputs, fp32 residual streams)", 0: "fp32 (f32-input MFMA)"}
         out["config"]["build"] = BUILD[dt]

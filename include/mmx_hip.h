@@ -215,6 +215,9 @@ int mmx_conv_cin1(const float* x, int64_t x_bs, int T, int C, int k, const float
  * z = m + noise * exp(logs).  All outputs fp32 [rows][D]. */
 int mmx_vae_sample(const float* ml, const float* noise, int64_t rows, int D, float* z, float* m, float* logs,
                    hipStream_t stream);
+/* Speed change (speech/cosyvoice/cli/model.py:312-314): x fp32 [rows][T] -> out fp32 [rows][T2], linear interpolation in time
+ * with torch's F.interpolate(mode="linear", align_corners=False) sample positions. */
+int mmx_resample_linear(const float* x, int64_t rows, int T, int T2, float* out, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DAC tail: Conv1d(C -> 1, k) + LeakyReLU(0.1) + tanh (dac-vae/model.py:364-370,509-514).

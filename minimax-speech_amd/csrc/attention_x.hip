@@ -394,16 +394,20 @@ extern "C" int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, co
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
     const bf16_t* q = (const bf16_t*)qk;
-    if constexpr (LAB) {                               // lab build only: MMX_LAB_FLASHX=mf2 -> 8 waves x 32 queries (256 per workgroup)
+    // 8 waves x 32 queries (256 per workgroup, MF = 2) halve the K / V fragment reads from LDS per MFMA, and a workgroup takes
+    // ~1.6 x as long as one of 128 queries (tools/flash_lab.py, profiles/r04_flash_lab_x.txt: 71 -> 62 us at 3 x 980 frames,
+    // 37 -> 30 at 5 x 420, 122 -> 112 at 8 x 896; 93 -> 100 at 5 x 860, where the 128-query grid needs 3 rounds of the 256 CUs
+    // and the 256-query grid 2).  Chosen per launch from the rounds each grid needs.
+    const int nq2 = (Tq + 255) / 256;
+    const long wg1 = (long)npairs * nq, wg2 = (long)npairs * nq2;
+    bool mf2 = !small && 1.6 * (double)((wg2 + 255) / 256) < (double)((wg1 + 255) / 256);
+    if constexpr (LAB) {                               // lab build only: MMX_LAB_FLASHX=mf1 / mf2 forces the form
         const char* e = getenv("MMX_LAB_FLASHX");
-        if (e && e[0] == 'm' && !small) {
-            const int nq2 = (Tq + 255) / 256;
-            dim3 grid2(8 * ((npairs + 7) / 8) * nq2);
-            return launch_flash_x<2, true, 8>(grid2, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq2, H, npairs, q_begin, klen);
-        }
-        if (e && e[0] == 'w' && !small) {              // MMX_LAB_FLASHX=w4: 4 waves x 32 queries (128 per workgroup, one wave per SIMD)
-            return launch_flash_x<2, true, 4>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
-        }
+        if (e && e[0] == 'm' && !small) mf2 = e[2] == '2';
+    }
+    if (mf2) {
+        dim3 grid2(8 * ((npairs + 7) / 8) * nq2);
+        return launch_flash_x<2, true, 8>(grid2, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq2, H, npairs, q_begin, klen);
     }
     if (small) return launch_flash_x<1, true, 4>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);
     return launch_flash_x<1, true, 8>(grid, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq, H, npairs, q_begin, klen);

@@ -331,6 +331,31 @@ extern "C" int mmx_vae_sample(const float* ml, const float* noise, int64_t rows,
     return MMX_OK;
 }
 
+// ---------------------------------------------------------------------------- linear resampling in time (speed change)
+// F.interpolate(x [rows][T], size=T2, mode="linear", align_corners=False) as torch's CPU kernel computes it: scale = T / T2 in
+// fp32, src = scale * (t + 0.5) - 0.5 clamped at 0, out = (1 - w) * x[i0] + w * x[min(i0 + 1, T - 1)], w = src - i0
+// (speech/cosyvoice/cli/model.py:312-314: tts_mel resampled by 1 / speed before the vocoder).
+__global__ void resample_linear_kernel(const float* __restrict__ x, int T, int T2, long rows, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * T2) return;
+    const long r = i / T2;
+    const int t = (int)(i - r * T2);
+    const float scale = (float)T / (float)T2;
+    float src = scale * ((float)t + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)src;
+    const int i1 = i0 + (i0 < T - 1 ? 1 : 0);
+    const float w1 = src - (float)i0, w0 = 1.f - w1;
+    out[i] = w0 * x[r * T + i0] + w1 * x[r * T + i1];
+}
+extern "C" int mmx_resample_linear(const float* x, int64_t rows, int T, int T2, float* out, hipStream_t stream) {
+    MMX_CHECK_ARG(x && out && rows > 0 && T > 0 && T2 > 0);
+    const long n = rows * T2;
+    hipLaunchKernelGGL(resample_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, T, T2, (long)rows, out);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
 // ---------------------------------------------------------------------------- SwiGLU (prefill)
 template <typename T>
 __global__ void swiglu_kernel(const float* __restrict__ gu, long ldgu, int I, T* __restrict__ out, long ldo) {
@@ -428,4 +453,4 @@ extern "C" int mmx_act_rows(const float* x, int64_t rows, int C, int act, const 
     return MMX_OK;
 }
 
-extern "C" int mmx_abi_version(void) { return 6; }
+extern "C" int mmx_abi_version(void) { return 7; }

@@ -35,7 +35,7 @@ class Decoder(EngineHost):
         dev = self._device()
         if self._engine is None:
             sd = {"decoder." + k: v for k, v in self.state_dict().items()}
-            self._engine = DacDecoderEngine(sd, self.rates, dtype=self.compute_dtype, device=dev,
+            self._engine = DacDecoderEngine(sd, self.rates, dtype=self.compute_dtype, device=dev, wplanes=getattr(self, 'weight_planes', False),
                                             use_tanh=self.use_tanh_as_final, with_pre=False)
         return self._engine.decode(x.float(), skip_pre=True)
 
@@ -119,6 +119,6 @@ class DACVAE(EngineHost):
         from mmx.dac import DacDecoderEngine
         dev = self._device()
         if self._engine is None:
-            self._engine = DacDecoderEngine(self.state_dict(), self.decoder_rates, dtype=self.compute_dtype, device=dev,
+            self._engine = DacDecoderEngine(self.state_dict(), self.decoder_rates, dtype=self.compute_dtype, device=dev, wplanes=getattr(self, 'weight_planes', False),
                                             use_tanh=self.decoder.use_tanh_as_final)
         return self._engine.decode(z.float())

@@ -26,7 +26,8 @@ class DacDecoderEngine:
         """wplanes (split build only): the checkpoint's folded fp32 weights are carried as two bf16 planes (MMX_X2W) instead of
         being rounded to bf16 - for checkpoints whose weights are not bf16-representable (any trained weight norm)."""
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
-        self.wplanes = bool(wplanes) and dtype == X2
+        self.wplanes = dtype == X2 and ops.resolve_wplanes(wplanes, (ops.fold_weight_norm(sd[k], sd[k[:-1] + "v"]) for k in sd
+                                                                     if k.endswith(".weight_g") and not k.startswith("encoder.")))
         # the fused ResidualUnit kernel exists for the bf16 and split builds; the fp32 build keeps two GEMM launches per unit
         self.fuse_ru = bool(fuse_ru) and dtype in (BF16, X2)
         dtype = X2W if self.wplanes else dtype                         # `dtype` below: the code the weights are packed for

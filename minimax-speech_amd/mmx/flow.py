@@ -127,7 +127,8 @@ class FlowEngine:
         (the reference loads fp32 flow.pt, cli/model.py:67-75).  Three MFMAs per fragment pair (hi*hi + lo*hi + hi*lo) and twice
         the weight stream, in the windowed GEMM and in the fused row-tile kernels alike."""
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
-        self.wplanes = bool(wplanes) and dtype == X2
+        self.wplanes = dtype == X2 and ops.resolve_wplanes(wplanes, (v for k, v in sd.items() if v.dim() >= 2 and v.is_floating_point()
+                                                                     and k != "input_embedding.weight" and not k.endswith("rand_noise")))
         self.pdt = X2W if self.wplanes else dtype            # the code weights are packed for
         self.n_timesteps, self.cfg, self.L = n_timesteps, cfg_rate, pre_lookahead_len
         self.enc_chunk, self.est_chunk = enc_chunk, est_chunk

@@ -61,7 +61,8 @@ class LlmEngine:
         bf16 - for checkpoints whose weights are not bf16-representable (the reference loads an fp32 llm.pt, cli/model.py:67-75).
         Costs 3 x the weight bytes and 2 x the MFMAs of the plain split build."""
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
-        self.wplanes = (bool(wplanes) and dtype == X3) if share_from is None else share_from.wplanes
+        self.wplanes = (dtype == X3 and ops.resolve_wplanes(wplanes, (v for k, v in sd.items() if v.dim() >= 2 and ("proj" in k or k == "llm_decoder.weight")))) \
+            if share_from is None else share_from.wplanes
         if self.wplanes:                                  # three weight planes in registers: one output tile per workgroup
             self.v2_cfg = dict(qkv=(1, 1), o=(1, 1), gu=(1, 1), down=(1, 8), head=(1, 1))
         self.split = is_split(dtype)                      # bf16 weights, fp32 activations split inside the MFMA products

@@ -33,6 +33,18 @@ def weight_planes(w: torch.Tensor, n: int):
     return out
 
 
+def resolve_wplanes(wplanes, weights) -> bool:
+    """wplanes of an engine constructor: True / False, or "auto" = True exactly when one of `weights` (the matrix-shaped weights
+    as the kernels will see them, weight norm folded) is not bf16-representable, i.e. when rounding at load would change it."""
+    if wplanes != "auto":
+        return bool(wplanes)
+    for w in weights:
+        w = w.detach().float()
+        if not torch.equal(w.to(torch.bfloat16).float(), w):
+            return True
+    return False
+
+
 def pack_linear(w: torch.Tensor, dtype) -> torch.Tensor:
     """[N, K] -> [N, Kpad] (K contiguous, zero padded to a multiple of 32) in the compute dtype.
     dtype X2W / X3W: w fp32 -> Planed [N, planes * Kpad], the planes side by side in every row."""
@@ -187,6 +199,15 @@ def conv_cin1(x, w, bias, *, T, C_, k, batch, dtype, slope=0.1, alpha=None, out_
 
 def vae_sample(ml, noise, z, m, logs, *, rows, D):
     check(load().mmx_vae_sample(_p(ml), _p(noise), i64(rows), D, _p(z), _p(m), _p(logs), stream()), "mmx_vae_sample")
+
+
+def resample_linear(x, T2):
+    """x fp32 [..., T] -> [..., T2]: F.interpolate(mode="linear", align_corners=False) along the last axis (mmx_resample_linear)."""
+    x = x.contiguous()
+    T = x.shape[-1]
+    out = torch.empty(*x.shape[:-1], T2, dtype=torch.float32, device=x.device)
+    check(load().mmx_resample_linear(_p(x), i64(x.numel() // T), T, T2, _p(out), stream()), "mmx_resample_linear")
+    return out
 
 
 def conv_cout1_tanh(act, w, bias, out, *, T, C_, k, batch, dtype, slope=0.1, use_tanh=True):

@@ -39,7 +39,7 @@ class TtsEngine:
         MMX_X3W / MMX_X2W) and the products keep every term above the last kept bit, so ids identical / waveform <= 1e-3 hold on
         such checkpoints too (tests/test_gpu_split.py::test_weight_planes_*)."""
         self.dtype, self.dev = dtype, torch.device(device)
-        self.wplanes = bool(wplanes) and is_split(dtype)
+        self.wplanes = wplanes if is_split(dtype) else False        # True / False / "auto" (per model: ops.resolve_wplanes)
         if self.dev.type == "cuda" and self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())
         device = self.dev
@@ -216,7 +216,9 @@ class TtsEngine:
             hi = T2 if finalize else T2 - CR               # frames whose right context is final
             if hi <= emitted:
                 return None
-            re = MC if (finalize and held is not None) else 0       # the closing pass renders the held frames again
+            # the closing pass renders the held frames again (as many as the last streaming pass held back: MEL_CACHE, or all
+            # it rendered when that was fewer)
+            re = held.shape[1] // self.hop if (finalize and held is not None) else 0
             start = emitted - re
             ctx = None if tail is None else tail[:tail.shape[0] - re][-CL:]
             seg = lat[start:] if ctx is None or ctx.shape[0] == 0 else torch.cat([ctx, lat[start:]], dim=0)
@@ -228,7 +230,7 @@ class TtsEngine:
             lat_used = lat[emitted:hi]
             if finalize:
                 if re:
-                    wav = fade_in_out(wav, held, self.fade_window(MC * self.hop, self.dev))
+                    wav = fade_in_out(wav, held, self.fade_window(re * self.hop, self.dev))
                     lat_used = torch.cat([held_lat, lat_used], 0)
                 out, held, held_lat = wav, None, None
             else:
@@ -562,10 +564,13 @@ class TtsEngine:
             # runs until every utterance has been seen (the bound only stops a runaway: each admitted utterance can wait
             # up to poll_every steps for its slot on top of its own max_len)
             done, max_steps = 1, (max(maxs) if B == NS else sum(maxs) + (B + 1) * poll_every)
+            issue_s = 0.0                                        # host time spent enqueueing decode steps (graph replays)
             while done < max_steps:
                 k = min(poll_every, max_steps - done)
+                t_i = _time.perf_counter()
                 for _ in range(k):
                     cur[0].step()
+                issue_s += _time.perf_counter() - t_i
                 done += k
                 steps_done[0] = done
                 harvest(False)
@@ -598,4 +603,8 @@ class TtsEngine:
             caller.wait_stream(sd)
         caller.wait_stream(main)
         self.last_tokens = toks                          # accepted ids per utterance (device int64 tensors)
+        # host-side accounting of the call (bench.py puts it into its JSON line: a multi-GPU node runs N x (decode thread + flow
+        # workers) on shared cores, and a slow host shows up here first)
+        self.last_host = dict(decode_steps=done, lm_issue_ms=round(issue_s * 1e3, 2), lm_done_ms=round((t_lm - self._t0) * 1e3, 1),
+                              call_ms=round((time.perf_counter() - self._t0) * 1e3, 1))
         return wavs

@@ -35,6 +35,11 @@ class EngineHost(nn.Module):
 
     _engine = None
     compute_dtype = 1          # BF16 by default; .float_parity() switches to the exact-fp32 build
+    dtype_chosen = False       # True once float_parity() / split_parity() was called (CosyVoice2Model's fp16 flag picks otherwise)
+    # split build: "auto" = the checkpoint's weights are carried as bf16 planes (include/mmx_hip.h MMX_X2W / MMX_X3W) exactly
+    # when they are not bf16-representable, so a module loaded from the reference's fp32 llm.pt / flow.pt / DAC generator
+    # (cli/model.py:67-75, dac-vae/inference.py:42-46) is not rounded at load; True / False force it
+    weight_planes = "auto"
 
     def _invalidate(self):
         self._engine = None
@@ -56,16 +61,16 @@ class EngineHost(nn.Module):
         """fp32 storage + exact-fp32 MFMA (the parity build) instead of bf16."""
         for m in self.modules():
             if isinstance(m, EngineHost):
-                m.compute_dtype = 0 if on else 1
+                m.compute_dtype, m.dtype_chosen = (0 if on else 1), True
                 m._invalidate()
         return self
 
-    def split_parity(self, on=True):
+    def split_parity(self, on=True, weight_planes="auto"):
         """The split build (mmx/_lib.py X2 / X3): bf16 weight stream, fp32 activations carried as bf16 terms inside the MFMA
         products - token ids and waveform as the fp32 build's, at (nearly) the bf16 build's speed."""
         for m in self.modules():
             if isinstance(m, EngineHost):
-                m.compute_dtype = 2 if on else 1
+                m.compute_dtype, m.dtype_chosen, m.weight_planes = (2 if on else 1), True, weight_planes
                 m._invalidate()
         return self
 

@@ -27,7 +27,14 @@ class CosyVoice2Model:
         """`hift` is the waveform decoder: a dac-vae `DACVAE` in this fork (kept under the reference's argument name)."""
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.llm, self.flow, self.hift = llm, flow, hift
-        self.fp16 = fp16                                  # the HIP engines pick bf16 / fp32 themselves
+        # cli/model.py:250-253: fp16=True halves llm and flow, fp16=False (the default) computes in fp32.  Here: fp16=True = the
+        # bf16 speed build of those two modules; fp16=False = the split build (fp32-grade: the CPU path's token ids, waveform
+        # within 1e-3; weight planes when the loaded checkpoint is not bf16-representable).  A module whose build was chosen
+        # explicitly (float_parity() / split_parity()) keeps it; the waveform decoder follows the flow's build.
+        self.fp16 = fp16
+        for m in (llm, flow, hift):
+            if hasattr(m, "split_parity") and not any(getattr(x, "dtype_chosen", False) for x in m.modules()):
+                m.split_parity(not fp16)
         self.token_hop_len = 25                           # must match the training static_chunk_size
         self.mel_cache_len = 8                            # model.py:258: frames two passes overlap by
         self.hop = int(np.prod(getattr(hift, "decoder_rates", [5, 4, 4, 3, 2])))   # samples per latent frame
@@ -35,12 +42,15 @@ class CosyVoice2Model:
         self.dac_ctx_left, self.dac_ctx_right = DacDecoderEngine.receptive_field(getattr(hift, "decoder_rates", [5, 4, 4, 3, 2]))
         # model.py:262 speech_window = np.hamming(2 * source_cache_len), here over mel_cache_len DAC frames and with each pair
         # of halves scaled to sum to one (a cross-fade of two equal renderings is then the identity)
-        w = np.hamming(2 * self.mel_cache_len * self.hop)
-        n = w.shape[0] // 2
-        self.speech_window = torch.from_numpy(np.concatenate([w[:n] / (w[:n] + w[n:]), w[n:] / (w[:n] + w[n:])])).float()
+        self.speech_window = self._window(self.mel_cache_len)
         self.llm_stream = None                            # the llm_job thread launches on its own stream (mmx/flow.py rule)
         self.lock = threading.Lock()
         self.tts_speech_token_dict, self.llm_end_dict, self.hift_cache_dict = {}, {}, {}
+
+    def _window(self, frames):
+        w = np.hamming(2 * frames * self.hop)
+        n = w.shape[0] // 2
+        return torch.from_numpy(np.concatenate([w[:n] / (w[:n] + w[n:]), w[n:] / (w[:n] + w[n:])])).float()
 
     def load(self, llm_model, flow_model, hift_model):
         self.llm.load_state_dict(torch.load(llm_model, map_location="cpu"), strict=True)
@@ -73,7 +83,6 @@ class CosyVoice2Model:
 
     def token2wav(self, token, prompt_token, prompt_feat, embedding, token_offset, uuid, stream=False, finalize=False,
                   speed=1.0):
-        assert speed == 1.0, "speed change is not on the hot path"
         i32 = lambda n: torch.tensor([n], dtype=torch.int32, device=self.device)
         lat, _ = self.flow.inference(token=token.to(self.device), token_len=i32(token.shape[1]),
                                      prompt_token=prompt_token.to(self.device), prompt_token_len=i32(prompt_token.shape[1]),
@@ -81,6 +90,10 @@ class CosyVoice2Model:
                                      embedding=embedding.to(self.device), streaming=stream, finalize=finalize)
         st = self.hift_cache_dict.get(uuid)
         start = token_offset * self.flow.token_mel_ratio
+        if speed != 1.0:                                   # cli/model.py:312-314: linear resampling of the latent frames in time
+            assert st is None and finalize, "speed change only support non-stream inference mode"
+            from mmx import ops
+            return self.hift.decode(ops.resample_linear(lat[:, :, start:].float(), int((lat.shape[2] - start) / speed)))[:, 0]
         if st is None and finalize:                        # one-shot synthesis: decode everything
             return self.hift.decode(lat[:, :, start:])[:, 0]
         # Streaming session (rule stated in mmx/pipeline.py::tts_stream and oracle/stream.py): `emitted` latent frames are
@@ -94,7 +107,7 @@ class CosyVoice2Model:
         hi = T2 if finalize else T2 - CR
         if hi <= emitted:
             return lat.new_zeros(1, 0)
-        re = MC if (finalize and held is not None) else 0
+        re = held.shape[1] // self.hop if (finalize and held is not None) else 0     # frames the last streaming pass held back
         first = emitted - re
         ctx = None if tail is None else tail[:, :, :tail.shape[2] - re][:, :, -CL:]
         seg = lat[:, :, first:] if ctx is None or ctx.shape[2] == 0 else torch.cat([ctx, lat[:, :, first:]], dim=2)
@@ -102,7 +115,7 @@ class CosyVoice2Model:
         wav = self.hift.decode(seg)[:, 0, nctx * self.hop:(nctx + hi - first) * self.hop]
         if finalize:
             if re:
-                wav = fade_in_out(wav, held, self.speech_window)
+                wav = fade_in_out(wav, held, self.speech_window if re == MC else self._window(re).to(wav.device))
             return wav
         keep = min(MC, hi - emitted)
         out = wav[:, :wav.shape[1] - keep * self.hop]

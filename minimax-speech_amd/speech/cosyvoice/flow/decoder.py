@@ -85,7 +85,7 @@ class CausalConditionalDecoder(EngineHost):
         dev = self._device()
         if self._engine is None:
             sd = {"decoder.estimator." + k: v for k, v in self.state_dict().items()}
-            self._engine = FlowEngine(sd, dtype=self.compute_dtype, device=dev, est_chunk=self.static_chunk_size,
+            self._engine = FlowEngine(sd, dtype=self.compute_dtype, device=dev, wplanes=getattr(self, 'weight_planes', False), est_chunk=self.static_chunk_size,
                                       parts=("estimator",))
         return self._engine
 

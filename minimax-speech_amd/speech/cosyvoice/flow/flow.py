@@ -41,7 +41,7 @@ class CausalMaskedDiffWithXvec(EngineHost):
         dev = self._device()
         if self._engine is None:
             est = self.decoder.estimator
-            self._engine = FlowEngine(self.state_dict(), dtype=self.compute_dtype, device=dev,
+            self._engine = FlowEngine(self.state_dict(), dtype=self.compute_dtype, device=dev, wplanes=getattr(self, 'weight_planes', False),
                                       enc_chunk=self.encoder.static_chunk_size, est_chunk=est.static_chunk_size,
                                       pre_lookahead_len=self.pre_lookahead_len, cfg_rate=self.decoder.inference_cfg_rate)
             self._engine.set_noise(self.decoder.rand_noise)

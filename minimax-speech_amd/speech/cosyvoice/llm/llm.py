@@ -90,7 +90,7 @@ class Qwen2Encoder(nn.Module):
         if self._engine is None:
             c = self.cfg
             sd = {"llm." + k: v for k, v in self.state_dict().items()}
-            self._engine = LlmEngine(sd, dtype=(3 if self.compute_dtype == 2 else self.compute_dtype), device=p.device, max_batch=1, max_ctx=self.max_ctx,
+            self._engine = LlmEngine(sd, dtype=(3 if self.compute_dtype == 2 else self.compute_dtype), device=p.device, max_batch=1, max_ctx=self.max_ctx, wplanes=getattr(self, 'weight_planes', False),
                                      heads=c["num_attention_heads"], kv_heads=c["num_key_value_heads"],
                                      head_dim=c["hidden_size"] // c["num_attention_heads"], rope_theta=c["rope_theta"],
                                      eps=c["rms_norm_eps"])
@@ -155,7 +155,7 @@ class Qwen2LM(EngineHost):
         dev = self._device()
         if self._engine is None or self._engine.B != max_batch:
             c = self.llm.cfg
-            self._engine = LlmEngine(self.state_dict(), dtype=(3 if self.compute_dtype == 2 else self.compute_dtype), device=dev, max_batch=max_batch,
+            self._engine = LlmEngine(self.state_dict(), dtype=(3 if self.compute_dtype == 2 else self.compute_dtype), device=dev, max_batch=max_batch, wplanes=getattr(self, 'weight_planes', False),
                                      max_ctx=self.max_ctx, heads=c["num_attention_heads"], kv_heads=c["num_key_value_heads"],
                                      head_dim=c["hidden_size"] // c["num_attention_heads"], rope_theta=c["rope_theta"],
                                      eps=c["rms_norm_eps"], speech_token_size=self.speech_token_size)

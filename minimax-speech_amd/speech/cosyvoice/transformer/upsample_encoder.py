@@ -37,7 +37,7 @@ class UpsampleConformerEncoder(EngineHost):
         dev = self._device()
         if self._engine is None:
             sd = {"encoder." + k: v for k, v in self.state_dict().items()}
-            self._engine = FlowEngine(sd, dtype=self.compute_dtype, device=dev, enc_chunk=self.static_chunk_size,
+            self._engine = FlowEngine(sd, dtype=self.compute_dtype, device=dev, wplanes=getattr(self, 'weight_planes', False), enc_chunk=self.static_chunk_size,
                                       parts=("encoder",))
         return self._engine
 

@@ -89,7 +89,6 @@ def render_passes(dac_sd, rates, passes, ctx_left: int, ctx_right: int):
     """The DAC rendering rule of the module docstring over [(token_offset * ratio, latents of all frames, finalize)] passes.
     Returns the emitted waveform chunks (1-D tensors, one per pass that emits something)."""
     hop = int(np.prod(rates))
-    n_over = MEL_CACHE * hop
     rendered = torch.zeros(0, 80)       # latent values each rendered frame was rendered from, by absolute frame
     held = None                         # samples of the last MEL_CACHE rendered frames, not yet emitted
     wavs = []
@@ -99,14 +98,14 @@ def render_passes(dac_sd, rates, passes, ctx_left: int, ctx_right: int):
         lo = rendered.shape[0]                                # first frame not yet rendered
         if hi <= lo:
             continue
-        re = MEL_CACHE if (fin and held is not None) else 0   # the closing pass renders the held frames again
+        re = held.shape[0] // hop if (fin and held is not None) else 0   # the closing pass renders the held frames again
         start = lo - re
         cl = min(ctx_left, start)
         win_lat = torch.cat([rendered[start - cl:start], lat[start:]], 0)
         wav = ODAC.decode(dac_sd, win_lat.t().unsqueeze(0).contiguous(), rates)[0, 0]
         seg = wav[cl * hop:(cl + hi - start) * hop]          # samples of frames [start, hi)
         if fin:
-            out = fade_in_out(seg, held, fade_window(n_over)) if re else seg
+            out = fade_in_out(seg, held, fade_window(re * hop)) if re else seg
             held = None
         else:
             keep = min(MEL_CACHE, hi - lo)                    # (a pass renders at least MEL_CACHE frames in practice)

@@ -390,3 +390,63 @@ def test_dropin_inference_bistream_device_sampler_vs_oracle(seed, ok):
         with pytest.raises(ValueError, match="should not get token 6563"):
             for t in gen:
                 got.append(t)
+
+
+@pytest.mark.gpu
+def test_cosyvoice2model_fp16_flag_speed_and_checkpoint_kind(golden_dir):
+    """CosyVoice2Model's `fp16` flag and `speed` argument (cli/model.py:250-253,312-314) and the checkpoint kind.
+      * fp16=False (the reference's default: fp32 arithmetic) selects the split build of every module whose build was not chosen
+        explicitly, fp16=True the bf16 build; float_parity() survives both.
+      * A module loaded from a checkpoint whose weights are not bf16-representable (the "fp32" kind of mmx/synth.py: what the
+        reference's loaders hand over) builds its engine with weight planes; the bf16 kind does not.
+      * speed != 1.0 (non-streaming only): the latent frames are resampled in time like F.interpolate(mode="linear") before the
+        waveform decoder - against the oracle's flow + torch's interpolate + the oracle's DAC, within 1e-3."""
+    import torch.nn.functional as F
+    from functools import partial
+    from cosyvoice.cli.model import CosyVoice2Model
+    from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM
+    from cosyvoice.utils.common import ras_sampling
+    from oracle import dac as ODAC, flow as OFLOW, llm as OLLM, weights as W
+    from mmx import shapes
+
+    def build(kind):
+        lm = Qwen2LM(896, 896, 6561, Qwen2Encoder({"num_hidden_layers": 2}), partial(ras_sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1))
+        sds = (W.synth_state_dict(shapes.llm_manifest(layers=2), 7, kind=kind), W.synth_state_dict(_ref(golden_dir, "flow"), 7, kind=kind),
+               W.synth_state_dict({**_ref(golden_dir, "dac80"), **_ref(golden_dir, "dacenc")}, 7, kind=kind))
+        lm.load_state_dict(sds[0], strict=True)
+        flow, dac = build_flow(), build_dac(80)
+        flow.load_state_dict(sds[1], strict=True)
+        dac.load_state_dict(sds[2], strict=True)
+        return [m.to("cuda").eval() for m in (lm, flow, dac)], sds
+
+    (lm, flow, dac), _ = build("bf16")
+    CosyVoice2Model(lm, flow, dac, fp16=True)
+    assert lm.compute_dtype == flow.compute_dtype == dac.compute_dtype == 1
+    flow.float_parity()
+    m = CosyVoice2Model(lm, flow, dac)
+    assert lm.compute_dtype == 2 and dac.compute_dtype == 2 and flow.compute_dtype == 0 and flow.decoder.estimator.compute_dtype == 0
+    dac.decode(torch.zeros(1, 80, 4, device="cuda"))
+    assert not lm.engine(1).wplanes and not dac._engine.wplanes
+    (lm, flow, dac), sds = build("fp32")
+    m = CosyVoice2Model(lm, flow, dac)
+    lm.seed = 3
+    dac.decode(torch.zeros(1, 80, 4, device="cuda"))
+    assert lm.engine(1).wplanes and flow._eng().wplanes and dac._engine.wplanes
+    g = torch.Generator().manual_seed(5)
+    text, emb = torch.randint(0, 151936, (1, 12), generator=g), torch.randn(1, 192, generator=g)
+    ratio = 40.5 / 12
+    orig = lm.inference
+    lm.inference = lambda **kw: orig(**{**kw, "min_token_text_ratio": ratio, "max_token_text_ratio": ratio})
+    z = torch.zeros(1, 0, dtype=torch.long)
+    with torch.no_grad():
+        toks = OLLM.lm_inference(sds[0], OLLM.QwenCfg(layers=2), text, z, z, seed=3, seq=0, max_steps=40, ignore_eos_always=True)
+        lat = OFLOW.flow_inference(sds[1], torch.tensor(toks).reshape(1, -1), z, torch.zeros(1, 0, 80), emb)
+    for speed in (1.0, 1.25, 0.8):
+        out = list(m.tts(text=text, flow_embedding=emb, llm_embedding=emb, stream=False, speed=speed))
+        wav = out[0]["tts_speech"]
+        with torch.no_grad():
+            l2 = lat if speed == 1.0 else F.interpolate(lat, size=int(lat.shape[2] / speed), mode="linear")
+            ref = ODAC.decode({k: v for k, v in sds[2].items() if not k.startswith("encoder.") and not k.startswith("en_conv")}, l2, [5, 4, 4, 3, 2])[:, 0]
+        err = (wav - ref).abs().max().item()
+        print(f"drop-in tts(speed={speed}) on an fp32 checkpoint (weight planes chosen automatically): waveform max abs err {err:.3e}")
+        assert wav.shape == ref.shape and err <= 1e-3, (speed, err)

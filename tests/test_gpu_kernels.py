@@ -638,3 +638,14 @@ def test_estimator_fused_equals_unfused(dt, tol, B, T, masked, streaming):
     err = (a - b_).abs().max().item()
     print(f"fused vs unfused estimator dtype {dt} B={B} T={T}: max abs diff {err:.3e} (std {b_.std().item():.3f})")
     assert torch.isfinite(a).all() and err < tol, err
+
+
+@pytest.mark.parametrize("T,T2", [(500, 400), (37, 46), (8, 8), (3, 10)])
+def test_resample_linear_matches_torch_interpolate(T, T2):
+    """mmx_resample_linear (the speed change of cli/model.py:312-314) against torch's own F.interpolate(mode="linear") on the CPU."""
+    import torch.nn.functional as F
+    from mmx import ops
+    x = torch.randn(2, 80, T, generator=torch.Generator().manual_seed(T))
+    got = ops.resample_linear(x.cuda(), T2).cpu()
+    ref = F.interpolate(x, size=T2, mode="linear")
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-6

@@ -637,3 +637,42 @@ def test_weight_planes_flow_fused_and_per_op_vs_oracle():
         errs[name] = (lat - ref).abs().max().item()
     print("flow.inference on an fp32 checkpoint vs the oracle: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert errs["fused, planes"] < 2e-3 and errs["per op, planes"] < 2e-3 and errs["fused, rounded"] > 5 * errs["fused, planes"]
+
+
+@pytest.mark.parametrize("B,T,chunk,ragged", [(6, 980, 0, False), (6, 980, 0, True), (10, 420, 50, False), (2, 300, 0, False), (16, 896, 0, True)])
+def test_attn_flash_xs_presplit_vs_float64(B, T, chunk, ragged):
+    """mmx_attn_flash_xs (operands split by the producer: bf16 rows [hi Q | hi K | lo Q | lo K], V transposed as two planes) against
+    float64 attention of hi + lo, over launch shapes that take each of its three forms: 4 waves x 16 queries (small launches),
+    8 x 16 and 8 x 32 queries (256 per workgroup, chosen when that grid needs fewer rounds of the 256 CUs: 6 x 980 and 10 x 420
+    here).  2^-17 per operand -> 4e-5 of the output range."""
+    from mmx import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    H, D = 8, 64
+    qkv = (torch.randn(B, T, 3 * H * D, generator=g) * 1.5).cuda()
+    hi = qkv.to(torch.bfloat16)
+    lo = (qkv - hi.float()).to(torch.bfloat16)
+    Tp = ops.round_up(T, 8)
+    qk = torch.cat([hi[:, :, :1024], lo[:, :, :1024]], dim=2).contiguous()                  # [hi Q | hi K | lo Q | lo K]
+    vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device="cuda")
+    vt[:, 0, :, :T], vt[:, 1, :, :T] = hi[:, :, 1024:].transpose(1, 2), lo[:, :, 1024:].transpose(1, 2)
+    lens = [T - (i * 53) % (T // 2) for i in range(B)] if ragged else [T] * B
+    lens[0] = T
+    out = torch.full((B, T, H * D), float("nan"), device="cuda")
+    ops.attn_flash_xs(qk, vt, out, B=B, H=H, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=2 * 512 * Tp, o_bs=T * 512, scale=0.125,
+                      chunk=chunk, klen=(torch.tensor(lens, dtype=torch.int32, device="cuda") if ragged else None))
+    x = (hi.double() + lo.double()).reshape(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    for b0 in range(0, B, 4):                                # float64 scores in slices of 4 batch rows (memory)
+        xb = x[:, b0:b0 + 4]
+        s = (xb[0] @ xb[1].transpose(-1, -2)) * 0.125
+        i = torch.arange(T, device="cuda")
+        vis = torch.ones(T, T, dtype=torch.bool, device="cuda")
+        if chunk:
+            vis &= i[None, :] < ((i[:, None] // chunk + 1) * chunk)
+        vis = vis[None, None].expand(s.shape[0], H, T, T).clone()
+        for j in range(s.shape[0]):
+            vis[j, :, :, lens[b0 + j]:] = False
+        ref = (torch.softmax(s.masked_fill(~vis, float("-inf")), -1) @ xb[2]).permute(0, 2, 1, 3).reshape(-1, T, H * D)
+        for j in range(ref.shape[0]):
+            n = lens[b0 + j]
+            a, r = out[b0 + j, :n], ref[j, :n]
+            assert torch.isfinite(a).all() and rel_err(a, r) < 4e-5, (b0 + j, rel_err(a, r))
