@@ -28,10 +28,14 @@ MFMA_BF16_PEAK_TFS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MF
 MFMA_F32_PEAK_TFS = 157.3      # f32-input MFMA = the fp32 vector rate
 
 
-def build_weights(seed=0):
+CKPT_KIND = "bf16"
+
+
+def build_weights(seed=0, kind=None):
     from mmx import shapes, synth
-    return (synth.synth_state_dict(shapes.llm_manifest(), seed), synth.synth_state_dict(shapes.flow_manifest(), seed),
-            synth.synth_state_dict(shapes.dac_decoder_manifest(80), seed))
+    kind = kind or CKPT_KIND
+    return (synth.synth_state_dict(shapes.llm_manifest(), seed, kind=kind), synth.synth_state_dict(shapes.flow_manifest(), seed, kind=kind),
+            synth.synth_state_dict(shapes.dac_decoder_manifest(80), seed, kind=kind))
 
 
 def measure_lm_kernel(eng, iters=240):
@@ -47,11 +51,11 @@ def measure_lm_kernel(eng, iters=240):
     S = llm._planes()
     ns = S["xs_b"].shape[0]
     nbytes = 2 * I * H * 2 + ns * (B * H + B * I) * 2
-    run = lambda l: ops.skinny2(S["xs_b"], llm.layers[l % llm.n_layers]["wgu"], B=B, K=H, N=I, dtype=llm.dtype, ssq_in=S["ssq_b"],
+    run = lambda l: ops.skinny2(S["xs_b"], llm.layers[l % llm.n_layers]["wgu"], B=B, K=H, N=I, dtype=llm.ddt, ssq_in=S["ssq_b"],
                                 eps=llm.eps, epi=1, xs_out=S["xs_act"], tiles_per_wg=llm.v2_cfg["gu"][0])
     us = _event_time_graph(run, iters)
     achieved = nbytes / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": f"skinny3_kernel (LM gate/up + SwiGLU, K=896, N=2x4864, batch {B}, {ns} activation plane(s))",
+    return {"bound": "hbm", "kernel": f"skinny3_kernel (LM gate/up + SwiGLU, K=896, N=2x4864, batch {B}, {ns} {'fp16' if getattr(llm, 'h2', False) else 'bf16'} activation plane(s))",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _pmc("lm_gate_up_hbm_bytes_per_launch", ns > 1), "bytes_per_launch": nbytes, "us_per_launch": round(us, 3)}
 
@@ -335,7 +339,7 @@ def make_engine(dt, device, max_batch, max_ctx):
         TtsEngine.group_fan = GROUP_FAN
     if FLOW_PRIO is not None:
         TtsEngine.flow_priority = FLOW_PRIO
-    return TtsEngine(*build_weights(0), dtype=dt, device=device, max_batch=max_batch, max_ctx=max_ctx, attn=ATTN)
+    return TtsEngine(*build_weights(0), dtype=dt, device=device, max_batch=max_batch, max_ctx=max_ctx, attn=ATTN, wplanes="auto")
 
 
 def main():
@@ -346,6 +350,10 @@ def main():
     ap.add_argument("--dtype", default="x", choices=["bf16", "f32", "x"],
                     help="x (default) = the split build, the build that meets the north-star parity: bf16 weight stream and bf16 MFMA products, "
                          "fp32 activations split into bf16 terms inside the products; bf16 = the speed build (ids diverge from the CPU path)")
+    ap.add_argument("--lm-planes", default=None, choices=["f16x2", "bf16x3"], help="split build: plane format of the LM decode step (LlmEngine.lm_planes)")
+    ap.add_argument("--checkpoint", default="bf16", choices=["bf16", "fp32"],
+                    help="kind of the synthetic checkpoint (mmx/synth.py): bf16 = bf16-representable weights; fp32 = general fp32 weights and "
+                         "trained-like weight norms, what the reference's loaders hand over - the split build then carries weight planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flow-bm-min", type=int, default=0, help="tuning: smallest tile height of the fused flow kernels")
     ap.add_argument("--flow-bm", type=int, default=0, help="cap the fused flow kernels' tile height (tuning: 32 leaves registers for co-resident decode waves)")
@@ -369,8 +377,11 @@ def main():
     ap.add_argument("--tail-active", type=int, default=0, help="with at most this many sequences still decoding, finished utterances go to an idle flow worker at once")
     ap.add_argument("--no-overlap", action="store_true", help="run LM decode and flow/DAC back to back (one stream)")
     a = ap.parse_args()
-    global ATTN, GROUP_FAN, FLOW_PRIO
-    ATTN, GROUP_FAN, FLOW_PRIO = a.attn, a.group_fan, a.flow_priority
+    global ATTN, GROUP_FAN, FLOW_PRIO, CKPT_KIND
+    ATTN, GROUP_FAN, FLOW_PRIO, CKPT_KIND = a.attn, a.group_fan, a.flow_priority, a.checkpoint
+    if a.lm_planes:
+        from mmx.llm import LlmEngine
+        LlmEngine.lm_planes = a.lm_planes
     if a.tpw2_min_tiles is not None:
         from mmx.flow import FlowEngine
         FlowEngine.polite_tpw2_min_tiles_default = a.tpw2_min_tiles
@@ -530,6 +541,9 @@ def main():
         BUILD = {2: "split (bf16 weight stream; fp32 activations carried as 2 (flow, DAC) / 3 (LM) bf16 terms inside the MFMA products)",
                  1: "bf16 (bf16 GEMM inputs, fp32 residual streams)", 0: "fp32 (f32-input MFMA)"}
         out["config"]["build"] = BUILD[dt]
+        out["config"]["checkpoint"] = ("bf16-representable weights (exact in the bf16 / fp16 weight stream)" if a.checkpoint == "bf16" else
+                                       "general fp32 weights, trained-like weight norms: the split build carries weight planes (2 fp16 planes in the LM "
+                                       "decode step, 2 bf16 planes in the flow and the DAC)")
         out["north_star"] = {"requirement": "FSQ token ids bit-exact and waveform within 1e-3 abs of the CPU path on identical inputs (BASELINE.json)",
                              "met_by": "split" if dt == 2 else ("fp32" if dt == 0 else None),
                              "evidence": "tests/test_gpu_split.py: config 3 (250 / 250 ids), config 4 at this batch size (32 utterances, overlapped "
@@ -605,7 +619,7 @@ def main():
                 torch.cuda.empty_cache()
                 w3 = build_weights(0)
                 # (1) BASELINE config 3 (one 10 s utterance) for the per-utterance RTF target (>= 10x real time), this build
-                e1 = TtsEngine(*w3, dtype=dt, device=f"cuda:{local}", max_batch=1, max_ctx=640)
+                e1 = TtsEngine(*w3, dtype=dt, device=f"cuda:{local}", max_batch=1, max_ctx=640, wplanes="auto")
                 ms1 = _time_steps(lambda: e1.tts(all_text[0].cuda(), emb, seed=0, exact_steps=250), build=2, warmup=1, steps=5)
                 out["single_utterance"] = {"workload": "BASELINE config 3: 48 text ids, 250 AR decode steps, flow 500 frames x 10 Euler steps, "
                                            "DAC 240000 samples", "build": a.dtype, "ms": round(ms1, 2), "rtf": round(ms1 / 1e4, 5),
@@ -618,7 +632,7 @@ def main():
                 d2 = {2: 1, 1: 2}.get(dt)
                 if d2 is not None:
                     torch.cuda.empty_cache()
-                    ef = TtsEngine(*w3, dtype=d2, device=f"cuda:{local}", max_batch=PER_GPU, max_ctx=640)
+                    ef = TtsEngine(*w3, dtype=d2, device=f"cuda:{local}", max_batch=PER_GPU, max_ctx=640, wplanes="auto")
                     fn = lambda: ef.tts_batch(texts, [emb] * len(texts), seed=0, exact_steps=lens)
                     for _ in range(2 + a.warmup):
                         fn()

@@ -47,6 +47,11 @@ typedef struct ihipStream_t* hipStream_t;
 #define MMX_X3 3
 #define MMX_X2W 0x12
 #define MMX_X3W 0x13
+/* fp16 planes of the LM decode step (mmx_skinny2, mmx_decode_prep, mmx_decode_attn's split output only): activations as TWO fp16
+ * planes hi + lo (22 significant bits), weights fp16 and stored * 2^8 - one plane for a bf16-representable checkpoint (MMX_H2),
+ * two planes hi + lo for an fp32 checkpoint (MMX_H2W); v_mfma_f32_16x16x32_f16.  |activation| < 65504, |weight| < 255. */
+#define MMX_H2 4
+#define MMX_H2W 0x14
 
 /* activation codes */
 #define MMX_ACT_NONE 0
@@ -301,7 +306,7 @@ int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, in
  * bit 1 = use the one-workgroup-per-query-head kernel even where the GQA-shared one applies (bf16, page = 16, Hq = 7 Hkv:
  * one workgroup per kv head serves its 7 query heads, Q K^T on the MFMA with the queries split into bf16 hi + lo). */
 /* out_packed bits: 1 = output in the packed A-fragment order of T; 2 = force the per-head kernel; 4 = output as SPLIT PLANES
- * (see mmx_skinny2; dtype MMX_F32 / the split builds only). */
+ * (see mmx_skinny2; dtype MMX_F32 / the split builds only); 8 = output as TWO fp16 planes (MMX_H2, same conditions). */
 int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                     const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
                     float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream);

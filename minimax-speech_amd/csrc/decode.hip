@@ -23,12 +23,20 @@
 // kernel); the hand-off is the measured-valid form of MI355X_MICROARCH.md "Workgroup dispatch ... visibility", table row 1:
 // sc1 stores, s_waitcnt vmcnt(0) in the storing wave, one agent-scope counter add by one lane of that wave, sc1 loads by
 // the wave whose add returned last.
+// fp16 planes (MMX_H2 / MMX_H2W, F16 = true below): the same kernels on TWO fp16 planes per activation (hi = fp16(x), lo = fp16(x - hi):
+// 22 significant bits) and fp16 weights, v_mfma_f32_16x16x32_f16 (the bf16 MFMA's rate; fp16 x fp16 products are exact in fp32).
+// A bf16-representable checkpoint converts to fp16 exactly (its weights are scaled by 2^8 at load so that the small ones stay
+// normal numbers; the epilogue multiplies by 2^-8) and costs two MFMAs per fragment on two thirds of the activation bytes of the
+// three-bf16-plane form; an fp32 checkpoint is two fp16 planes (MMX_H2W: 4 bytes per weight, three MFMAs per fragment) instead
+// of three bf16 planes (MMX_X3W: 6 bytes, six MFMAs).  Range: |activation| < 65504, |weight| < 255.
 #include "common.h"
 #include "../../include/mmx_hip.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+constexpr float H2_WSCALE = 256.f;                     // weights of the fp16 forms are stored as w * 2^8
 
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -40,15 +48,27 @@ constexpr int SSQ_SLOTS = 64;                          // tile slots per row of 
 __device__ __forceinline__ int plane_index(int row, int col, int nkb) {
     return (((((row >> 4) * nkb + (col >> 5)) << 6) + (((col & 31) >> 3) << 4) + (row & 15)) << 3) + (col & 7);
 }
-// v -> NS bf16 terms (NS = 3: hi + mid + lo = v; NS = 1, the bf16 build: bf16(v)) at `idx` of planes `ps` elements apart
-template <int NS>
+// v -> NS bf16 terms (NS = 3: hi + mid + lo = v; NS = 1, the bf16 build: bf16(v)) at `idx` of planes `ps` elements apart;
+// F16: NS fp16 terms (round to nearest each; the remainder of a rounded fp32 value is exact in fp32)
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void store_split(bf16_t* planes, int ps, int idx, float v) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const bf16_t h = f2bf(v);
-        planes[s * ps + idx] = h;
-        v -= bf2f(h);
+        if constexpr (F16) {
+            const _Float16 h = (_Float16)v;
+            planes[s * ps + idx] = __builtin_bit_cast(unsigned short, h);
+            v -= (float)h;
+        } else {
+            const bf16_t h = f2bf(v);
+            planes[s * ps + idx] = h;
+            v -= bf2f(h);
+        }
     }
+}
+template <bool F16>
+__device__ __forceinline__ float4_t mma16(u32x4_t a, u32x4_t b, float4_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, a), __builtin_bit_cast(short8_t, b), c, 0, 0, 0);
 }
 
 struct Skinny3Args {
@@ -65,7 +85,8 @@ struct Skinny3Args {
     long ldo;
     int B, K, N, ntiles, kb_per_wg;
     float eps;
-    unsigned wplane;         // NWP > 1 (MMX_X3W): bytes between two weight planes (each a whole pack)
+    unsigned wplane;         // NWP > 1 (MMX_X3W / MMX_H2W): bytes between two weight planes (each a whole pack)
+    float wscale;            // the accumulator is multiplied by this (1, or 2^-8 for the fp16 forms' scaled weights)
 };
 
 // lab build only (common.h, MMX_LAB): [workgroup][wave][8] shader-clock stamps of the kernel's phases, set by mmx_lab_skinny_stamps
@@ -75,7 +96,7 @@ __device__ unsigned long long* g_skinny_stamps = nullptr;
 // MT: 16-row tiles of the batch; TW: output tiles (EPI 1: gate/up tile pairs) per workgroup; KPW: k-blocks per wave (bound)
 // NWP = 3 (MMX_X3W, an fp32 checkpoint): the weights as three bf16 planes hi + mid + lo = w, each a pack of its own; a product keeps
 // the six terms (activation plane s) x (weight plane p) with s + p < 3 - both operands to fp32's 24 bits.
-template <int MT, int TW, int KPW, int EPI, int NS, int NWP = 1>
+template <int MT, int TW, int KPW, int EPI, int NS, int NWP = 1, bool F16 = false>
 __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     unsigned long long* stamps = nullptr;
     unsigned long long t_entry = 0;
@@ -167,13 +188,12 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
             for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int p2 = 0; p2 < NWP; ++p2) {
-                    const short8_t bfr = __builtin_bit_cast(short8_t, wf[p2][t][n][i]);
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int s = 0; s < NS; ++s) {
                             if (s + p2 >= NS) continue;    // (compile time) terms below the last kept bit
-                            acc[t][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(short8_t, xf[s][i][m]), bfr, acc[t][n][m], 0, 0, 0);
+                            acc[t][n][m] = mma16<F16>(xf[s][i][m], wf[p2][t][n][i], acc[t][n][m]);
                         }
                 }
     // reduction over the 8 k slices of the workgroup through LDS, fixed order
@@ -256,17 +276,17 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
         const int u = wave + 8 * k, t = u / (MT * 4), m = (u / 4) % MT, r = u & 3;
         if (u >= UNITS) break;                         // wave-uniform
         const int row = m * 16 + 4 * g + r, tile = tile0 + t, ncol = tile * 16 + l16;
-        const float sc = a.ssq_in ? rstd[row] : 1.f;
+        const float sc = (a.ssq_in ? rstd[row] : 1.f) * a.wscale;
         const bool ok = tile < ntiles && row < a.B && ncol < a.N;
         if constexpr (EPI == 1) {
             const float gte = sum[k][0] * sc, up = sum[k][1] * sc;
-            if (ok) store_split<NS>(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), gte / (1.f + expf(-gte)) * up);
+            if (ok) store_split<NS, F16>(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), gte / (1.f + expf(-gte)) * up);
         } else {
             float vv = sum[k][0] * sc + pre_bias[k];
             if constexpr (EPI == 2) vv += pre_res[k];
             if (ok) a.out[(long)row * a.ldo + ncol] = vv;
             if constexpr (EPI == 2) {
-                if (ok && a.xs_out) store_split<NS>(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), vv * pre_gn[k]);
+                if (ok && a.xs_out) store_split<NS, F16>(a.xs_out, ps_out, plane_index(row, ncol, nkb_out), vv * pre_gn[k]);
                 if (a.ssq_out) {                       // this tile's share of the row's sum of squares: over its 16 columns
                     const float q = group16_sum(ok ? vv * vv : 0.f);
                     if (l16 == 0 && tile < ntiles) a.ssq_out[row * SSQ_SLOTS + tile] = q;
@@ -277,20 +297,20 @@ __global__ __launch_bounds__(512) void skinny3_kernel(Skinny3Args a) {
     STAMP(6);
 }
 
-template <int MT, int TW, int KPW, int EPI, int NS, int NWP = 1>
+template <int MT, int TW, int KPW, int EPI, int NS, int NWP = 1, bool F16 = false>
 int launch(const Skinny3Args& a, int J, hipStream_t s) {
     constexpr int NB = EPI == 1 ? 2 : 1;
     const size_t lds = (size_t)8 * (TW * NB * MT * 4) * 64 * sizeof(float) + 32 * sizeof(float) + 16;
-    MMX_LDS_OPT_IN((skinny3_kernel<MT, TW, KPW, EPI, NS, NWP>), lds);
+    MMX_LDS_OPT_IN((skinny3_kernel<MT, TW, KPW, EPI, NS, NWP, F16>), lds);
     dim3 grid((a.ntiles + TW - 1) / TW, J);
-    hipLaunchKernelGGL((skinny3_kernel<MT, TW, KPW, EPI, NS, NWP>), grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL((skinny3_kernel<MT, TW, KPW, EPI, NS, NWP, F16>), grid, dim3(512), lds, s, a);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
 }
 
 // x fp32 [B][K] -> residual stream copy h, planes of (x * gamma) and the per-tile sums of squares of x: the form in which
 // the first projection of a decode step wants the sampler's output (the next input embedding)
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(256) void decode_prep_kernel(const float* __restrict__ x, long ldx, int B, int K, const float* __restrict__ gamma,
                                                           float* __restrict__ h, long ldh, bf16_t* __restrict__ xs, int mt,
                                                           float* __restrict__ ssq) {
@@ -302,7 +322,7 @@ __global__ __launch_bounds__(256) void decode_prep_kernel(const float* __restric
         if (col < K) {
             v = x[(long)row * ldx + col];
             if (h) h[(long)row * ldh + col] = v;
-            store_split<NS>(xs, ps, plane_index(row, col, nkb), v * (gamma ? gamma[col] : 1.f));
+            store_split<NS, F16>(xs, ps, plane_index(row, col, nkb), v * (gamma ? gamma[col] : 1.f));
         }
         const float q = group16_sum(v * v);
         if ((t0 & 15) == 0) ssq[row * SSQ_SLOTS + tile] = q;           // tiles beyond K / 16 get 0
@@ -313,8 +333,9 @@ __global__ __launch_bounds__(256) void decode_prep_kernel(const float* __restric
 
 extern "C" int mmx_decode_prep(const float* x, int64_t ldx, int B, int K, const float* gamma, float* h, int64_t ldh, void* xs,
                                float* ssq, int dtype, hipStream_t stream) {
-    MMX_CHECK_ARG(x && xs && ssq && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && K <= SSQ_SLOTS * 16 && (dtype == MMX_X3 || dtype == MMX_BF16));
-    if (dtype == MMX_X3) hipLaunchKernelGGL(decode_prep_kernel<3>, dim3(B), dim3(256), 0, stream, x, ldx, B, K, gamma, h, ldh, (bf16_t*)xs, (B + 15) / 16, ssq);
+    MMX_CHECK_ARG(x && xs && ssq && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && K <= SSQ_SLOTS * 16 && (dtype == MMX_X3 || dtype == MMX_BF16 || dtype == MMX_H2));
+    if (dtype == MMX_H2) hipLaunchKernelGGL((decode_prep_kernel<2, true>), dim3(B), dim3(256), 0, stream, x, ldx, B, K, gamma, h, ldh, (bf16_t*)xs, (B + 15) / 16, ssq);
+    else if (dtype == MMX_X3) hipLaunchKernelGGL(decode_prep_kernel<3>, dim3(B), dim3(256), 0, stream, x, ldx, B, K, gamma, h, ldh, (bf16_t*)xs, (B + 15) / 16, ssq);
     else hipLaunchKernelGGL(decode_prep_kernel<1>, dim3(B), dim3(256), 0, stream, x, ldx, B, K, gamma, h, ldh, (bf16_t*)xs, (B + 15) / 16, ssq);
     MMX_LAUNCH_CHECK();
     return MMX_OK;
@@ -326,7 +347,8 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
                            int epi, float* out, int64_t ldo, void* xs_out, const float* gamma_next, float* ssq_out,
                            int tiles_per_wg, int ksplit, float* part, int64_t part_floats, int32_t* tickets, int dtype,
                            hipStream_t stream) {
-    MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 && (dtype == MMX_X3 || dtype == MMX_X3W || dtype == MMX_BF16));
+    MMX_CHECK_ARG(xs && wp && B > 0 && B <= 32 && K > 0 && K % 32 == 0 && N > 0 &&
+                  (dtype == MMX_X3 || dtype == MMX_X3W || dtype == MMX_BF16 || dtype == MMX_H2 || dtype == MMX_H2W));
     MMX_CHECK_ARG(dtype != MMX_X3W || tiles_per_wg == 1);   // three weight planes in registers: one output tile per workgroup
     MMX_CHECK_ARG(((uintptr_t)xs % 16) == 0 && ((uintptr_t)wp % 16) == 0 && (!ssq_in || ((uintptr_t)ssq_in % 16) == 0));
     MMX_CHECK_ARG(ksplit >= 1 && ksplit <= 8 && (ksplit == 1 || (epi == 2 && part && tickets)));
@@ -338,10 +360,13 @@ extern "C" int mmx_skinny2(const void* xs, int B, int K, int N, const void* wp, 
     MMX_CHECK_ARG(ksplit == 1 || part_floats >= (int64_t)ksplit * ((ntiles + tiles_per_wg - 1) / tiles_per_wg) * tiles_per_wg * mt * 4 * 64);
     // 32-bit buffer offsets: the packed weights and the planes must stay below 2 GiB
     const double plane_bytes = (double)ntiles * (epi == 1 ? 2 : 1) * nkb * 1024.0;
-    MMX_CHECK_ARG(plane_bytes * (dtype == MMX_X3W ? 3 : 1) < 2147483000.0);
+    MMX_CHECK_ARG(plane_bytes * (dtype == MMX_X3W ? 3 : (dtype == MMX_H2W ? 2 : 1)) < 2147483000.0);
+    const bool f16 = dtype == MMX_H2 || dtype == MMX_H2W;
     Skinny3Args a{(const bf16_t*)xs, (const bf16_t*)wp, bias, ssq_in, out, (bf16_t*)xs_out, gamma_next, ssq_out, part, tickets,
-                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps, (unsigned)plane_bytes};
+                  ldo, B, K, N, ntiles, (nkb + ksplit - 1) / ksplit, eps, (unsigned)plane_bytes, f16 ? 1.0f / H2_WSCALE : 1.0f};
 #define GO(MT, TW, KPW, EPI) do { if (dtype == MMX_X3) return launch<MT, TW, KPW, EPI, 3>(a, ksplit, stream); \
+                                  if (dtype == MMX_H2) return launch<MT, TW, KPW, EPI, 2, 1, true>(a, ksplit, stream); \
+                                  if (dtype == MMX_H2W) return launch<MT, TW, KPW, EPI, 2, 2, true>(a, ksplit, stream); \
                                   if (dtype == MMX_X3W) { if constexpr (TW == 1) return launch<MT, 1, KPW, EPI, 3, 3>(a, ksplit, stream); else return MMX_EARG; } \
                                   return launch<MT, TW, KPW, EPI, 1>(a, ksplit, stream); } while (0)
 #define BY_MT(TW, KPW, EPI) do { if (mt == 1) GO(1, TW, KPW, EPI); else GO(2, TW, KPW, EPI); } while (0)

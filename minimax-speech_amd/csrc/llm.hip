@@ -575,7 +575,8 @@ struct Raw8 {
 };
 
 // OM: how the attention output is stored - 0 row-major T, 1 the packed A-fragment order of T (bf16 / fp32 builds, batch > 8),
-// 2 split planes (the split build: 3 bf16 planes hi + mid + lo in A-fragment order, csrc/decode.hip)
+// 2 split planes (the split build: 3 bf16 planes hi + mid + lo in A-fragment order, csrc/decode.hip), 3 two fp16 planes hi + lo
+// (MMX_H2, csrc/decode.hip)
 template <typename T, int OM>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
@@ -712,6 +713,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             pl[idx] = hh;
             pl[ps + idx] = mm;
             pl[2 * ps + idx] = f2bf(r1 - bf2f(mm));
+        } else if constexpr (OM == 3) {
+            const int nkb = Hq * D / 32, col = h * D + tid;
+            const long ps = (long)((nseq + 15) / 16) * nkb * 512;
+            const long idx = ((((long)(b >> 4) * nkb + (col >> 5)) * 64) + (((col & 31) >> 3) << 4) + (b & 15)) * 8 + (col & 7);
+            unsigned short* pl = reinterpret_cast<unsigned short*>(out);
+            const float v = o / L;
+            const _Float16 hh = (_Float16)v;
+            pl[idx] = __builtin_bit_cast(unsigned short, hh);
+            pl[ps + idx] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)hh));
         } else {
             out[OM == 1 ? act_packed_index<T>(b, h * D + tid, Hq * D) : (long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
         }
@@ -944,10 +954,11 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
                                int page, float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream) {
     dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
-    MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 7);
+    MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 15);
     const bool gqa_shared = !(out_packed & 2);         // bit 1: force the per-head kernel (A/B measurements, tests)
     const bool split_out = out_packed & 4;             // bit 2: output as split planes (fp32 build of the kernel only)
-    MMX_CHECK_ARG(!split_out || (dtype == MMX_F32 && !(out_packed & 1)));
+    const bool split_h2 = out_packed & 8;              // bit 3: output as two fp16 planes (MMX_H2; fp32 build of the kernel only)
+    MMX_CHECK_ARG(!(split_out || split_h2) || (dtype == MMX_F32 && !(out_packed & 1) && !(split_out && split_h2)));
     out_packed &= 1;
     const size_t max_ctx = (size_t)max_pages * page;
     (void)max_ctx;
@@ -963,7 +974,7 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
 #define DG(OPK) hipLaunchKernelGGL((decode_attn_gqa_kernel<OPK, 7>), dim3(Hkv * B), dim3(256), lds2, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (bf16_t*)kc, (bf16_t*)vc, block_table, max_pages, scale, (bf16_t*)out, ldo, B)
         if (out_packed) DG(true); else DG(false);
     } else if (dtype == MMX_BF16) { if (out_packed) DA(bf16_t, 1); else DA(bf16_t, 0); }
-    else if (dtype == MMX_F32) { if (split_out) DA(float, 2); else if (out_packed) DA(float, 1); else DA(float, 0); }
+    else if (dtype == MMX_F32) { if (split_h2) DA(float, 3); else if (split_out) DA(float, 2); else if (out_packed) DA(float, 1); else DA(float, 0); }
     else return MMX_EARG;
     MMX_LAUNCH_CHECK();
     return MMX_OK;

@@ -14,6 +14,8 @@ X2, X3 = 2, 3
 # ops.Planed tensors) and the GEMM wrappers switch the dtype code when they are handed a Planed weight; every other entry point
 # keeps seeing X2 / X3.
 X2W, X3W = 0x12, 0x13
+# fp16 planes of the LM decode step (include/mmx_hip.h MMX_H2 / MMX_H2W; mmx_skinny2, mmx_decode_prep, mmx_decode_attn only)
+H2, H2W = 4, 0x14
 ACT = {"none": 0, "lrelu": 1, "gelu": 2, "silu": 3, "mish": 4, "tanh": 5}
 TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.float32, X3: torch.float32, X2W: torch.float32, X3W: torch.float32}       # activation storage
 WEIGHT_DT = {F32: torch.float32, BF16: torch.bfloat16, X2: torch.bfloat16, X3: torch.bfloat16, X2W: torch.bfloat16, X3W: torch.bfloat16}   # weight storage

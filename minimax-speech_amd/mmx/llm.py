@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
-from ._lib import BF16, F32, TORCH_DT, WEIGHT_DT, X3, X3W, is_split
+from ._lib import BF16, F32, H2, TORCH_DT, WEIGHT_DT, X3, X3W, is_split
 from .flow import Graphed
 
 ST_POS, ST_STEP, ST_NOUT, ST_FIN, ST_MINLEN, ST_MAXLEN, ST_SEQ, ST_ERR = range(8)
@@ -52,10 +52,14 @@ class LlmEngine:
     # its 7 query heads), smaller ones the per-head kernel (more workgroups for the few sequences there are)
     gqa_min_batch = 1 << 30
     use_v2 = True            # bf16 / split builds: decode step on csrc/decode.hip (False: the round-2 projection kernel)
+    # split build, decode step: "f16x2" = activations as two fp16 planes (22 bits) and fp16 weights (csrc/decode.hip MMX_H2 / H2W:
+    # two thirds of the activation bytes and of the MFMAs of the three-bf16-plane form, 4 instead of 6 bytes per weight on an
+    # fp32 checkpoint); "bf16x3" = three bf16 planes (MMX_X3 / X3W)
+    lm_planes = "f16x2"
 
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
-                 prefix="llm.model.model", share_from=None, kv_pages=None, wplanes=False):
+                 prefix="llm.model.model", share_from=None, kv_pages=None, wplanes=False, lm_planes=None):
         """wplanes (split build X3 only): every projection weight is carried as THREE bf16 planes hi + mid + lo = the checkpoint's
         fp32 value (MMX_X3W: csrc/decode.hip for the decode step, csrc/gemm.hip for the prompt pass) instead of being rounded to
         bf16 - for checkpoints whose weights are not bf16-representable (the reference loads an fp32 llm.pt, cli/model.py:67-75).
@@ -63,7 +67,11 @@ class LlmEngine:
         self.dtype, self.tdt, self.dev = dtype, TORCH_DT[dtype], torch.device(device)
         self.wplanes = (dtype == X3 and ops.resolve_wplanes(wplanes, (v for k, v in sd.items() if v.dim() >= 2 and ("proj" in k or k == "llm_decoder.weight")))) \
             if share_from is None else share_from.wplanes
-        if self.wplanes:                                  # three weight planes in registers: one output tile per workgroup
+        planes = (lm_planes or self.lm_planes) if share_from is None else ("f16x2" if share_from.h2 else "bf16x3")
+        assert planes in ("f16x2", "bf16x3")
+        self.h2 = dtype == X3 and planes == "f16x2" and self.use_v2
+        self.ddt = H2 if self.h2 else dtype               # dtype code of the decode-step kernels (csrc/decode.hip)
+        if self.wplanes and not self.h2:                  # three bf16 weight planes in registers: one output tile per workgroup
             self.v2_cfg = dict(qkv=(1, 1), o=(1, 1), gu=(1, 1), down=(1, 8), head=(1, 1))
         self.split = is_split(dtype)                      # bf16 weights, fp32 activations split inside the MFMA products
         self.Hq, self.Hkv, self.D, self.eps = heads, kv_heads, head_dim, eps
@@ -102,13 +110,20 @@ class LlmEngine:
             wqkv = torch.cat([f(a + ".q_proj.weight"), f(a + ".k_proj.weight"), f(a + ".v_proj.weight")], 0)
             bqkv = torch.cat([f(a + ".q_proj.bias"), f(a + ".k_proj.bias"), f(a + ".v_proj.bias")], 0).contiguous()
             wgu = torch.cat([f(p + ".mlp.gate_proj.weight"), f(p + ".mlp.up_proj.weight")], 0)
-            if max_batch >= 4 or self.wplanes:
+            if max_batch >= 4 or self.wplanes or self.h2:
                 # row-major copies for the batched prompt pass (_prefill_batch): many prompts at once are an ordinary
                 # tall GEMM over weights read once, not max_batch passes of the weight-streaming decode kernels
                 self.pf_layers.append(dict(
                     wqkv=ops.pack_linear(c(wqkv), dt), wo=ops.pack_linear(c(f(a + ".o_proj.weight")), dt),
                     wgu=ops.pack_linear(c(wgu), dt), wdown=ops.pack_linear(c(f(p + ".mlp.down_proj.weight")), dt),
                     g1=f(p + ".input_layernorm.weight"), g2=f(p + ".post_attention_layernorm.weight")))
+            if self.h2:                                   # fp16 packs (w * 2^8): one plane (bf16-representable checkpoint) or hi + lo
+                pk = lambda w, ih=0: ops.pack_skinny_h2(w, planes=(2 if self.wplanes else 1), interleave_half=ih)
+                self.layers.append(dict(wqkv=pk(wqkv), bqkv=bqkv, wo=pk(f(a + ".o_proj.weight")), wgu=pk(wgu, self.I),
+                                        wdown=pk(f(p + ".mlp.down_proj.weight")),
+                                        g1=f(p + ".input_layernorm.weight"), g2=f(p + ".post_attention_layernorm.weight")))
+                del wqkv, wgu
+                continue
             self.layers.append(dict(
                 wqkv=ops.pack_skinny(c(wqkv), dtype=dt, kscale=ks(f(p + ".input_layernorm.weight"))), bqkv=bqkv,
                 wo=ops.pack_skinny(c(f(a + ".o_proj.weight")), dtype=dt),
@@ -119,7 +134,8 @@ class LlmEngine:
         self.norm_w = f(prefix + ".norm.weight")
         self.embed_tokens = f(prefix + ".embed_tokens.weight")
         if "llm_decoder.weight" in sd:
-            self.wdec = ops.pack_skinny(c(f("llm_decoder.weight")), dtype=dt, kscale=ks(self.norm_w))
+            self.wdec = ops.pack_skinny_h2(f("llm_decoder.weight"), planes=(2 if self.wplanes else 1)) if self.h2 else \
+                ops.pack_skinny(c(f("llm_decoder.weight")), dtype=dt, kscale=ks(self.norm_w))
             self.bdec = f("llm_decoder.bias")
             self.speech_emb = f("speech_embedding.weight")
             self.llm_emb = f("llm_embedding.weight")
@@ -214,7 +230,7 @@ class LlmEngine:
         if not hasattr(self, "_v2"):
             H, I, R = self.H, self.I, ops.packed_rows(self.B)
             NQ = (self.Hq + 2 * self.Hkv) * self.D
-            bf = lambda K: torch.zeros(3 if self.split else 1, R * K, dtype=torch.bfloat16, device=self.dev)
+            bf = lambda K: torch.zeros((2 if self.h2 else 3) if self.split else 1, R * K, dtype=torch.bfloat16, device=self.dev)
             J = self.v2_cfg["down"][1]
             self._v2 = dict(qkv=torch.empty(self.B, NQ, device=self.dev), xs_a=bf(H), xs_b=bf(H), xs_att=bf(self.Hq * self.D), xs_act=bf(I),
                             ssq_a=torch.zeros(32, ops.SSQ_SLOTS, device=self.dev), ssq_b=torch.zeros(32, ops.SSQ_SLOTS, device=self.dev),
@@ -227,7 +243,7 @@ class LlmEngine:
         launches per layer.  x_in -> h (residual stream, fp32) and the planes of h * gamma; every projection's epilogue
         writes the planes (and the RMSNorm partial sums) its consumer reads.  Leaves the planes of h * norm_w and the sums
         of squares of h in xs_a / ssq_a for the head."""
-        dt, H, I, c, S = self.dtype, self.H, self.I, self.v2_cfg, self._planes()
+        dt, H, I, c, S = self.ddt, self.H, self.I, self.v2_cfg, self._planes()
         NQ = (self.Hq + 2 * self.Hkv) * self.D
         qkv = S["qkv"][:B]
         ops.decode_prep(x_in, S["xs_a"], S["ssq_a"], B=B, K=H, gamma=self.layers[0]["g1"], h=h, dtype=dt)
@@ -237,8 +253,8 @@ class LlmEngine:
                         tiles_per_wg=c["qkv"][0])
             # (bf16 build: one plane = the packed A-fragment order the attention kernels already write)
             ops.decode_attn(qkv, self.inv_freq, pos, self.kc[l], self.vc[l], block_table, S["xs_att"], B=B, Hq=self.Hq,
-                            Hkv=self.Hkv, page=self.page, dtype=dt, rope_tab=self.rope_tab, per_head=(self.split or B < self.gqa_min_batch),
-                            out_split=self.split, out_packed=not self.split)
+                            Hkv=self.Hkv, page=self.page, dtype=self.dtype, rope_tab=self.rope_tab, per_head=(self.split or B < self.gqa_min_batch),
+                            out_split=("f16" if self.h2 else self.split), out_packed=not self.split)
             ops.skinny2(S["xs_att"], w["wo"], B=B, K=self.Hq * self.D, N=H, dtype=dt, epi=2, out=h, xs_out=S["xs_b"],
                         gamma_next=w["g2"], ssq_out=S["ssq_b"], tiles_per_wg=c["o"][0])
             ops.skinny2(S["xs_b"], w["wgu"], B=B, K=H, N=I, dtype=dt, ssq_in=S["ssq_b"], eps=self.eps, epi=1, xs_out=S["xs_act"],
@@ -277,8 +293,8 @@ class LlmEngine:
         if self.unfolded and B <= 32 and self.use_v2:
             S = self._planes()
             if not planes_ready:
-                ops.decode_prep(self.h, S["xs_a"], S["ssq_a"], B=B, K=self.H, gamma=self.norm_w, dtype=self.dtype)
-            ops.skinny2(S["xs_a"], self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, ssq_in=S["ssq_a"],
+                ops.decode_prep(self.h, S["xs_a"], S["ssq_a"], B=B, K=self.H, gamma=self.norm_w, dtype=self.ddt)
+            ops.skinny2(S["xs_a"], self.wdec, B=B, K=self.H, N=self.V, dtype=self.ddt, bias=self.bdec, ssq_in=S["ssq_a"],
                         eps=self.eps, epi=0, out=self.logits, tiles_per_wg=self.v2_cfg["head"][0])
         elif self.unfolded:
             ops.skinny_gemm(self.h, self.wdec, B=B, K=self.H, N=self.V, dtype=self.dtype, bias=self.bdec, rs=True,
@@ -371,9 +387,6 @@ class LlmEngine:
         self.release(slot)
         self._set_pages(slot, L + (max_len if ahead is None else min(ahead, max_len)))
         x = x.to(self.dev, torch.float32).contiguous()
-        if self.wplanes:
-            raise NotImplementedError("admit() with weight planes: the prompt chunks run on the round-2 projection kernel, which has no "
-                                      "weight-plane form; start() (the windowed-GEMM prompt pass) does")
         for c0 in range(0, L - 1, 64):
             self._prefill_chunk(x[c0:min(L - 1, c0 + 64)], c0, slot)
         self.x_in[slot].copy_(x[L - 1])
@@ -405,7 +418,7 @@ class LlmEngine:
             assert x.shape[0] + max_lens[b] <= self.max_pages * self.page, "sequence exceeds the KV cache"
             self.release(b)
             self._set_pages(b, x.shape[0] + min(max_lens[b], self.reserve_ahead))
-        if (B >= 4 or self.wplanes) and self.pf_layers:
+        if (B >= 4 or self.wplanes or self.h2) and self.pf_layers:
             self._prefill_batch(lm_inputs)
             lm_inputs = []
         for b, x in enumerate(lm_inputs):
@@ -439,36 +452,48 @@ class LlmEngine:
         for b, x in enumerate(lm_inputs):
             h[b, :Ls[b]].copy_(x)
         h = h.reshape(R, H)
-        a = torch.empty(R, H, dtype=self.tdt, device=self.dev)
-        qkv = torch.empty(R, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
-        q = torch.empty(R, self.Hq * self.D, dtype=self.tdt, device=self.dev)
-        att = torch.empty(R, self.Hq * self.D, dtype=self.tdt, device=self.dev)
-        gu = torch.empty(R, 2 * I, device=self.dev)
-        act = torch.empty(R, I, dtype=self.tdt, device=self.dev)
-        pos = torch.zeros(B, dtype=torch.int32, device=self.dev)
-        for l, (w, ws) in enumerate(zip(self.pf_layers, self.layers)):
-            ops.rownorm(h, w["g1"], None, self.eps, rows=R, C_=H, rms=True, out_act=a, dtype=dt)
-            ops.linear(a, w["wqkv"], H, dtype=dt, bias=ws["bqkv"], out_f32=qkv)
-            ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], self.block_table, B=B, rows=Lm,
-                              Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
-            ops.paged_attn(q, pos, self.kc[l], self.vc[l], self.block_table, att, B=B, rows=Lm, Hq=self.Hq,
-                           Hkv=self.Hkv, page=self.page, dtype=dt)
-            ops.linear(att, w["wo"], self.Hq * self.D, dtype=dt, residual=h, out_f32=h)
-            ops.rownorm(h, w["g2"], None, self.eps, rows=R, C_=H, rms=True, out_act=a, dtype=dt)
-            ops.linear(a, w["wgu"], H, dtype=dt, out_f32=gu)
-            ops.swiglu(gu, act, rows=R, I=I, dtype=dt)
-            ops.linear(act, w["wdown"], I, dtype=dt, residual=h, out_f32=h)
+        self._gemm_layers(h, B, Lm, torch.zeros(B, dtype=torch.int32, device=self.dev), self.block_table)
         last = torch.tensor([b * Lm + Ls[b] - 1 for b in range(B)], dtype=torch.long, device=self.dev)
         hl = h.index_select(0, last)
         self.h[:B].copy_(hl)
         self.h_act[:B].copy_(hl)
         self.state[ST_POS].copy_(torch.tensor([L - 1 for L in Ls], dtype=torch.int32))
 
+    def _gemm_layers(self, h, B, Lm, pos, block_table):
+        """The layers over B x Lm prompt rows h [B * Lm, H] (fp32, in place) on the windowed GEMM: RMSNorm, projections (weights read
+        once for all rows; weight planes when the packs are ops.Planed), RoPE + KV store + causal attention over the paged cache
+        from position pos[b], SwiGLU - 9 launches per layer."""
+        dt, H, I = self.dtype, self.H, self.I
+        R = B * Lm
+        a = torch.empty(R, H, dtype=self.tdt, device=self.dev)
+        qkv = torch.empty(R, (self.Hq + 2 * self.Hkv) * self.D, device=self.dev)
+        q = torch.empty(R, self.Hq * self.D, dtype=self.tdt, device=self.dev)
+        att = torch.empty(R, self.Hq * self.D, dtype=self.tdt, device=self.dev)
+        gu = torch.empty(R, 2 * I, device=self.dev)
+        act = torch.empty(R, I, dtype=self.tdt, device=self.dev)
+        for l, (w, ws) in enumerate(zip(self.pf_layers, self.layers)):
+            ops.rownorm(h, w["g1"], None, self.eps, rows=R, C_=H, rms=True, out_act=a, dtype=dt)
+            ops.linear(a, w["wqkv"], H, dtype=dt, bias=ws["bqkv"], out_f32=qkv)
+            ops.rope_kv_store(qkv, self.inv_freq, pos, q, self.kc[l], self.vc[l], block_table, B=B, rows=Lm,
+                              Hq=self.Hq, Hkv=self.Hkv, page=self.page, dtype=dt)
+            ops.paged_attn(q, pos, self.kc[l], self.vc[l], block_table, att, B=B, rows=Lm, Hq=self.Hq,
+                           Hkv=self.Hkv, page=self.page, dtype=dt)
+            ops.linear(att, w["wo"], self.Hq * self.D, dtype=dt, residual=h, out_f32=h)
+            ops.rownorm(h, w["g2"], None, self.eps, rows=R, C_=H, rms=True, out_act=a, dtype=dt)
+            ops.linear(a, w["wgu"], H, dtype=dt, out_f32=gu)
+            ops.swiglu(gu, act, rows=R, I=I, dtype=dt)
+            ops.linear(act, w["wdown"], I, dtype=dt, residual=h, out_f32=h)
+
     def _prefill_chunk(self, xc, pos0, b):
         """<= 64 prompt rows of sequence b through the layers at cache position pos0.  One hipGraph per chunk length over
         static staging buffers: a 50-row prompt is 144 launches, which the host issues in ~1.5 ms eagerly (32 prompts
         in front of a batch: ~50 ms with the GPU mostly idle) and the graph replays in ~0.4 ms."""
         rows = xc.shape[0]
+        if self.h2 or self.wplanes:
+            # the decode packs are fp16 / weight planes (csrc/decode.hip only): prompt rows go through the windowed GEMM
+            hc = xc.to(self.dev, torch.float32).clone()
+            self._gemm_layers(hc, 1, rows, torch.tensor([pos0], dtype=torch.int32, device=self.dev), self.block_table[b:b + 1].contiguous())
+            return hc, hc.to(self.tdt)
         if not self.use_graphs:
             hc = xc.clone()
             hca = hc.to(self.tdt)

@@ -391,20 +391,40 @@ def plane_elems(B, K):
     return packed_rows(B) * K
 
 
-def split_planes(x):
-    """Host-side statement of the split-plane format (tests): x fp32 [B, K] -> bf16 [3, plane_elems]."""
+def split_planes(x, f16=False):
+    """Host-side statement of the split-plane format (tests): x fp32 [B, K] -> bf16 [3, plane_elems] (hi + mid + lo), or with
+    f16 the two fp16 planes hi + lo of MMX_H2, returned as their bit patterns in a bf16-typed tensor [2, plane_elems]."""
     B, K = x.shape
     out, r = [], x.float()
-    for _ in range(3):
-        t = r.to(torch.bfloat16)
-        out.append(pack_act(t, BF16))
+    for _ in range(2 if f16 else 3):
+        t = r.to(torch.float16 if f16 else torch.bfloat16)
+        out.append(pack_act(t.view(torch.bfloat16) if f16 else t, BF16))
         r = r - t.float()
     return torch.stack(out)
 
 
-def merge_planes(xs, B, K):
-    """bf16 [3, plane_elems] -> fp32 [B, K] (hi + mid + lo)."""
+def merge_planes(xs, B, K, f16=False):
+    """bf16 [3, plane_elems] -> fp32 [B, K] (hi + mid + lo); f16: the two fp16 planes (bit patterns in a bf16-typed tensor)."""
+    if f16:
+        return sum(unpack_act(xs[s], B, K, BF16).contiguous().view(torch.float16).float() for s in range(2))
     return sum(unpack_act(xs[s], B, K, BF16).float() for s in range(3))
+
+
+H2_WSCALE = 256.0            # csrc/decode.hip: the fp16 forms store weights * 2^8
+
+
+def pack_skinny_h2(w, *, planes=1, interleave_half=0):
+    """[N, K] fp32 weights -> the MMX_H2 (planes = 1: for bf16-representable checkpoints, exact) or MMX_H2W (planes = 2: hi + lo of
+    an fp32 checkpoint, Planed) pack of mmx_skinny2: fp16 values of w * 2^8 in the MFMA-fragment order (the pack is a
+    permutation of 16-bit words, so the bf16 packer carries the fp16 bit patterns)."""
+    ws = w.float() * H2_WSCALE
+    assert float(ws.abs().max()) < 65504.0, "weight out of the fp16 range of MMX_H2"
+    out, r = [], ws
+    for _ in range(planes):
+        t = r.to(torch.float16)
+        out.append(pack_skinny(t.view(torch.bfloat16).contiguous(), dtype=L.X3, interleave_half=interleave_half))
+        r = r - t.float()
+    return out[0] if planes == 1 else torch.cat(out).as_subclass(Planed)
 
 
 def decode_prep(x, xs, ssq, *, B, K, gamma=None, h=None, dtype=L.X3):
@@ -416,7 +436,7 @@ def skinny2(xs, wp, *, B, K, N, dtype, bias=None, ssq_in=None, eps=1e-6, epi=0, 
             ssq_out=None, tiles_per_wg=1, ksplit=1, part=None, tickets=None):
     """The split build's decode-step projection on split-plane activations (include/mmx_hip.h mmx_skinny2)."""
     if isinstance(wp, Planed):
-        dtype = L.X3W
+        dtype = L.H2W if dtype in (L.H2, L.H2W) else L.X3W
     check(load().mmx_skinny2(_p(xs), B, K, N, _p(wp), _p(bias), _p(ssq_in), C.c_float(eps), epi, _p(out),
                              i64(ldo if ldo is not None else N), _p(xs_out), _p(gamma_next), _p(ssq_out), tiles_per_wg, ksplit,
                              _p(part), i64(part.numel() if part is not None else 0), _p(tickets), dtype, stream()), "mmx_skinny2")
@@ -438,10 +458,11 @@ def paged_attn(q, pos, kc, vc, block_table, out, *, B, rows, Hq, Hkv, page, dtyp
 def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None, out_packed=False,
                 per_head=False, out_split=False):
     """per_head: the one-workgroup-per-query-head kernel even where the GQA-shared one applies (measurements, tests).
-    out_split: `out` receives split planes (the split build's decode step, include/mmx_hip.h)."""
+    out_split: `out` receives split planes (the split build's decode step, include/mmx_hip.h): True = three bf16 planes,
+    "f16" = two fp16 planes (MMX_H2)."""
     check(load().mmx_decode_attn(_p(qkv), i64((Hq + 2 * Hkv) * 64), B, Hq, Hkv, 64, _p(inv_freq), _p(rope_tab), _p(pos), _p(kc),
                                  _p(vc), _p(block_table), block_table.shape[1], page, C.c_float(0.125), _p(out),
-                                 i64(Hq * 64), dtype, int(bool(out_packed)) | (2 if per_head else 0) | (4 if out_split else 0), stream()), "mmx_decode_attn")
+                                 i64(Hq * 64), dtype, int(bool(out_packed)) | (2 if per_head else 0) | (8 if out_split == "f16" else (4 if out_split else 0)), stream()), "mmx_decode_attn")
 
 
 def swiglu(gu, out, *, rows, I, dtype):

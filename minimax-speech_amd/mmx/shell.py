@@ -65,12 +65,12 @@ class EngineHost(nn.Module):
                 m._invalidate()
         return self
 
-    def split_parity(self, on=True, weight_planes="auto"):
+    def split_parity(self, on=True, weight_planes="auto", chosen=True):
         """The split build (mmx/_lib.py X2 / X3): bf16 weight stream, fp32 activations carried as bf16 terms inside the MFMA
         products - token ids and waveform as the fp32 build's, at (nearly) the bf16 build's speed."""
         for m in self.modules():
             if isinstance(m, EngineHost):
-                m.compute_dtype, m.dtype_chosen, m.weight_planes = (2 if on else 1), True, weight_planes
+                m.compute_dtype, m.dtype_chosen, m.weight_planes = (2 if on else 1), chosen, weight_planes
                 m._invalidate()
         return self
 

@@ -34,7 +34,7 @@ class CosyVoice2Model:
         self.fp16 = fp16
         for m in (llm, flow, hift):
             if hasattr(m, "split_parity") and not any(getattr(x, "dtype_chosen", False) for x in m.modules()):
-                m.split_parity(not fp16)
+                m.split_parity(not fp16, chosen=False)
         self.token_hop_len = 25                           # must match the training static_chunk_size
         self.mel_cache_len = 8                            # model.py:258: frames two passes overlap by
         self.hop = int(np.prod(getattr(hift, "decoder_rates", [5, 4, 4, 3, 2])))   # samples per latent frame

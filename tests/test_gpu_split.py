@@ -676,3 +676,100 @@ def test_attn_flash_xs_presplit_vs_float64(B, T, chunk, ragged):
             n = lens[b0 + j]
             a, r = out[b0 + j, :n], ref[j, :n]
             assert torch.isfinite(a).all() and rel_err(a, r) < 4e-5, (b0 + j, rel_err(a, r))
+
+
+# ------------------------------------------------------------------------------------------------ fp16 planes of the LM decode step
+@pytest.mark.parametrize("wp", [1, 2])
+@pytest.mark.parametrize("B,K,N,epi,rs,tw,J", [(1, 896, 1152, 0, True, 1, 1), (32, 896, 1152, 0, True, 1, 1), (17, 896, 896, 2, False, 1, 1),
+                                               (32, 896, 4864, 1, True, 2, 1), (32, 4864, 896, 2, False, 2, 8), (3, 4864, 896, 2, False, 1, 8),
+                                               (32, 896, 6564, 0, True, 2, 1)])
+def test_skinny2_fp16_planes_vs_float64(B, K, N, epi, rs, tw, J, wp):
+    """mmx_skinny2 with MMX_H2 / MMX_H2W: activations as TWO fp16 planes (22 significant bits), fp16 weights stored * 2^8 - one
+    plane for bf16-representable weights (exact), hi + lo for general fp32 weights - on v_mfma_f32_16x16x32_f16, against float64
+    on the same values.  Stated: 3e-6 of the output range (the three-bf16-plane form's bound; 22 bits against 24 is 2.4e-7
+    relative per operand).  The epilogue's plane outputs (fp16 hi + lo of out * gamma_next, of the SwiGLU) are checked too."""
+    from mmx import ops
+    from mmx._lib import H2
+    g = torch.Generator().manual_seed(B * 31 + N + J + wp)
+    x = (torch.randn(B, K, generator=g) * 3).cuda()
+    w = (torch.randn((2 * N if epi == 1 else N), K, generator=g) / math.sqrt(K))
+    w = (w.to(torch.bfloat16).float() if wp == 1 else w).cuda()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).cuda() if rs else None
+    gnext = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda() if epi == 0 else None
+    wpk = ops.pack_skinny_h2(w.contiguous(), planes=wp, interleave_half=(N if epi == 1 else 0))
+    assert isinstance(wpk, ops.Planed) == (wp == 2)
+    xg = x * gam if rs else x
+    xs = ops.split_planes(xg, f16=True)
+    assert rel_err(ops.merge_planes(xs, B, K, f16=True), xg) < 3e-7            # two fp16 terms: 22 bits
+    ssq = _ssq_table(x) if rs else None
+    acc = xg.double() @ w.double().t()
+    if rs:
+        acc = acc * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-6)
+    res = torch.randn(B, N, generator=g).cuda()
+    ref = acc + bias.double() if epi == 0 else (F.silu(acc[:, :N]) * acc[:, N:] if epi == 1 else res.double() + acc)
+    nt = (N + 15) // 16
+    part = torch.full((J * nt * ops.packed_rows(B) // 4 * 64,), float("nan"), device="cuda") if J > 1 else None
+    tickets = torch.zeros(nt, dtype=torch.int32, device="cuda") if J > 1 else None
+    out = res.clone() if epi == 2 else (torch.full((B, N), float("nan"), device="cuda") if epi == 0 else None)
+    xs_out = torch.zeros(2, ops.plane_elems(B, N), dtype=torch.bfloat16, device="cuda") if epi != 0 and N % 32 == 0 else None
+    ops.skinny2(xs, wpk, B=B, K=K, N=N, dtype=H2, bias=bias, ssq_in=ssq, eps=1e-6, epi=epi, out=out, xs_out=xs_out,
+                gamma_next=(gnext if epi == 2 else None), ssq_out=(torch.zeros(32, 64, device="cuda") if epi == 2 else None),
+                tiles_per_wg=tw, ksplit=J, part=part, tickets=tickets)
+    got = ops.merge_planes(xs_out, B, N, f16=True) if epi == 1 else out
+    assert rel_err(got, ref) < 3e-6, rel_err(got, ref)
+    if epi == 2:
+        assert rel_err(ops.merge_planes(xs_out, B, N, f16=True), got.double() * gnext.double()) < 3e-7
+
+
+def test_decode_prep_and_attention_fp16_planes():
+    """mmx_decode_prep and the decode attention's output as two fp16 planes (MMX_H2) against the same kernels' fp32 outputs."""
+    from mmx import ops
+    from mmx._lib import H2
+    g = torch.Generator().manual_seed(9)
+    B, K = 19, 896
+    x = torch.randn(B, K, generator=g).cuda()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).cuda()
+    xs = torch.zeros(2, ops.plane_elems(B, K), dtype=torch.bfloat16, device="cuda")
+    ssq, h = torch.zeros(32, 64, device="cuda"), torch.zeros(B, K, device="cuda")
+    ops.decode_prep(x, xs, ssq, B=B, K=K, gamma=gam, h=h, dtype=H2)
+    assert torch.equal(h, x) and rel_err(ops.merge_planes(xs, B, K, f16=True), x.double() * gam.double()) < 3e-7
+    assert rel_err(ssq[:B, :56], _ssq_table(x)[:B, :56]) < 1e-6
+    Hq, Hkv, D, page, P = 14, 2, 64, 16, 8
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, generator=g).cuda()
+    pos = torch.randint(1, page * P - 1, (B,), generator=g).to(torch.int32).cuda()
+    kc = torch.randn(B * P + 1, Hkv, page, D, generator=g).cuda()
+    vc = torch.randn(B * P + 1, Hkv, page, D, generator=g).cuda()
+    bt = torch.arange(B * P, dtype=torch.int32).reshape(B, P).cuda()
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2).float() / D))).cuda()
+    o1 = torch.zeros(B, Hq * D, device="cuda")
+    o2 = torch.zeros(2, ops.plane_elems(B, Hq * D), dtype=torch.bfloat16, device="cuda")
+    ops.decode_attn(qkv, inv, pos, kc.clone(), vc.clone(), bt, o1, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=0, per_head=True)
+    ops.decode_attn(qkv, inv, pos, kc.clone(), vc.clone(), bt, o2, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=0, per_head=True, out_split="f16")
+    assert rel_err(ops.merge_planes(o2, B, Hq * D, f16=True), o1) < 3e-7
+
+
+def test_lm_decode_fp16_planes_equals_bf16_planes():
+    """The decode step on two fp16 planes (LlmEngine.lm_planes = "f16x2", the default) produces the log-probs of the same steps on
+    three bf16 planes to fp32-level rounding and the same ids, at batch 1 and batch 32, on a bf16-representable and on an fp32
+    checkpoint (weight planes: two fp16 planes against three bf16 planes)."""
+    from mmx import shapes, synth
+    from mmx.llm import LlmEngine
+    z = torch.zeros(1, 0, dtype=torch.long, device="cuda")
+    g = torch.Generator().manual_seed(4)
+    for kind in ("bf16", "fp32"):
+        sd = synth.synth_state_dict(shapes.llm_manifest(layers=2), 0, kind=kind)
+        for B in (1, 32):
+            texts = [torch.randint(0, 151936, (1, 6 + b % 5), generator=g).cuda() for b in range(B)]
+            lp = {}
+            for planes in ("bf16x3", "f16x2"):
+                eng = LlmEngine(sd, dtype=X3, max_batch=B, max_ctx=128, use_graphs=False, lm_planes=planes, wplanes="auto")
+                assert eng.h2 == (planes == "f16x2") and eng.wplanes == (kind == "fp32")
+                xs = [eng.build_lm_input(t, z, z) for t in texts]
+                eng.start(xs, [12] * B, [12] * B, seed=3, want_logp=True)
+                for _ in range(6):
+                    eng.step()
+                lp[planes] = (eng.logp.clone(), eng.tokens())
+            d = (lp["f16x2"][0] - lp["bf16x3"][0]).abs().max().item()
+            print(f"decode step, fp16 planes vs bf16 planes, {kind} checkpoint, batch {B}: max |dlogp| {d:.3e}")
+            assert d < 2e-4 and lp["f16x2"][1] == lp["bf16x3"][1]
