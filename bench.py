@@ -355,6 +355,7 @@ def main():
                     help="kind of the synthetic checkpoint (mmx/synth.py): bf16 = bf16-representable weights; fp32 = general fp32 weights and "
                          "trained-like weight norms, what the reference's loaders hand over - the split build then carries weight planes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the live kernel measurements after the timed region (profiler passes over the step itself)")
     ap.add_argument("--flow-bm-min", type=int, default=0, help="tuning: smallest tile height of the fused flow kernels")
     ap.add_argument("--flow-bm", type=int, default=0, help="cap the fused flow kernels' tile height (tuning: 32 leaves registers for co-resident decode waves)")
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"], help="fp8: estimator attention on the fp8 MFMA (config 5)")
@@ -494,6 +495,11 @@ def main():
         step()
     for _ in range(a.warmup):
         step()
+    if os.environ.get("MMX_DUMP_MAPS"):
+        # profiler runs: the process map at the start of the timed region (every library is loaded by now), so that the frames of
+        # a fault report can be put back on their libraries (the rocprofv3 --pmc abort of round 3 could not be: no map was kept)
+        with open("/proc/self/maps") as src, open(os.environ["MMX_DUMP_MAPS"], "w") as dst:
+            dst.write(src.read())
     shape_log = []
     flows = getattr(eng, "_flows", None) or ([eng.flow] if hasattr(eng, "flow") else [])
     for fl in flows:                                       # the (n, T) of every flow group of the timed steps, for `roofline`
@@ -565,7 +571,7 @@ def main():
                 r["roofline_attn"] = measure_attn_kernel(e, log, nsteps)
             return r
 
-        if world == 1:
+        if world == 1 and not a.no_roofline:
             # `roofline`: the LM decode step as a whole - its projection family is the largest share of the step's GPU time
             # (profiles/r04_bench*_kernel_stats.csv) and the decode loop is the step's critical path; the other objects are the
             # largest single projection (roofline_lm) and the two flow kernels (roofline_flow / _attn)

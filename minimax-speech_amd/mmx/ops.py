@@ -35,12 +35,13 @@ def weight_planes(w: torch.Tensor, n: int):
 
 def resolve_wplanes(wplanes, weights) -> bool:
     """wplanes of an engine constructor: True / False, or "auto" = True exactly when one of `weights` (the matrix-shaped weights
-    as the kernels will see them, weight norm folded) is not bf16-representable, i.e. when rounding at load would change it."""
+    as the kernels will see them, weight norm folded) is not bf16-representable, i.e. when rounding at load would change it
+    (by more than the few fp32 ulps a weight-norm fold g * v / ||v|| with g = ||v|| leaves on a bf16-representable v)."""
     if wplanes != "auto":
         return bool(wplanes)
     for w in weights:
         w = w.detach().float()
-        if not torch.equal(w.to(torch.bfloat16).float(), w):
+        if bool(((w - w.to(torch.bfloat16).float()).abs() > 2.4e-7 * w.abs()).any()):
             return True
     return False
 
