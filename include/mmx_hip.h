@@ -220,6 +220,11 @@ int mmx_conv_cin1(const float* x, int64_t x_bs, int T, int C, int k, const float
  * z = m + noise * exp(logs).  All outputs fp32 [rows][D]. */
 int mmx_vae_sample(const float* ml, const float* noise, int64_t rows, int D, float* z, float* m, float* logs,
                    hipStream_t stream);
+/* Cache prefetch: reads the byte ranges [p_i, p_i + n_i) (16-byte aligned, n_i multiples of 16; NULL = none) with default-policy
+ * loads and keeps nothing, so the lines are left in L2 / the Infinity Cache for a later launch (the next LM layer's weights while
+ * the current layer computes: a side stream of the captured decode step).  sink: 4 writable bytes (never written in practice). */
+int mmx_prefetch4(const void* p0, int64_t n0, const void* p1, int64_t n1, const void* p2, int64_t n2, const void* p3, int64_t n3,
+                  void* sink, int workgroups, hipStream_t stream);
 /* Speed change (speech/cosyvoice/cli/model.py:312-314): x fp32 [rows][T] -> out fp32 [rows][T2], linear interpolation in time
  * with torch's F.interpolate(mode="linear", align_corners=False) sample positions. */
 int mmx_resample_linear(const float* x, int64_t rows, int T, int T2, float* out, hipStream_t stream);

@@ -331,6 +331,42 @@ extern "C" int mmx_vae_sample(const float* ml, const float* noise, int64_t rows,
     return MMX_OK;
 }
 
+// ---------------------------------------------------------------------------- weight prefetch into L2 / Infinity Cache
+// Reads up to four byte ranges with default-policy 16-byte loads and keeps nothing: the lines stay in the issuing XCD's L2 and in
+// the memory-side Infinity Cache.  Launched on a SIDE stream of the captured LM decode step with the NEXT layer's packed weights
+// while the current layer computes (mmx/llm.py: LlmEngine.prefetch), so that the next layer's projections - one dependent round of
+// weight loads each - find their 30 MB in the Infinity Cache (545 cycles, ~10 TB/s) instead of HBM (900 cycles).  The loaded
+// words are folded into one value that is stored only if it equals a sentinel no data produces (the loads stay, nothing is written).
+struct PrefetchArgs { const uint4* p[4]; long n[4]; unsigned* sink; };
+__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchArgs a) {
+    unsigned acc = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long n16 = a.n[r] >> 4;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256 * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long j = i + (long)u * gridDim.x * 256;
+                v[u] = j < n16 ? a.p[r][j] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    if (acc == 0x9E3779B9u && a.sink) *a.sink = acc;   // never true for packed weights in practice; harmless if it is
+}
+extern "C" int mmx_prefetch4(const void* p0, int64_t n0, const void* p1, int64_t n1, const void* p2, int64_t n2, const void* p3,
+                             int64_t n3, void* sink, int workgroups, hipStream_t stream) {
+    MMX_CHECK_ARG(workgroups > 0 && workgroups <= 4096 && n0 >= 0 && n1 >= 0 && n2 >= 0 && n3 >= 0);
+    MMX_CHECK_ARG(((uintptr_t)p0 % 16) == 0 && ((uintptr_t)p1 % 16) == 0 && ((uintptr_t)p2 % 16) == 0 && ((uintptr_t)p3 % 16) == 0);
+    PrefetchArgs a{{(const uint4*)p0, (const uint4*)p1, (const uint4*)p2, (const uint4*)p3}, {p0 ? n0 : 0, p1 ? n1 : 0, p2 ? n2 : 0, p3 ? n3 : 0},
+                   (unsigned*)sink};
+    hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, stream, a);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
 // ---------------------------------------------------------------------------- linear resampling in time (speed change)
 // F.interpolate(x [rows][T], size=T2, mode="linear", align_corners=False) as torch's CPU kernel computes it: scale = T / T2 in
 // fp32, src = scale * (t + 0.5) - 0.5 clamped at 0, out = (1 - w) * x[i0] + w * x[min(i0 + 1, T - 1)], w = src - i0
@@ -453,4 +489,4 @@ extern "C" int mmx_act_rows(const float* x, int64_t rows, int C, int act, const 
     return MMX_OK;
 }
 
-extern "C" int mmx_abi_version(void) { return 7; }
+extern "C" int mmx_abi_version(void) { return 8; }

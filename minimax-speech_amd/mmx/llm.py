@@ -56,6 +56,10 @@ class LlmEngine:
     # two thirds of the activation bytes and of the MFMAs of the three-bf16-plane form, 4 instead of 6 bytes per weight on an
     # fp32 checkpoint); "bf16x3" = three bf16 planes (MMX_X3 / X3W)
     lm_planes = "f16x2"
+    # weight prefetch: a side stream of the (captured) decode step touches layer l + 1's packed weights while layer l computes
+    # (csrc/elementwise.hip prefetch_kernel), so that the next projections read them from the Infinity Cache; 0 = off, else the
+    # number of workgroups of the prefetch launch
+    prefetch = 0
 
     def __init__(self, sd: Dict[str, torch.Tensor], dtype=BF16, device="cuda", max_batch=1, max_ctx=2048, page=16,
                  heads=14, kv_heads=2, head_dim=64, rope_theta=1e6, eps=1e-6, speech_token_size=6561, use_graphs=True,
@@ -247,7 +251,20 @@ class LlmEngine:
         NQ = (self.Hq + 2 * self.Hkv) * self.D
         qkv = S["qkv"][:B]
         ops.decode_prep(x_in, S["xs_a"], S["ssq_a"], B=B, K=H, gamma=self.layers[0]["g1"], h=h, dtype=dt)
+        pf = int(self.prefetch)
+        if pf:
+            if not hasattr(self, "_pf_side"):
+                self._pf_side = torch.cuda.Stream(device=self.dev)
+                self._pf_sink = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            cur, side = torch.cuda.current_stream(), self._pf_side
         for l, w in enumerate(self.layers):
+            if pf:                                        # fork: the next layer's weights (the head's after the last layer)
+                nxt = self.layers[l + 1] if l + 1 < len(self.layers) else None
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    ops.prefetch4([nxt["wqkv"], nxt["wo"], nxt["wgu"], nxt["wdown"]] if nxt is not None else [self.wdec], self._pf_sink, pf)
             g_next = self.layers[l + 1]["g1"] if l + 1 < len(self.layers) else self.norm_w
             ops.skinny2(S["xs_a"], w["wqkv"], B=B, K=H, N=NQ, dtype=dt, bias=w["bqkv"], ssq_in=S["ssq_a"], eps=self.eps, epi=0, out=qkv,
                         tiles_per_wg=c["qkv"][0])
@@ -261,6 +278,10 @@ class LlmEngine:
                         tiles_per_wg=c["gu"][0])
             ops.skinny2(S["xs_act"], w["wdown"], B=B, K=I, N=H, dtype=dt, epi=2, out=h, xs_out=S["xs_a"], gamma_next=g_next,
                         ssq_out=S["ssq_a"], tiles_per_wg=c["down"][0], ksplit=c["down"][1], part=S["part"], tickets=S["tickets"])
+        if pf:                                            # join: the side stream's last launch belongs to this step
+            ev = torch.cuda.Event()
+            ev.record(side)
+            cur.wait_event(ev)
 
     def _layers_split(self, h, B, rows, pos, block_table):
         """The split build of _layers: every GEMM input is the fp32 tensor itself (row-major), the RMSNorm gains ride as

@@ -202,6 +202,14 @@ def vae_sample(ml, noise, z, m, logs, *, rows, D):
     check(load().mmx_vae_sample(_p(ml), _p(noise), i64(rows), D, _p(z), _p(m), _p(logs), stream()), "mmx_vae_sample")
 
 
+def prefetch4(tensors, sink, workgroups=128):
+    """mmx_prefetch4: leaves the bytes of up to four tensors in L2 / the Infinity Cache (a side stream of the LM decode step)."""
+    t = list(tensors) + [None] * (4 - len(tensors))
+    nb = lambda x: 0 if x is None else (x.numel() * x.element_size()) // 16 * 16
+    check(load().mmx_prefetch4(_p(t[0]), i64(nb(t[0])), _p(t[1]), i64(nb(t[1])), _p(t[2]), i64(nb(t[2])), _p(t[3]), i64(nb(t[3])),
+                               _p(sink), workgroups, stream()), "mmx_prefetch4")
+
+
 def resample_linear(x, T2):
     """x fp32 [..., T] -> [..., T2]: F.interpolate(mode="linear", align_corners=False) along the last axis (mmx_resample_linear)."""
     x = x.contiguous()

@@ -30,10 +30,15 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--v1", action="store_true", help="split build: the round-2 projection kernel instead of csrc/decode.hip")
     ap.add_argument("--cfg", default="", help="split build: LlmEngine.v2_cfg overrides, e.g. gu=1,1:down=2,8")
+    ap.add_argument("--prefetch", type=int, default=0, help="workgroups of the per-layer weight prefetch on a side stream (LlmEngine.prefetch)")
+    ap.add_argument("--lm-planes", default=None, choices=["f16x2", "bf16x3"])
     a = ap.parse_args()
     dt = {"bf16": 1, "f32": 0, "x": 2}[a.dtype]
     from mmx.llm import LlmEngine
     LlmEngine.use_v2 = not a.v1
+    LlmEngine.prefetch = a.prefetch
+    if a.lm_planes:
+        LlmEngine.lm_planes = a.lm_planes
     if a.cfg:
         LlmEngine.v2_cfg = dict(LlmEngine.v2_cfg, **{kv.split("=")[0]: tuple(int(v) for v in kv.split("=")[1].split(",")) for kv in a.cfg.split(":")})
     eng = DecodeOnly(synth.synth_state_dict(shapes.llm_manifest(), 0), synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0),
