@@ -180,6 +180,13 @@ int mmx_attn_flash_bf16(const void* q, int64_t ldq, int64_t q_bs, const void* k,
                         const void* vt, int64_t ldvt, int64_t vt_bs, void* out, int64_t ldo, int64_t o_bs,
                         int B, int H, int T, float scale, const float* keymask, int64_t km_bs, int chunk, int q_begin,
                         const int32_t* klen, hipStream_t stream);
+/* Conformer rel-pos attention of the split build (speech/cosyvoice/transformer/attention.py:215-330 incl. rel_shift): fp32
+ * q / k / v rows, pos fp32 [2T - 1][ldp] = linear_pos(ESPnet table), pos_u / pos_v fp32 [H * 64]; every product as bf16
+ * hi*hi + lo*hi + hi*lo on the MFMA (as mmx_attn_flash_x); klen int32 [B] valid rows per batch member or NULL; out fp32. */
+int mmx_attn_relpos_x(const float* q, int64_t ldq, int64_t q_bs, const float* k, int64_t ldk, int64_t k_bs, const float* v,
+                      int64_t ldv, int64_t v_bs, const float* pos, int64_t ldp, const float* pos_u, const float* pos_v,
+                      float* out, int64_t ldo, int64_t o_bs, int B, int H, int T, float scale, int chunk, const int32_t* klen,
+                      hipStream_t stream);
 /* mmx_attn_flash_xs: the split build's attention on operands the PRODUCER has already split (MmxEstNext, MMX_X2 with
  * vt_out): qk bf16 [B][T][ldqk >= 2048] = [hi Q | hi K | lo Q | lo K], vt bf16 [B][2][512][ldvt], out fp32 [B][T][ldo].
  * mmx_attn_flash_x: the same contract on fp32 operands:

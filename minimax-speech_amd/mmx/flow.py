@@ -328,6 +328,13 @@ class FlowEngine:
             ops.attn_relpos_bf16(qk, qk[:, 512:], vt, p, lw["pu"], lw["pv"], ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp,
                                  ldp=512, ldo=512, q_bs=T * 1024, k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125,
                                  chunk=chunk, klen=klen)
+        elif self.split and getattr(self, "enc_attn", "mfma") == "mfma" and (klen is not None or keymask is None):
+            # split build: the same attention on the MFMA with every operand as bf16 hi + lo (mmx_attn_relpos_x; prefix masks
+            # only: the batched encoder's klen)
+            qkv = self._new(R, 1536)
+            ops.linear(hn, lw["wqkv"], 512, dtype=dt, bias=lw["bqkv"], out_act=qkv)
+            ops.attn_relpos_x(qkv, qkv[:, 512:], qkv[:, 1024:], p, lw["pu"], lw["pv"], ao, B=B, H=8, T=T, ldq=1536, ldk=1536, ldv=1536,
+                              ldp=512, ldo=512, q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, chunk=chunk, klen=klen)
         else:
             qkv = self._new(R, 1536)
             ops.linear(hn, lw["wqkv"], 512, dtype=dt, bias=lw["bqkv"], out_act=qkv)

@@ -35,13 +35,14 @@ def weight_planes(w: torch.Tensor, n: int):
 
 def resolve_wplanes(wplanes, weights) -> bool:
     """wplanes of an engine constructor: True / False, or "auto" = True exactly when one of `weights` (the matrix-shaped weights
-    as the kernels will see them, weight norm folded) is not bf16-representable, i.e. when rounding at load would change it
-    (by more than the few fp32 ulps a weight-norm fold g * v / ||v|| with g = ||v|| leaves on a bf16-representable v)."""
+    as the kernels will see them, weight norm folded) is not bf16-representable, i.e. when rounding at load would change it by
+    more than 2^-16 relative - the precision the split build's products keep anyway (a weight-norm fold g * v / ||v|| with
+    g = ||v|| leaves ~1e-6 on a bf16-representable v: the norm of 10 000 elements is not summed in the same order twice)."""
     if wplanes != "auto":
         return bool(wplanes)
     for w in weights:
         w = w.detach().float()
-        if bool(((w - w.to(torch.bfloat16).float()).abs() > 2.4e-7 * w.abs()).any()):
+        if bool(((w - w.to(torch.bfloat16).float()).abs() > 2.0 ** -16 * w.abs()).any()):
             return True
     return False
 
@@ -300,6 +301,15 @@ def attn_relpos_bf16(q, k, vt, pos, pos_u, pos_v, out, *, B, H, T, ldq, ldk, ldv
     check(load().mmx_attn_relpos_bf16(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(vt), i64(ldvt), i64(vt_bs),
                                       _p(pos), i64(ldp), _p(pos_u), _p(pos_v), _p(out), i64(ldo), i64(o_bs), B, H, T,
                                       C.c_float(scale), chunk, _p(klen), stream()), "mmx_attn_relpos_bf16")
+
+
+def attn_relpos_x(q, k, v, pos, pos_u, pos_v, out, *, B, H, T, ldq, ldk, ldv, ldp, ldo, q_bs, k_bs, v_bs, o_bs, scale, chunk=0, klen=None):
+    """The split build's conformer rel-pos attention on the MFMA (include/mmx_hip.h mmx_attn_relpos_x): fp32 operands."""
+    if klen is not None:
+        assert klen.dtype == torch.int32 and klen.numel() >= B
+    check(load().mmx_attn_relpos_x(_p(q), i64(ldq), i64(q_bs), _p(k), i64(ldk), i64(k_bs), _p(v), i64(ldv), i64(v_bs), _p(pos), i64(ldp),
+                                   _p(pos_u), _p(pos_v), _p(out), i64(ldo), i64(o_bs), B, H, T, C.c_float(scale), chunk, _p(klen), stream()),
+          "mmx_attn_relpos_x")
 
 
 def attn_flash_bf16(q, k, vt, out, *, B, H, T, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, scale, keymask=None,

@@ -773,3 +773,37 @@ def test_lm_decode_fp16_planes_equals_bf16_planes():
             d = (lp["f16x2"][0] - lp["bf16x3"][0]).abs().max().item()
             print(f"decode step, fp16 planes vs bf16 planes, {kind} checkpoint, batch {B}: max |dlogp| {d:.3e}")
             assert d < 2e-4 and lp["f16x2"][1] == lp["bf16x3"][1]
+
+
+@pytest.mark.parametrize("T,chunk,ragged", [(50, 0, False), (100, 25, False), (173, 0, True), (300, 50, True)])
+def test_attn_relpos_x_vs_float64(T, chunk, ragged):
+    """Conformer rel-pos attention of the split build on the MFMA (mmx_attn_relpos_x: fp32 operands, every product as bf16
+    hi*hi + lo*hi + hi*lo) against the float64 statement of RelPositionMultiHeadedAttention (attention.py:215-330): (q + u) k^T +
+    rel_shift((q + v) p^T), chunk mask, prefix lengths of a padded batch, softmax, P V.  2^-17 per operand -> 4e-5 of the range."""
+    from mmx import ops
+    from oracle import flow as OF
+    g = torch.Generator().manual_seed(T + 3)
+    B, H, D = 3, 8, 64
+    qkv = torch.randn(B, T, 3 * H * D, generator=g).cuda()
+    pos = torch.randn(2 * T - 1, H * D, generator=g).cuda()
+    pu, pv = (torch.randn(H, D, generator=g) * 0.2).cuda(), (torch.randn(H, D, generator=g) * 0.2).cuda()
+    lens = [T, T - 9, T // 2 + 5] if ragged else [T] * B
+    out = torch.full((B, T, H * D), float("nan"), device="cuda")
+    ops.attn_relpos_x(qkv, qkv[:, :, 512:], qkv[:, :, 1024:], pos, pu, pv, out, B=B, H=H, T=T, ldq=1536, ldk=1536, ldv=1536, ldp=512, ldo=512,
+                      q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=D ** -0.5, chunk=chunk,
+                      klen=(torch.tensor(lens, dtype=torch.int32, device="cuda") if ragged else None))
+    x = qkv.double().cpu().reshape(B, T, 3, H, D)
+    qh = x[:, :, 0]
+    kh, vh = x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    ph = pos.double().cpu().view(1, 2 * T - 1, H, D).transpose(1, 2)
+    ac = (qh + pu.double().cpu()).transpose(1, 2) @ kh.transpose(-2, -1)
+    bd = OF.rel_shift((qh + pv.double().cpu()).transpose(1, 2) @ ph.transpose(-2, -1))
+    s = (ac + bd) * D ** -0.5
+    if chunk:
+        s = s.masked_fill(~OF.subsequent_chunk_mask(T, chunk)[None, None], float("-inf"))
+    for b in range(B):
+        s[b, :, :, lens[b]:] = float("-inf")
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, H * D)
+    for b in range(B):
+        a, r = out[b, :lens[b]].cpu().double(), ref[b, :lens[b]]
+        assert torch.isfinite(a).all() and rel_err(a, r) < 4e-5, (b, rel_err(a, r))
