@@ -227,6 +227,9 @@ int mmx_conv_cin1(const float* x, int64_t x_bs, int T, int C, int k, const float
  * z = m + noise * exp(logs).  All outputs fp32 [rows][D]. */
 int mmx_vae_sample(const float* ml, const float* noise, int64_t rows, int D, float* z, float* m, float* logs,
                    hipStream_t stream);
+/* x[row][:] = 0 where rowmask[row] == 0, in place; x is T [rows][C] (C a multiple of 16 bytes).  The rows beyond a member's length
+ * of a zero-padded batch behind a ConvTranspose1d (dac-vae/model.py:252-284), whose GEMM rows straddle that boundary. */
+int mmx_mask_rows(void* x, int64_t rows, int C, const float* rowmask, int dtype, hipStream_t stream);
 /* Cache prefetch: reads the byte ranges [p_i, p_i + n_i) (16-byte aligned, n_i multiples of 16; NULL = none) with default-policy
  * loads and keeps nothing, so the lines are left in L2 / the Infinity Cache for a later launch (the next LM layer's weights while
  * the current layer computes: a side stream of the captured decode step).  sink: 4 writable bytes (never written in practice). */

@@ -331,6 +331,27 @@ extern "C" int mmx_vae_sample(const float* ml, const float* noise, int64_t rows,
     return MMX_OK;
 }
 
+// ---------------------------------------------------------------------------- row mask in place
+// x[row][:] = 0 where rowmask[row] == 0 (T = fp32 or bf16, 16-byte chunks): the rows beyond a member's length in a zero-padded
+// batch after a ConvTranspose1d, whose GEMM rows straddle the boundary (mmx/dac.py: batched DAC decode of a flow group).
+template <typename T>
+__global__ void mask_rows_kernel(T* __restrict__ x, long rows, int C, const float* __restrict__ rowmask) {
+    constexpr int E = 16 / sizeof(T);
+    const long cpr = C / E, i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cpr) return;
+    const long r = i / cpr;
+    if (rowmask[r] == 0.f) reinterpret_cast<uint4*>(x)[i] = make_uint4(0, 0, 0, 0);
+}
+extern "C" int mmx_mask_rows(void* x, int64_t rows, int C, const float* rowmask, int dtype, hipStream_t stream) {
+    dtype = MMX_ACT_DTYPE(dtype);
+    MMX_CHECK_ARG(x && rowmask && rows > 0 && C > 0 && ((uintptr_t)x % 16) == 0 && C % (dtype == MMX_BF16 ? 8 : 4) == 0);
+    const long n = rows * (C / (dtype == MMX_BF16 ? 8 : 4));
+    if (dtype == MMX_BF16) hipLaunchKernelGGL(mask_rows_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, (long)rows, C, rowmask);
+    else hipLaunchKernelGGL(mask_rows_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (float*)x, (long)rows, C, rowmask);
+    MMX_LAUNCH_CHECK();
+    return MMX_OK;
+}
+
 // ---------------------------------------------------------------------------- weight prefetch into L2 / Infinity Cache
 // Reads up to four byte ranges with default-policy 16-byte loads and keeps nothing: the lines stay in the issuing XCD's L2 and in
 // the memory-side Infinity Cache.  Launched on a SIDE stream of the captured LM decode step with the NEXT layer's packed weights
@@ -489,4 +510,4 @@ extern "C" int mmx_act_rows(const float* x, int64_t rows, int C, int act, const 
     return MMX_OK;
 }
 
-extern "C" int mmx_abi_version(void) { return 8; }
+extern "C" int mmx_abi_version(void) { return 9; }

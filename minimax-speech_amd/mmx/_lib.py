@@ -32,7 +32,7 @@ LIB_PATH = os.environ.get("MMX_LIB") or os.path.join(os.path.dirname(_HERE), "li
 
 SYMBOLS = [
     "mmx_abi_version", "mmx_gemm_win", "mmx_gemm_win_tile", "mmx_rownorm", "mmx_groupnorm", "mmx_act_rows", "mmx_gather_rows", "mmx_copy2d", "mmx_est_pack",
-    "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_attn_flash_fp8", "mmx_attn_relpos_bf16", "mmx_attn_relpos_x", "mmx_attn_flash_x", "mmx_attn_flash_xs", "mmx_conv_cout1_tanh", "mmx_conv_cin1", "mmx_vae_sample", "mmx_resample_linear", "mmx_prefetch4",
+    "mmx_sinusoidal_emb", "mmx_cfg_euler", "mmx_attn_dense", "mmx_attn_flash_bf16", "mmx_attn_flash_fp8", "mmx_attn_relpos_bf16", "mmx_attn_relpos_x", "mmx_attn_flash_x", "mmx_attn_flash_xs", "mmx_conv_cout1_tanh", "mmx_conv_cin1", "mmx_vae_sample", "mmx_resample_linear", "mmx_prefetch4", "mmx_mask_rows",
     "mmx_est_tail", "mmx_est_resnet", "mmx_dac_ru", "mmx_pack_skinny", "mmx_skinny_gemm", "mmx_skinny2", "mmx_decode_prep", "mmx_rope_kv_store", "mmx_paged_attn", "mmx_decode_attn", "mmx_swiglu", "mmx_sample_step",
 ]
 
@@ -85,7 +85,7 @@ def fill_struct(st, **kw):
     return st
 
 
-ABI_VERSION = 8                                          # include/mmx_hip.h: mmx_abi_version()
+ABI_VERSION = 9                                          # include/mmx_hip.h: mmx_abi_version()
 _lib = None
 
 

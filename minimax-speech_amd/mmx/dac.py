@@ -99,44 +99,61 @@ class DacDecoderEngine:
         return self.decode_time_major(zt, B, T, skip_pre)
 
     @torch.no_grad()
-    def decode_time_major(self, zt: torch.Tensor, B: int, T: int, skip_pre=False) -> torch.Tensor:
-        """zt [B, T, D] in the compute dtype (what the flow engine hands over)."""
+    def decode_time_major(self, zt: torch.Tensor, B: int, T: int, skip_pre=False, lens=None) -> torch.Tensor:
+        """zt [B, T, D] in the compute dtype (what the flow engine hands over).
+        lens (list of ints, optional): a ZERO-PADDED batch - member b has lens[b] <= T valid frames.  Every layer then treats the
+        rows beyond a member's length as the zero padding a decode of that member alone would see: the windowed GEMMs multiply
+        them by a row mask in their epilogue, a ConvTranspose1d's output (whose GEMM rows straddle the boundary) is masked by
+        one row-mask launch, the fused ResidualUnits take the lengths themselves (mmx_dac_ru).  Member b of the result is
+        wav[b, :, :lens[b] * hop], equal to decode_time_major(zt[b:b+1, :lens[b]]) bit for bit (the same arithmetic per row)."""
         dt, tdt, dev = self.dtype, self.tdt, self.dev
         new = lambda t, c, d=None: torch.empty(B, t, c, dtype=(d or tdt), device=dev)
+        if lens is not None:
+            assert len(lens) == B and max(lens) <= T
+            ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+            mask_at = lambda rate: (torch.arange(T * rate, device=dev)[None, :] < (ln * rate)[:, None]).float().contiguous()
+        rm, rate = (mask_at(1) if lens is not None else None), 1
         if skip_pre:
             h = zt
         else:
             h = new(T, self.D)
-            ops.conv1d(zt, self.w_pre, T=T, Cin=self.D, k=1, dtype=dt, batch=B, bias=self.b_pre, act="lrelu", out_act=h)
+            ops.conv1d(zt, self.w_pre, T=T, Cin=self.D, k=1, dtype=dt, batch=B, bias=self.b_pre, act="lrelu", rowmask=rm, out_act=h)
         a = new(T, self.C0)
-        ops.conv1d(h, self.w0, T=T, Cin=self.D, k=7, pad_left=3, dtype=dt, batch=B, bias=self.b0, act="lrelu",
+        ops.conv1d(h, self.w0, T=T, Cin=self.D, k=7, pad_left=3, dtype=dt, batch=B, bias=self.b0, act="lrelu", rowmask=rm,
                    alpha=self.blocks[0]["alpha_in"], out_act=a)
         for bi, blk in enumerate(self.blocks):
             s, cin, cout = blk["stride"], blk["cin"], blk["cout"]
             T2 = T * s
+            rate *= s
             x = new(T2, cout, torch.float32)
             if blk["fused"]:
                 # one kernel per ResidualUnit: the fp32 residual stream is all that passes between them; the last unit also
-                # writes the next layer's input activation
+                # writes the next layer's input activation (a padded batch: the units zero the rows beyond a member's length on
+                # the way in and out themselves)
                 ops.convtranspose1d(a, blk["wt"], T=T, Cin=cin, Cout=cout, stride=s, dtype=dt, batch=B, bias=blk["bt"], out_f32=x)
                 T = T2
                 nxt = self.blocks[bi + 1]["alpha_in"] if bi + 1 < len(self.blocks) else self.alpha_final
+                ln_s = (ln * rate).to(torch.int32) if lens is not None else None
                 for j, ru in enumerate(blk["rus"]):
                     last = j == 2
                     x2 = new(T, cout, torch.float32)
                     a = new(T, cout) if last else None
-                    ops.dac_ru(x, x2, ru, B=B, T=T, C_=cout, dil=ru["dil"], dtype=dt, act_out=a, alpha_next=(nxt if last else None))
+                    ops.dac_ru(x, x2, ru, B=B, T=T, C_=cout, dil=ru["dil"], dtype=dt, act_out=a, alpha_next=(nxt if last else None), lens=ln_s)
                     x = x2
                 continue
             a2 = new(T2, cout)
             ops.convtranspose1d(a, blk["wt"], T=T, Cin=cin, Cout=cout, stride=s, dtype=dt, batch=B, bias=blk["bt"],
                                 alpha=blk["rus"][0]["a0"], out_f32=x, out_act=a2)
             T, a = T2, a2
+            rm = mask_at(rate) if lens is not None else None
+            if rm is not None:                             # the transposed conv's GEMM rows straddle a member's end: mask its outputs
+                ops.mask_rows(x, rm, rows=B * T, C_=cout, dtype=F32)
+                ops.mask_rows(a, rm, rows=B * T, C_=cout, dtype=dt)
             for j, ru in enumerate(blk["rus"]):
                 d = ru["dil"]
                 hmid = new(T, cout)
                 ops.conv1d(a, ru["w7"], T=T, Cin=cout, k=7, dil=d, pad_left=3 * d, dtype=dt, batch=B, bias=ru["b7"],
-                           act="lrelu", alpha=ru["a2"], out_act=hmid)
+                           act="lrelu", alpha=ru["a2"], rowmask=rm, out_act=hmid)
                 last = j == 2
                 if not last:
                     nxt = blk["rus"][j + 1]["a0"]
@@ -147,7 +164,7 @@ class DacDecoderEngine:
                 x2 = None if last else new(T, cout, torch.float32)
                 a3 = new(T, cout)
                 ops.conv1d(hmid, ru["w1"], T=T, Cin=cout, k=1, dtype=dt, batch=B, bias=ru["b1"], act="lrelu",
-                           residual=x, alpha=nxt, out_f32=x2, out_act=a3)
+                           residual=x, alpha=nxt, rowmask=rm, out_f32=x2, out_act=a3)
                 x, a = x2, a3
         wav = torch.empty(B, 1, T, dtype=torch.float32, device=dev)
         ops.conv_cout1_tanh(a, self.w_final, self.b_final, wav, T=T, C_=self.blocks[-1]["cout"], k=self.k_final,

@@ -168,6 +168,11 @@ def act_rows(x, *, rows, C_, act="none", rowmask=None, out_f32=None, out_act=Non
           "mmx_act_rows")
 
 
+def mask_rows(x, rowmask, *, rows, C_, dtype):
+    """x[row][:] = 0 where rowmask[row] == 0, in place (mmx_mask_rows)."""
+    check(load().mmx_mask_rows(_p(x), i64(rows), C_, _p(rowmask), dtype, stream()), "mmx_mask_rows")
+
+
 def gather_rows(ids, table, *, scale=1.0, rowmask=None, out_f32=None, out_act=None, dtype=F32):
     n, C_ = ids.numel(), table.shape[1]
     check(load().mmx_gather_rows(_p(ids), n, _p(table), C_, C.c_float(scale), _p(rowmask), _p(out_f32), i64(C_),

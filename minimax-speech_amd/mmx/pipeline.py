@@ -61,6 +61,7 @@ class TtsEngine:
     # loop slow its launches more than the per-utterance stages gain); useful only without a decode loop alongside
     group_fan = 1
     batch_encoder = True      # the conformer encoder of a flow group runs as one zero-padded batch (FlowEngine.encode_batch)
+    batch_dac = True          # ... and so does its DAC decode (DacDecoderEngine.decode_time_major with per-member lengths)
 
     flow_priority = 0      # HIP stream priority of the flow workers' streams (the decode loop runs at -1 = high)
 
@@ -361,8 +362,22 @@ class TtsEngine:
             ops.copy2d(lat, F32, 0, 80, 1, zt, self.dtype, 0, 80, 1, rows=T2, cols=80)
             return self.dac.decode_time_major(zt, 1, T2)
 
-        for b, w in zip(grp, fanned([(lambda b=b, lat=lat, c=c: dac_job(b, lat, c)) for b, lat, c in zip(grp, xs, conds)])):
-            wavs[b] = w
+        if self.batch_dac and len(grp) > 1 and not aux:
+            # ONE decode of the zero-padded group (DacDecoderEngine.decode_time_major with per-member lengths: row masks in the
+            # GEMM epilogues, lengths in the fused ResidualUnits) instead of ~32 launches per utterance; member i of the result
+            # equals its own decode bit for bit
+            lats = [lat[c[3]:] for lat, c in zip(xs, conds)]
+            Ts = [int(l.shape[0]) for l in lats]
+            Tm = max(Ts)
+            zt = torch.zeros(len(grp), Tm, 80, dtype=TORCH_DT[self.dtype], device=self.dev)
+            for i, l in enumerate(lats):
+                ops.copy2d(l, F32, 0, 80, 1, zt[i], self.dtype, 0, 80, 1, rows=Ts[i], cols=80)
+            wav = self.dac.decode_time_major(zt, len(grp), Tm, lens=Ts)
+            for i, b in enumerate(grp):
+                wavs[b] = wav[i:i + 1, :, :Ts[i] * self.hop]
+        else:
+            for b, w in zip(grp, fanned([(lambda b=b, lat=lat, c=c: dac_job(b, lat, c)) for b, lat, c in zip(grp, xs, conds)])):
+                wavs[b] = w
         if aux:
             # blocks the auxiliary streams allocated (and this function's temporaries freed there) go back to THEIR pools:
             # nothing on them may be reused before the group's stream has finished reading it

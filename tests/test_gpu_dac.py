@@ -170,3 +170,26 @@ def test_strided_windowed_gemm_matches_conv1d():
                    pad_left=math.ceil(s / 2), stride=s, T_out=T // s, dtype=0, batch=2, bias=b.cuda(), out_f32=out)
         assert ref.shape[-1] == T // s
         assert (out.cpu().transpose(1, 2) - ref).abs().max().item() < 1e-4, s
+
+
+@pytest.mark.parametrize("dt", [0, 1, 2])
+def test_dac_decode_of_a_zero_padded_batch_equals_each_member(golden_dir, dt):
+    """DacDecoderEngine.decode_time_major(lens=...): ONE decode of a zero-padded batch of latents of different lengths (what a flow
+    group hands over) gives every member the samples of its own decode, bit for bit - the row masks of the GEMM epilogues, the mask
+    launch behind each unfused ConvTranspose1d (mmx_mask_rows) and the lengths of the fused ResidualUnits stand in for the zero
+    padding a member decoded alone would see (dac-vae/model.py:107-143,252-284).  Lengths chosen so that members end inside tiles."""
+    from mmx import ops
+    from mmx._lib import TORCH_DT
+    eng, _ = _engine(golden_dir, 80, dt)
+    lens = [37, 9, 50, 23]
+    g = torch.Generator().manual_seed(3)
+    lat = [torch.randn(n, 80, generator=g).cuda().to(TORCH_DT[dt]) for n in lens]
+    Tm = max(lens)
+    zt = torch.zeros(len(lens), Tm, 80, dtype=TORCH_DT[dt], device="cuda")
+    for i, l in enumerate(lat):
+        zt[i, :lens[i]] = l
+    wav = eng.decode_time_major(zt, len(lens), Tm, lens=lens)
+    assert wav.shape == (len(lens), 1, Tm * 480)
+    for i, l in enumerate(lat):
+        one = eng.decode_time_major(l.reshape(1, lens[i], 80).contiguous(), 1, lens[i])
+        assert torch.equal(wav[i:i + 1, :, :lens[i] * 480], one), (dt, i, (wav[i:i + 1, :, :lens[i] * 480] - one).abs().max().item())
