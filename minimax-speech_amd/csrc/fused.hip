@@ -1156,7 +1156,7 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     if (narrow) {                                      // 8 waves, 32-column passes (PW = 2)
         if (dtype == MMX_BF16 && bm == 64) { if (pf == 2) TAILP(bf16_t, 64, 2, 8, 1, 1, 2); else TAILP(bf16_t, 64, 4, 8, 1, 1, 2); }
         else if (dtype == MMX_BF16 && bm == 32) { if (pf == 8) TAILP(bf16_t, 32, 8, 8, 1, 1, 2); else TAILP(bf16_t, 32, 4, 8, 1, 1, 2); }
-        else if (dtype == MMX_X2 && bm == 32) { if (pf == 2) TAILP(bf16_t, 32, 2, 8, 2, 1, 2); else if (pf == 8) TAILP(bf16_t, 32, 8, 8, 2, 1, 2); else TAILP(bf16_t, 32, 4, 8, 2, 1, 2); }
+        else if (dtype == MMX_X2 && bm == 32) { if (pf == 2) TAILP(bf16_t, 32, 2, 8, 2, 1, 2); else TAILP(bf16_t, 32, 4, 8, 2, 1, 2); }
         else return MMX_EARG;
     } else if (occ2) {                                 // two workgroups per CU (4 waves each)
         if (dtype == MMX_BF16 && bm == 32) { if (pf == 4) TAILO(bf16_t, 32, 4, 4, 1, 2); else TAILO(bf16_t, 32, 2, 4, 1, 2); }
@@ -1165,7 +1165,9 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
         else return MMX_EARG;
     } else if (dtype == MMX_X2) {
         // split build: two bf16 planes per LDS tile, so the largest tile is 32 rows (137 KB with 8 waves)
-        if (bm == 32) { if (nw == 4) TAILN(bf16_t, 32, 4, 4, 2); else if (pf == 4) TAILN(bf16_t, 32, 4, 8, 2); else TAILN(bf16_t, 32, 2, 8, 2); }
+        // (a ring 4 k-steps deep measured no faster: 35.7 / 38.5 / 54.6 us at 32 / 128 / 256 workgroups against 37.4 / 40.4 / 55.2 -
+        // the stages are bound by the CU's L2 read rate, not by the latency of the loads in flight: profiles/r04_tail_lab_x.txt)
+        if (bm == 32) { if (nw == 4) TAILN(bf16_t, 32, 4, 4, 2); else TAILN(bf16_t, 32, 2, 8, 2); }
         else if (bm == 16) { if (nw == 8) TAILN(bf16_t, 16, 4, 8, 2); else TAILN(bf16_t, 16, 8, 4, 2); }
         else return MMX_EARG;
     } else if (dtype == MMX_BF16) {

