@@ -350,7 +350,6 @@ def main():
     ap.add_argument("--dtype", default="x", choices=["bf16", "f32", "x"],
                     help="x (default) = the split build, the build that meets the north-star parity: bf16 weight stream and bf16 MFMA products, "
                          "fp32 activations split into bf16 terms inside the products; bf16 = the speed build (ids diverge from the CPU path)")
-    ap.add_argument("--max-group-wgs", type=int, default=None, help="tuning: workgroup cap of a flow group's fused launches (TtsEngine.max_group_wgs; 0 = none)")
     ap.add_argument("--lm-prefetch", type=int, default=None, help="tuning: workgroups of the per-layer weight prefetch on a side stream of the decode step (LlmEngine.prefetch; 0 = off)")
     ap.add_argument("--lm-planes", default=None, choices=["f16x2", "bf16x3"], help="split build: plane format of the LM decode step (LlmEngine.lm_planes)")
     ap.add_argument("--checkpoint", default="bf16", choices=["bf16", "fp32"],
@@ -385,9 +384,6 @@ def main():
     if a.lm_planes:
         from mmx.llm import LlmEngine
         LlmEngine.lm_planes = a.lm_planes
-    if a.max_group_wgs is not None:
-        from mmx.pipeline import TtsEngine
-        TtsEngine.max_group_wgs = a.max_group_wgs or (1 << 30)
     if a.lm_prefetch is not None:
         from mmx.llm import LlmEngine
         LlmEngine.prefetch = a.lm_prefetch

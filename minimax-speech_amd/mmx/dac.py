@@ -111,7 +111,8 @@ class DacDecoderEngine:
         if lens is not None:
             assert len(lens) == B and max(lens) <= T
             ln = torch.tensor(lens, dtype=torch.int32, device=dev)
-            mask_at = lambda rate: (torch.arange(T * rate, device=dev)[None, :] < (ln * rate)[:, None]).float().contiguous()
+            T0 = T                                            # (T is rebound stage by stage below)
+            mask_at = lambda rate: (torch.arange(T0 * rate, device=dev)[None, :] < (ln * rate)[:, None]).float().contiguous()
         rm, rate = (mask_at(1) if lens is not None else None), 1
         if skip_pre:
             h = zt

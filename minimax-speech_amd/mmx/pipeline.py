@@ -61,7 +61,6 @@ class TtsEngine:
     # loop slow its launches more than the per-utterance stages gain); useful only without a decode loop alongside
     group_fan = 1
     batch_encoder = True      # the conformer encoder of a flow group runs as one zero-padded batch (FlowEngine.encode_batch)
-    max_group_wgs = 256       # workgroups of a flow group's fused launches: one round of the chip's 256 CUs (TtsEngine._groups)
     batch_dac = True          # ... and so does its DAC decode (DacDecoderEngine.decode_time_major with per-member lengths)
 
     flow_priority = 0      # HIP stream priority of the flow workers' streams (the decode loop runs at -1 = high)
@@ -287,18 +286,11 @@ class TtsEngine:
         repeats.  A ramp such as [2, 2, 4, 8] lets the flow stage start as soon as the two shortest utterances are
         decoded instead of waiting for eight."""
         sizes = group_size if isinstance(group_size, (list, tuple)) else [group_size]
-        # A group's fused-kernel launches have 2 (CFG pair) * members * ceil(padded frames / tile rows) workgroups, one per CU and
-        # round: a group that needs 257 .. 512 of them pays two rounds of the 256 CUs for every one of its ~1 300 launches (measured,
-        # split build: est_tail 55 us at 256 workgroups, 88 us at 320).  A member that would push the group past one round starts
-        # the next group instead.
-        bm = 32 if is_split(self.dtype) else 64
-        wgs = lambda n, t: 2 * n * (-(-(-(-t // frame_quantum) * frame_quantum) // bm))
         out, i = [], 0
         while i < len(order):
             gs = sizes[min(first + len(out), len(sizes) - 1)]
             j, t0 = i + 1, frames[order[i]]
-            while (j < len(order) and j - i < gs and frames[order[j]] <= max(t0 * max_pad_ratio, t0 + frame_quantum)
-                   and (wgs(j - i + 1, frames[order[j]]) <= self.max_group_wgs or wgs(j - i, frames[order[j - 1]]) > self.max_group_wgs)):
+            while j < len(order) and j - i < gs and frames[order[j]] <= max(t0 * max_pad_ratio, t0 + frame_quantum):
                 j += 1
             out.append(order[i:j])
             i = j
