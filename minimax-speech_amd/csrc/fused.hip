@@ -1142,10 +1142,9 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
         MMX_LAUNCH_CHECK();
         return MMX_OK;
     }
-    if ((cfg >> 10) & 1) {                             // two row tiles per workgroup: the tile defaults of the two fast builds only
-        if (dtype == MMX_BF16 && bm == 64) TAILT(bf16_t, 64, 2, 8, 1, 1, 2, 2);
-        else if (dtype == MMX_BF16 && bm == 32) TAILT(bf16_t, 32, 8, 8, 1, 1, 2, 2);
-        else if (dtype == MMX_X2 && bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 2);
+    if ((cfg >> 10) & 1) {                             // two row tiles per workgroup: the split build's flow groups beside the decode loop
+        // (the bf16 build's 64- / 32-row forms measured a loss and spilled 256 - 448 bytes per lane: removed)
+        if (dtype == MMX_X2 && bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 2);
         else return MMX_EARG;
         MMX_LAUNCH_CHECK();
         return MMX_OK;
@@ -1153,15 +1152,11 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     // library defaults of the bf16 build (cfg = 0): the narrow-pass 8-wave kernels for the 64- and 32-row tiles (measured per
     // launch at 10 000 rows: 51.1 us against 58.7 us with 4 waves x 64-column passes; 32 rows, 4 000 rows: 31.8 against 33.0)
     if (cfg == 0 && dtype == MMX_BF16 && (bm == 64 || bm == 32)) { narrow = 1; pf = bm == 64 ? 2 : 8; }
+    if (occ2) return MMX_EARG;                         // (two 4-wave workgroups per CU: measured slower everywhere, spilled; removed)
     if (narrow) {                                      // 8 waves, 32-column passes (PW = 2)
-        if (dtype == MMX_BF16 && bm == 64) { if (pf == 2) TAILP(bf16_t, 64, 2, 8, 1, 1, 2); else TAILP(bf16_t, 64, 4, 8, 1, 1, 2); }
+        if (dtype == MMX_BF16 && bm == 64) TAILP(bf16_t, 64, 2, 8, 1, 1, 2);
         else if (dtype == MMX_BF16 && bm == 32) { if (pf == 8) TAILP(bf16_t, 32, 8, 8, 1, 1, 2); else TAILP(bf16_t, 32, 4, 8, 1, 1, 2); }
         else if (dtype == MMX_X2 && bm == 32) { if (pf == 2) TAILP(bf16_t, 32, 2, 8, 2, 1, 2); else TAILP(bf16_t, 32, 4, 8, 2, 1, 2); }
-        else return MMX_EARG;
-    } else if (occ2) {                                 // two workgroups per CU (4 waves each)
-        if (dtype == MMX_BF16 && bm == 32) { if (pf == 4) TAILO(bf16_t, 32, 4, 4, 1, 2); else TAILO(bf16_t, 32, 2, 4, 1, 2); }
-        else if (dtype == MMX_BF16 && bm == 16) TAILO(bf16_t, 16, 4, 4, 1, 2);
-        else if (dtype == MMX_X2 && bm == 16) { if (pf == 4) TAILO(bf16_t, 16, 4, 4, 2, 2); else TAILO(bf16_t, 16, 2, 4, 2, 2); }
         else return MMX_EARG;
     } else if (dtype == MMX_X2) {
         // split build: two bf16 planes per LDS tile, so the largest tile is 32 rows (137 KB with 8 waves)
@@ -1171,12 +1166,10 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
         else if (bm == 16) { if (nw == 8) TAILN(bf16_t, 16, 4, 8, 2); else TAILN(bf16_t, 16, 8, 4, 2); }
         else return MMX_EARG;
     } else if (dtype == MMX_BF16) {
-        if (bm == 64) {
+        if (bm == 64) {                                // (reached with an explicit cfg only: the round-2 / round-3 forms, tools/tail_lab.py)
             if (nw == 0 || nw == 4) { if (pf == 4) TAIL(bf16_t, 64, 4, 4); else TAIL(bf16_t, 64, 2, 4); }
-            else if (nw == 8) TAIL(bf16_t, 64, 2, 8);
             else return MMX_EARG;
         } else if (bm == 32) {
-            // default: 8 waves, ring depth 2 (measured 32.5 us per workgroup against 37.2 us with 4 waves / depth 4)
             if (nw == 8 || nw == 0) { if (pf == 4) TAIL(bf16_t, 32, 4, 8); else TAIL(bf16_t, 32, 2, 8); }
             else if (nw == 4) { if (pf == 2) TAIL(bf16_t, 32, 2, 4); else TAIL(bf16_t, 32, 4, 4); }
             else return MMX_EARG;

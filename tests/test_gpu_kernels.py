@@ -550,12 +550,11 @@ def test_est_tail_fused(env, dt, B, T, masked, with_next):
     wqkv_p = _pk(ops, wqkv, dt)
     tol = FUSED_TOL[dt]
     # every kernel variant of the build: the library defaults (bf16: 8 waves with 32-column passes for 64 / 32 rows), the
-    # one-wave-per-SIMD kernels, the 64-column-pass 8-wave ones and the two-workgroups-per-CU ones (explicit cfg)
+    # one-wave-per-SIMD kernels and the 64-column-pass 8-wave ones (explicit cfg)
     variants = [(bm, {}) for bm in FUSED_BM[dt]]
     if dt == 1:
         variants += [(64, dict(waves=4, pf=2)), (64, dict(waves=4, pf=4)), (32, dict(waves=4, pf=4)), (32, dict(waves=8, pf=2)),
-                     (32, dict(occ2=True, pf=2)), (16, dict(waves=8)), (32, dict(narrow=True, pf=4)), (64, dict(narrow=True, pf=4)),
-                     (64, dict(tpw2=True)), (32, dict(tpw2=True))]
+                     (16, dict(waves=8)), (32, dict(narrow=True, pf=4))]
     for bm, cfg in variants:
         xio = x.clone()
         Tp = ops.round_up(T, 8)

@@ -44,10 +44,10 @@ def run(n, T, bm, waves, pf):
 
 
 def sweep():
-    # waves 1xx: the two-workgroups-per-CU variants (4 waves each); 2xx: 8 waves with 32-column passes
+    # waves 2xx: 8 waves with 32-column passes
     # 3xx: the default kernel of (dtype, rows) with two row tiles per workgroup
     cfgs = ([(32, 8, 0), (32, 208, 4), (32, 300, 0), (16, 8, 0)] if split else
-            [(64, 4, 2), (64, 208, 2), (64, 300, 0), (32, 208, 8), (32, 300, 0), (32, 104, 2), (16, 8, 4)])
+            [(64, 4, 2), (64, 208, 2), (32, 208, 8), (16, 8, 4)])
     for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
         line = []
