@@ -1144,6 +1144,8 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     }
     if ((cfg >> 10) & 1) {                             // two row tiles per workgroup: the split build's flow groups beside the decode loop
         // (the bf16 build's 64- / 32-row forms measured a loss and spilled 256 - 448 bytes per lane: removed)
+        // (its 32-column-pass form - 172 registers in the one-tile kernel, which would let one-row-tile decode workgroups share the
+        // CU - still takes 255 here; the one-tile narrow form beside the decode loop measured 503 audio-s/s against 505: gpurun_out/r4_13)
         if (dtype == MMX_X2 && bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 2);
         else return MMX_EARG;
         MMX_LAUNCH_CHECK();
