@@ -396,7 +396,7 @@ def test_config5_long_form_streaming_full_size_split_vs_oracle(case, capsys):
           step; teacher forced along the oracle's ids, EVERY draw equals the oracle's except at such steps.
       (b) The first four chunks of the stream (teacher forced: the oracle's ids) within 1e-3 of oracle/stream.py's first four
           hops (a hop sees only the tokens before it, so the prefix of the oracle's schedule is the schedule of the prefix).
-      (c) The closing chunk (cross-faded seam included) within 1e-3 of the oracle's, on a 20 s utterance of the same schedule (a
+      (c) The closing chunk (cross-faded seam included) within 1e-3 of the oracle's, on a 10 s utterance of the same schedule (a
           3000-frame oracle pass takes minutes on the host cores).  The oracle side is two flow passes instead of twenty: the
           LAST streaming pass and the closing pass - streaming passes agree on finished frames (the flow is chunk causal), so
           the last streaming pass alone holds every latent frame the earlier ones rendered."""
@@ -449,9 +449,9 @@ def test_config5_long_form_streaming_full_size_split_vs_oracle(case, capsys):
         assert [g.shape for g in chunks[:4]] == [w.shape for w in want]
         print(f"config 5 on the split build ({len(chunks)} chunks): first four chunks vs the oracle's hops {[f'{e:.2e}' for e in errs]}")
         assert max(errs) <= 1e-3, errs
-    # (c) the closing seam at 20 s (500 steps): the same schedule, the oracle's last streaming pass and closing pass (a 60 s
+    # (c) the closing seam at 10 s (250 steps, ten hops): the same schedule, the oracle's last streaming pass and closing pass (a 60 s
     # oracle pass over 3000 frames takes minutes on the host cores; the seam arithmetic does not depend on the length)
-    N2 = 500
+    N2 = 250
     drawn2 = []
     with torch.no_grad():
         toks2 = OLLM.lm_inference(case["llm_sd"], OLLM.QwenCfg(), text, z, z, seed=2, seq=0, max_steps=N2, ignore_eos_always=True, sampled_out=drawn2)
