@@ -170,11 +170,12 @@ def measure_attn_kernel(eng, shapes, steps=1):
     fl = eng.flow
     count = {}
     tot_us = tot_fl = tot_n = 0.0
-    for n, T, _, sq, _pol in shapes:
-        count.setdefault((n, T), [0, 0])[0] += 1
+    for n, T, _, sq, pol in shapes:
+        count.setdefault((n, T, bool(pol)), [0, 0])[0] += 1
         tot_fl += 4.0 * 64 * 8 * 2 * sq
-    for (n, T), (cnt, _) in sorted(count.items()):
+    for (n, T, pol), (cnt, _) in sorted(count.items()):
         B, Tp = 2 * n, ops.round_up(T, 8)
+        form = fl.polite_flash_form if (pol and fl.split) else 0     # the workgroup shape the step used for this group (FlowEngine.polite)
         if fl.split:
             qk = torch.randn(B, T, 2048, device=fl.dev).to(torch.bfloat16)
             vt = torch.randn(B, 2, 512, Tp, device=fl.dev).to(torch.bfloat16)
@@ -184,7 +185,7 @@ def measure_attn_kernel(eng, shapes, steps=1):
         ao = torch.empty(B, T, 512, device=fl.dev, dtype=fl.tdt)
         # the group as the step ran it: utterance lengths spread evenly from the group's mean down and up to T (the log
         # keeps n, T, sum T_i, sum T_i^2, not every length), passed as klen like FlowEngine does for a padded group
-        valid = sum(v for n_, T_, v, _, _p in shapes if (n_, T_) == (n, T)) / cnt
+        valid = sum(v for n_, T_, v, _, p_ in shapes if (n_, T_, bool(p_)) == (n, T, pol)) / cnt
         lo = max(1, int(2 * valid / n - T))
         lens = [int(round(lo + (T - lo) * i / max(1, n - 1))) for i in range(n)]
         lens[-1] = T
@@ -193,7 +194,7 @@ def measure_attn_kernel(eng, shapes, steps=1):
         def one(i=0):
             if fl.split:
                 ops.attn_flash_xs(qk, vt, ao, B=B, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=2 * 512 * Tp, o_bs=T * 512,
-                                  scale=0.125, klen=(klen if n > 1 else None))
+                                  scale=0.125, klen=(klen if n > 1 else None), form=form)
             else:
                 ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=B, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
                                     k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125, klen=(klen if n > 1 else None))
@@ -365,6 +366,7 @@ def main():
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
     ap.add_argument("--tpw2-min-tiles", type=int, default=None, help="tuning: two-tile workgroups only for est_tail launches of at least this many row tiles")
+    ap.add_argument("--flash-form", type=int, default=None, help="lab: mmx_attn_flash_xs form of the flow groups beside the decode loop (0 chosen per launch, 1 = 128-query workgroups [default], 2 = 256-query, 3 = 4-wave 64-query)")
     ap.add_argument("--tpw2", type=int, default=None, help="tuning: 1 / 0 = polite flow groups run est_tail with two / one row tiles per workgroup (FlowEngine.polite_tpw2; default: split build only)")
     ap.add_argument("--flow-priority", type=int, default=None, help="tuning: HIP stream priority of the flow workers' streams (TtsEngine.flow_priority)")
     ap.add_argument("--lm-cfg", default="", help="tuning: LlmEngine.v2_cfg overrides (output tiles per workgroup, k slices), e.g. gu=2,1:down=2,4")
@@ -390,6 +392,9 @@ def main():
     if a.tpw2_min_tiles is not None:
         from mmx.flow import FlowEngine
         FlowEngine.polite_tpw2_min_tiles_default = a.tpw2_min_tiles
+    if a.flash_form is not None:
+        from mmx.flow import FlowEngine
+        FlowEngine.polite_flash_form_default = a.flash_form
     if a.tpw2 is not None:
         from mmx.flow import FlowEngine
         FlowEngine.polite_tpw2_default = bool(a.tpw2)

@@ -189,6 +189,9 @@ int mmx_attn_relpos_x(const float* q, int64_t ldq, int64_t q_bs, const float* k,
                       hipStream_t stream);
 /* mmx_attn_flash_xs: the split build's attention on operands the PRODUCER has already split (MmxEstNext, MMX_X2 with
  * vt_out): qk bf16 [B][T][ldqk >= 2048] = [hi Q | hi K | lo Q | lo K], vt bf16 [B][2][512][ldvt], out fp32 [B][T][ldo].
+ * form: 0 = workgroup shape chosen per launch (fastest alone); 1 = the shape that leaves LDS and registers for a co-resident
+ * workgroup of another stream (launches beside the LM decode loop); 2 / 3 = 256-query / 4-wave 64-query workgroups (measurements).
+ * The forms agree to fp32 rounding (different query-tile heights accumulate the online softmax over the same key tiles).
  * mmx_attn_flash_x: the same contract on fp32 operands:
  * q / k / v / out fp32, V ROW-major (v[b][t][h*D + d], ldv elements per
  * row — the QKV projection's own output, no transposed copy), both operands of Q K^T and P V split into bf16 hi + lo
@@ -199,7 +202,7 @@ int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const float* k, 
                      int q_begin, const int32_t* klen, hipStream_t stream);
 int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, const void* vt, int64_t ldvt, int64_t vt_bs,
                       float* out, int64_t ldo, int64_t o_bs, int B, int H, int T, float scale, const float* keymask,
-                      int64_t km_bs, int chunk, int q_begin, const int32_t* klen, hipStream_t stream);
+                      int64_t km_bs, int chunk, int q_begin, const int32_t* klen, int form, hipStream_t stream);
 /* Conformer rel-pos attention on the MFMA (speech/cosyvoice/transformer/attention.py:215-330), bf16 build:
  *   score(i, j) = ((q_i + pos_u) . k_j + (q_i + pos_v) . pos[T - 1 - i + j]) * scale      (rel_shift folded into the index)
  * q, k: bf16 rows (head h at column h * 64), vt: V TRANSPOSED [B][H * 64][ldvt] (zero padded to ldvt >= round_up(T, 8)

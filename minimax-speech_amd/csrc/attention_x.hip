@@ -670,27 +670,28 @@ extern "C" int mmx_attn_flash_x(const float* q, int64_t ldq, int64_t q_bs, const
 // [hi Q | hi K | lo Q | lo K], vt bf16 [B][2 planes][512][ldvt] (V transposed, zero padded columns), out fp32.
 extern "C" int mmx_attn_flash_xs(const void* qk, int64_t ldqk, int64_t qk_bs, const void* vt, int64_t ldvt, int64_t vt_bs,
                                  float* out, int64_t ldo, int64_t o_bs, int B, int H, int T_, float scale, const float* keymask,
-                                 int64_t km_bs, int chunk, int q_begin, const int32_t* klen, hipStream_t stream) {
-    MMX_CHECK_ARG(qk && vt && out && B > 0 && H > 0 && H * 64 <= 512 && T_ > 0 && chunk >= 0);
+                                 int64_t km_bs, int chunk, int q_begin, const int32_t* klen, int form, hipStream_t stream) {
+    MMX_CHECK_ARG(qk && vt && out && B > 0 && H > 0 && H * 64 <= 512 && T_ > 0 && chunk >= 0 && form >= 0 && form <= 3);
     MMX_CHECK_ARG(q_begin >= 0 && q_begin < T_ && q_begin % 16 == 0);
     MMX_CHECK_ARG(ldqk >= 2048 && ldqk % 8 == 0 && qk_bs % 8 == 0 && ldvt % 8 == 0 && ldvt >= ((T_ + 7) / 8) * 8 && vt_bs % 8 == 0 && vt_bs >= 2 * 512 * ldvt);
     MMX_CHECK_ARG(ldo % 4 == 0 && o_bs % 4 == 0 && ((uintptr_t)qk % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 16) == 0);
     const int npairs = H * B, Tq = T_ - q_begin;
-    const bool small = (long)npairs * ((Tq + 127) / 128) < 192;
+    const bool small = form == 3 || (long)npairs * ((Tq + 127) / 128) < 192;
     const int qtile = small ? 64 : 128, nq = (Tq + qtile - 1) / qtile;
     dim3 grid(8 * ((npairs + 7) / 8) * nq);
     const bf16_t* q = (const bf16_t*)qk;
     // 8 waves x 32 queries (256 per workgroup, MF = 2) halve the K / V fragment reads from LDS per MFMA, and a workgroup takes
     // ~1.6 x as long as one of 128 queries (tools/flash_lab.py, profiles/r04_flash_lab_x.txt: 71 -> 62 us at 3 x 980 frames,
     // 37 -> 30 at 5 x 420, 122 -> 112 at 8 x 896; 93 -> 100 at 5 x 860, where the 128-query grid needs 3 rounds of the 256 CUs
-    // and the 256-query grid 2).  Chosen per launch from the rounds each grid needs.
+    // and the 256-query grid 2).  form 0: chosen per launch from the rounds each grid needs.
+    // form 1 (the caller's launch runs BESIDE a latency-bound kernel chain on another stream): the 128-query workgroups - 96 KB of
+    // LDS and 136 registers per wave (two waves per SIMD leave 224) instead of 128 KB and 216 (80): a decode workgroup of csrc/decode.hip
+    // fits on the same CU.  Measured in the 32-utterance step (gpurun_out/r4_17): decode loop done at 524 ms against 541 (chosen
+    // per launch) and 549 (256-query everywhere); 520.8 / 512.4 / 510.7 audio-s/s.  form 2: 256-query workgroups wherever the
+    // grid is not small; form 3: the 4-wave 64-query form everywhere (80 KB of LDS).
     const int nq2 = (Tq + 255) / 256;
     const long wg1 = (long)npairs * nq, wg2 = (long)npairs * nq2;
-    bool mf2 = !small && 1.6 * (double)((wg2 + 255) / 256) < (double)((wg1 + 255) / 256);
-    if constexpr (LAB) {                               // lab build only: MMX_LAB_FLASHX=mf1 / mf2 forces the form
-        const char* e = getenv("MMX_LAB_FLASHX");
-        if (e && e[0] == 'm' && !small) mf2 = e[2] == '2';
-    }
+    const bool mf2 = !small && form != 1 && (form == 2 || 1.6 * (double)((wg2 + 255) / 256) < (double)((wg1 + 255) / 256));
     if (mf2) {
         dim3 grid2(8 * ((npairs + 7) / 8) * nq2);
         return launch_flash_x<2, true, 8>(grid2, stream, q, ldqk, qk_bs, q + 512, ldqk, qk_bs, vt, ldvt, vt_bs, out, ldo, o_bs, T_, scale, keymask, km_bs, chunk, nq2, H, npairs, q_begin, klen);

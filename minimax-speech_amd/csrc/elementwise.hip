@@ -510,4 +510,4 @@ extern "C" int mmx_act_rows(const float* x, int64_t rows, int C, int act, const 
     return MMX_OK;
 }
 
-extern "C" int mmx_abi_version(void) { return 9; }
+extern "C" int mmx_abi_version(void) { return 10; }

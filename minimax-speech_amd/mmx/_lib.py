@@ -85,7 +85,7 @@ def fill_struct(st, **kw):
     return st
 
 
-ABI_VERSION = 9                                          # include/mmx_hip.h: mmx_abi_version()
+ABI_VERSION = 10                                         # include/mmx_hip.h: mmx_abi_version()
 _lib = None
 
 

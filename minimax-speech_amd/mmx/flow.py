@@ -162,6 +162,10 @@ class FlowEngine:
         # loop ends 15 ms earlier); off for the bf16 build (64-row tiles: 702 -> 670, the flow groups fall behind)
         self.polite_tpw2 = getattr(FlowEngine, "polite_tpw2_default", None)
         self.polite_tpw2_min_tiles = getattr(FlowEngine, "polite_tpw2_min_tiles_default", 0)   # only launches of at least this many tiles
+        # polite groups of the split build: flash attention on its 128-query workgroups (96 KB of LDS, 136 registers per wave) instead
+        # of the 256-query ones (128 KB, 216) the launch-time rule would pick: a decode workgroup fits beside them on the CU
+        # (measured in the step: decode loop done at 524 ms against 541, 520.8 against 512.4 audio-s/s; include/mmx_hip.h, form)
+        self.polite_flash_form = getattr(FlowEngine, "polite_flash_form_default", 1)
         self.plan_bytes = 0
         # CausalConditionalCFM.__init__: torch CPU manual_seed(0); randn([1,80,15000]) (flow_matching.py:320-321)
         self.rand_noise = torch.randn([1, 80, 50 * 300], generator=torch.Generator().manual_seed(0))
@@ -728,7 +732,8 @@ class FlowEngine:
                                     keymask=(None if klen is not None else mask), chunk=chunk, fp8=self.attn_fp8, klen=klen)
             elif self.split:
                 ops.attn_flash_xs(qk, vt, ao, B=B, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=vt_bs, o_bs=T * 512,
-                                  scale=0.125, keymask=(None if klen is not None else mask), chunk=chunk, klen=klen)
+                                  scale=0.125, keymask=(None if klen is not None else mask), chunk=chunk, klen=klen,
+                                  form=(self.polite_flash_form if self.polite else 0))
             else:
                 ops.attn_dense(qk, qk[:, :, 512:], qk[:, :, 1024:], ao, B=B, H=8, Tq=T, Tk=T, ldq=1536, ldk=1536, ldv=1536, ldo=512,
                                q_bs=T * 1536, k_bs=T * 1536, v_bs=T * 1536, o_bs=T * 512, scale=0.125, dtype=dt, keymask=mask,

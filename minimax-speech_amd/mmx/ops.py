@@ -343,12 +343,13 @@ def attn_flash_x(q, k, v, out, *, B, H, T, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs,
 
 
 def attn_flash_xs(qk, vt, out, *, B, H, T, ldqk, ldvt, ldo, qk_bs, vt_bs, o_bs, scale, keymask=None, chunk=0, q_begin=0, km_bs=None,
-                  klen=None):
-    """The split build's flash attention on pre-split operands (include/mmx_hip.h): qk bf16 [B, T, >=2048], vt bf16 [B, 2, 512, ldvt]."""
+                  klen=None, form=0):
+    """The split build's flash attention on pre-split operands (include/mmx_hip.h): qk bf16 [B, T, >=2048], vt bf16 [B, 2, 512, ldvt].
+    form: 0 = workgroup shape chosen per launch, 1 = the co-residency-friendly shape (launches beside the decode loop)."""
     if klen is not None:
         assert klen.dtype == torch.int32 and klen.numel() >= B
     check(load().mmx_attn_flash_xs(_p(qk), i64(ldqk), i64(qk_bs), _p(vt), i64(ldvt), i64(vt_bs), _p(out), i64(ldo), i64(o_bs), B, H, T,
-                                   C.c_float(scale), _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen),
+                                   C.c_float(scale), _p(keymask), i64(T if km_bs is None else km_bs), chunk, q_begin, _p(klen), int(form),
                                    stream()), "mmx_attn_flash_xs")
 
 

@@ -25,7 +25,7 @@ def test_abi_symbols_declared_in_header_are_exported():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.mmx_abi_version() == 9
+    assert lib.mmx_abi_version() == 10
 
 
 def test_gemm_params_struct_matches_header_layout():

@@ -673,12 +673,14 @@ def test_weight_planes_flow_fused_and_per_op_vs_oracle():
     assert errs["fused, planes"] < 2e-3 and errs["per op, planes"] < 2e-3 and errs["fused, rounded"] > 5 * errs["fused, planes"]
 
 
-@pytest.mark.parametrize("B,T,chunk,ragged", [(6, 980, 0, False), (6, 980, 0, True), (10, 420, 50, False), (2, 300, 0, False), (16, 896, 0, True)])
-def test_attn_flash_xs_presplit_vs_float64(B, T, chunk, ragged):
+@pytest.mark.parametrize("B,T,chunk,ragged,form", [(6, 980, 0, False, 0), (6, 980, 0, True, 0), (10, 420, 50, False, 0), (2, 300, 0, False, 0), (16, 896, 0, True, 0),
+                                                    (6, 980, 0, True, 1), (10, 420, 50, False, 1), (6, 980, 0, True, 2), (10, 420, 50, True, 3), (2, 300, 0, False, 2)])
+def test_attn_flash_xs_presplit_vs_float64(B, T, chunk, ragged, form):
     """mmx_attn_flash_xs (operands split by the producer: bf16 rows [hi Q | hi K | lo Q | lo K], V transposed as two planes) against
     float64 attention of hi + lo, over launch shapes that take each of its three forms: 4 waves x 16 queries (small launches),
     8 x 16 and 8 x 32 queries (256 per workgroup, chosen when that grid needs fewer rounds of the 256 CUs: 6 x 980 and 10 x 420
-    here).  2^-17 per operand -> 4e-5 of the output range."""
+    here), and with the form given by the caller (1: the 128-query workgroups of the groups beside the decode loop, 2 / 3: the
+    256-query and the 4-wave 64-query workgroups).  2^-17 per operand -> 4e-5 of the output range."""
     from mmx import ops
     g = torch.Generator().manual_seed(B * 1000 + T)
     H, D = 8, 64
@@ -693,7 +695,7 @@ def test_attn_flash_xs_presplit_vs_float64(B, T, chunk, ragged):
     lens[0] = T
     out = torch.full((B, T, H * D), float("nan"), device="cuda")
     ops.attn_flash_xs(qk, vt, out, B=B, H=H, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=2 * 512 * Tp, o_bs=T * 512, scale=0.125,
-                      chunk=chunk, klen=(torch.tensor(lens, dtype=torch.int32, device="cuda") if ragged else None))
+                      chunk=chunk, klen=(torch.tensor(lens, dtype=torch.int32, device="cuda") if ragged else None), form=form)
     x = (hi.double() + lo.double()).reshape(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
     for b0 in range(0, B, 4):                                # float64 scores in slices of 4 batch rows (memory)
         xb = x[:, b0:b0 + 4]
