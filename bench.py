@@ -366,6 +366,7 @@ def main():
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
     ap.add_argument("--tpw2-min-tiles", type=int, default=None, help="tuning: two-tile workgroups only for est_tail launches of at least this many row tiles")
+    ap.add_argument("--sched-adapt", action="store_true", help="tts_batch's cost model follows its own measurements (TtsEngine.sched_adapt)")
     ap.add_argument("--flash-form", type=int, default=None, help="lab: mmx_attn_flash_xs form of the flow groups beside the decode loop (0 chosen per launch, 1 = 128-query workgroups [default], 2 = 256-query, 3 = 4-wave 64-query)")
     ap.add_argument("--tpw2", type=int, default=None, help="tuning: 1 / 0 = polite flow groups run est_tail with two / one row tiles per workgroup (FlowEngine.polite_tpw2; default: split build only)")
     ap.add_argument("--flow-priority", type=int, default=None, help="tuning: HIP stream priority of the flow workers' streams (TtsEngine.flow_priority)")
@@ -392,6 +393,9 @@ def main():
     if a.tpw2_min_tiles is not None:
         from mmx.flow import FlowEngine
         FlowEngine.polite_tpw2_min_tiles_default = a.tpw2_min_tiles
+    if a.sched_adapt:
+        from mmx.pipeline import TtsEngine
+        TtsEngine.sched_adapt = True
     if a.flash_form is not None:
         from mmx.flow import FlowEngine
         FlowEngine.polite_flash_form_default = a.flash_form
@@ -552,7 +556,8 @@ def main():
         out["collective"] = {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None)}
         lh = getattr(eng, "last_host", None)
         if lh:                                             # rank 0's last timed step: host issue time of the decode loop, when it ended, the whole call
-            out["host"] = dict(host, **lh, lm_issue_us_per_decode_step=round(lh["lm_issue_ms"] * 1e3 / max(1, lh["decode_steps"]), 1))
+            out["host"] = dict(host, **lh, lm_issue_us_per_decode_step=round(lh["lm_issue_ms"] * 1e3 / max(1, lh["decode_steps"]), 1),
+                               sched_model=getattr(eng, "sched", None), sched_fit=getattr(eng, "sched_fit", None))
         BUILD = {2: "split (bf16 weight stream; fp32 activations carried as 2 (flow, DAC) / 3 (LM) bf16 terms inside the MFMA products)",
                  1: "bf16 (bf16 GEMM inputs, fp32 residual streams)", 0: "fp32 (f32-input MFMA)"}
         out["config"]["build"] = BUILD[dt]

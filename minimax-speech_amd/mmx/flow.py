@@ -77,6 +77,9 @@ class Graphed:
     CAPTURE_LOCK (captures are serialised against each other only) and uses the thread-local capture mode, so other
     threads keep launching on their own streams meanwhile."""
 
+    cold_calls = 0          # calls (of any instance) that ran eagerly or captured instead of replaying: a caller that times itself
+                            # compares the counter before and after (TtsEngine._refit_sched)
+
     def __init__(self, fn, enabled=True):
         self.fn, self.enabled, self.graph, self.calls = fn, enabled, None, 0
 
@@ -95,6 +98,7 @@ class Graphed:
             return self.fn()
         if self.graph is None:
             self.calls += 1
+            Graphed.cold_calls += 1
             if self.calls == 1:
                 return self.fn()
             with CAPTURE_LOCK:

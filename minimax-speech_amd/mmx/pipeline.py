@@ -14,7 +14,7 @@ import torch
 from . import ops
 from ._lib import BF16, F32, TORCH_DT, X2, X3, is_split
 from .dac import DacDecoderEngine
-from .flow import FlowEngine
+from .flow import FlowEngine, Graphed
 from .llm import LlmEngine
 
 TOKEN_RATE = 25          # FSQ tokens per second (config.yaml:12)
@@ -55,6 +55,12 @@ class TtsEngine:
         self.flow = FlowEngine(flow_sd, dtype=dtype, device=device, use_graphs=use_graphs, attn=attn, wplanes=self.wplanes)
         self.dac = DacDecoderEngine(dac_sd, list(dac_rates), dtype=dtype, device=device, wplanes=self.wplanes)
         self.hop = self.dac.hop
+        # tts_batch's cost model of its own stages (ms): a decode step beside the flow; a flow group = group_ms + frame_ms per frame.
+        # Initial values: what _refit_sched measures for this build on one MI355X on the config-4 share (it re-measures them in
+        # every call: self.sched_fit; sched_adapt lets the model follow the fit)
+        self.sched = ({"step_ms": 1.05, "group_ms": 47.0, "frame_ms": 0.026} if is_split(dtype) else
+                      {"step_ms": 0.84, "group_ms": 35.0, "frame_ms": 0.009})
+        self.sched_fit, self._sched_prev = None, None
 
     # auxiliary streams per flow group for its per-utterance stages (conformer encoder, DAC decode); 1 = off.  Off by default:
     # measured on the config-4 rank share, 2 / 3 / 4 streams cost 15 % / 13 % / 32 % of the step (more queues beside the decode
@@ -478,7 +484,11 @@ class TtsEngine:
                         grp, ev, flow.polite = item
                         side.wait_event(ev)                      # the group's token ids were written on the LM stream
                         t_in = _time.perf_counter()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(side)
                         self._flow_dac_group(grp, toks, flow_embeddings, wavs, frame_quantum, flow, prompts)
+                        e1.record(side)                          # read after the call has drained: the scheduler's cost model
+                        group_events.append((sum(2 * toks[b].numel() for b in grp), flow.polite, e0, e1))
                         if _trace:
                             side.synchronize()
                             print(f"[tts_batch]   worker {wi}: group of {len(grp)} ({[2 * toks[b].numel() for b in grp]} frames) "
@@ -498,9 +508,12 @@ class TtsEngine:
         issued = [0]
         arrived, steps_done = {}, [1]
         free_at = [0.0] * flow_workers
-        # fitted to MMX_TIMING=3 traces of the round-3 kernels beside the decode loop (a decode step 0.86 ms; a flow group
-        # 44 ms + 9.5 us per frame: 536 frames 50 ms, 2 904 frames 74 ms, 4 196 frames 85 ms)
-        STEP_MS, GROUP_MS, FRAME_MS = 0.86, 44.0, 0.0095
+        # the scheduler's cost model (self.sched): a decode step STEP_MS; a flow group GROUP_MS + FRAME_MS per frame - measured by
+        # every call for itself (_refit_sched) and, with sched_adapt, followed when two steady calls in a row say it is off by more
+        # than SCHED_HYSTERESIS (a steady workload keeps one assignment - and one set of captured plans - from call to call)
+        STEP_MS, GROUP_MS, FRAME_MS = self.sched["step_ms"], self.sched["group_ms"], self.sched["frame_ms"]
+        group_events: list = []
+        cold0 = Graphed.cold_calls
 
         cur = [self.llm, list(range(NS))]                           # active engine, slot -> utterance index
         waiting = list(range(NS, B))                                # utterances waiting for a slot
@@ -622,4 +635,35 @@ class TtsEngine:
         # workers) on shared cores, and a slow host shows up here first)
         self.last_host = dict(decode_steps=done, lm_issue_ms=round(issue_s * 1e3, 2), lm_done_ms=round((t_lm - self._t0) * 1e3, 1),
                               call_ms=round((time.perf_counter() - self._t0) * 1e3, 1))
+        self._refit_sched(done, (t_lm - self._t0) * 1e3, group_events, steady=(Graphed.cold_calls == cold0 and B == NS))
         return wavs
+
+    SCHED_HYSTERESIS = 0.25
+    sched_adapt = False       # True: self.sched follows the measured fit (off by default: a change of the model moves groups between
+                              # workers, and a worker that meets a new group shape spends two calls capturing a plan for it)
+
+    def _refit_sched(self, steps, lm_ms, group_events, steady=True):
+        """The scheduler's cost model from this call's own clock: decode step = loop time / steps; group cost = least squares of
+        (frames, HIP-event duration) over the groups that ran beside the decode loop.  self.sched_fit always holds the latest fit;
+        with sched_adapt, self.sched (what the next call uses) follows it past SCHED_HYSTERESIS when two steady calls in a row gave the
+        same fit, one parameter at a time."""
+        if not steady:                                   # a call that captured plans (or queued utterances) times something else
+            self._sched_prev = None
+            return
+        fit = {"step_ms": lm_ms / max(1, steps)}
+        pts = [(f, e0.elapsed_time(e1)) for f, pol, e0, e1 in group_events if pol]
+        if len(pts) >= 3 and len({f for f, _ in pts}) >= 2:
+            n = float(len(pts))
+            sx, sy = sum(f for f, _ in pts), sum(t for _, t in pts)
+            sxx, sxy = sum(f * f for f, _ in pts), sum(f * t for f, t in pts)
+            den = n * sxx - sx * sx
+            slope = (n * sxy - sx * sy) / den if den > 0 else 0.0
+            if slope > 0 and (sy - slope * sx) / n > 0:
+                fit["frame_ms"], fit["group_ms"] = slope, (sy - slope * sx) / n
+        prev, self._sched_prev = self._sched_prev, fit
+        self.sched_fit = {k: round(v, 5) for k, v in fit.items()}
+        if not self.sched_adapt:
+            return
+        for k, v in fit.items():
+            if prev and k in prev and abs(v - prev[k]) <= 0.1 * prev[k] and abs(v - self.sched[k]) > self.SCHED_HYSTERESIS * self.sched[k]:
+                self.sched[k] = round(v, 5)

@@ -184,3 +184,34 @@ def test_bench_two_rank_rehearsal_gloo(tmp_path):
     lens = torch.randint(50, 501, (8,), generator=torch.Generator().manual_seed(3)).tolist()
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert abs(j["config"]["audio_s_per_step"] - sum(lens) / 25.0) < 0.01          # both ranks' utterances are counted
+
+
+def test_scheduler_cost_model_refit():
+    """TtsEngine._refit_sched (host logic of tts_batch): the fit of (decode step, group cost = a + b * frames) from a call's own
+    events; calls that captured plans are ignored; with sched_adapt the model follows two agreeing steady fits past the hysteresis."""
+    from types import SimpleNamespace
+    from mmx.pipeline import TtsEngine
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    def groups(a, b):
+        return [(f, True, Ev(0.0), Ev(a + b * f)) for f in (600, 1500, 2900, 4200)] + [(900, False, Ev(0.0), Ev(1e3))]   # (the last: not beside the loop)
+
+    eng = SimpleNamespace(sched={"step_ms": 1.0, "group_ms": 40.0, "frame_ms": 0.01}, sched_fit=None, _sched_prev=None, sched_adapt=False,
+                          SCHED_HYSTERESIS=TtsEngine.SCHED_HYSTERESIS)
+    TtsEngine._refit_sched(eng, 500, 600.0, groups(50.0, 0.02), steady=True)
+    assert abs(eng.sched_fit["step_ms"] - 1.2) < 1e-6 and abs(eng.sched_fit["group_ms"] - 50.0) < 1e-3 and abs(eng.sched_fit["frame_ms"] - 0.02) < 1e-6
+    assert eng.sched == {"step_ms": 1.0, "group_ms": 40.0, "frame_ms": 0.01}                      # reported, not adopted
+    eng.sched_adapt = True
+    TtsEngine._refit_sched(eng, 500, 2000.0, groups(300.0, 0.05), steady=False)                 # a call that captured plans
+    assert eng._sched_prev is None and eng.sched["frame_ms"] == 0.01
+    TtsEngine._refit_sched(eng, 500, 600.0, groups(50.0, 0.02), steady=True)                    # first steady fit: nothing to agree with yet
+    assert eng.sched["frame_ms"] == 0.01
+    TtsEngine._refit_sched(eng, 500, 606.0, groups(51.0, 0.0201), steady=True)                  # second: agrees, off by more than 25 %
+    assert abs(eng.sched["frame_ms"] - 0.0201) < 1e-6 and abs(eng.sched["group_ms"] - 51.0) < 1e-3
+    assert eng.sched["step_ms"] == 1.0                                                          # 1.21 is within the hysteresis of 1.0
