@@ -215,3 +215,14 @@ def test_scheduler_cost_model_refit():
     TtsEngine._refit_sched(eng, 500, 606.0, groups(51.0, 0.0201), steady=True)                  # second: agrees, off by more than 25 %
     assert abs(eng.sched["frame_ms"] - 0.0201) < 1e-6 and abs(eng.sched["group_ms"] - 51.0) < 1e-3
     assert eng.sched["step_ms"] == 1.0                                                          # 1.21 is within the hysteresis of 1.0
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md maps every exported entry point to the reference code it replaces; include/mmx_hip.h declares each one."""
+    from mmx import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "mmx_hip.h")).read()
+    assert [s for s in _lib.SYMBOLS if f"`{s}`" not in doc] == []
+    assert [s for s in _lib.SYMBOLS if not re.search(r"\b" + s + r"\(", hdr)] == []
+    assert f"mmx_abi_version() == {_lib.ABI_VERSION}" in doc
