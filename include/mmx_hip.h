@@ -324,7 +324,9 @@ int mmx_paged_attn(const void* q, int64_t ldq, int64_t q_bs, int B, int rows, in
  * bit 1 = use the one-workgroup-per-query-head kernel even where the GQA-shared one applies (bf16, page = 16, Hq = 7 Hkv:
  * one workgroup per kv head serves its 7 query heads, Q K^T on the MFMA with the queries split into bf16 hi + lo). */
 /* out_packed bits: 1 = output in the packed A-fragment order of T; 2 = force the per-head kernel; 4 = output as SPLIT PLANES
- * (see mmx_skinny2; dtype MMX_F32 / the split builds only); 8 = output as TWO fp16 planes (MMX_H2, same conditions). */
+ * (see mmx_skinny2; dtype MMX_F32 / the split builds only); 8 = output as TWO fp16 planes (MMX_H2, same conditions);
+ * 16 = the per-head kernel with ONE query head per workgroup at every batch size (default: from B * Hq > 256 on, two heads share a
+ * workgroup's K / V reads; same results bit for bit). */
 int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, int Hkv, int D, const float* inv_freq,
                     const float* rope_tab, const int32_t* pos, void* kc, void* vc, const int32_t* block_table, int max_pages, int page,
                     float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream);

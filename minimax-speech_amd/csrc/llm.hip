@@ -577,7 +577,11 @@ struct Raw8 {
 // OM: how the attention output is stored - 0 row-major T, 1 the packed A-fragment order of T (bf16 / fp32 builds, batch > 8),
 // 2 split planes (the split build: 3 bf16 planes hi + mid + lo in A-fragment order, csrc/decode.hip), 3 two fp16 planes hi + lo
 // (MMX_H2, csrc/decode.hip)
-template <typename T, int OM>
+// HP: query heads per workgroup.  HP = 2 (the default): the `group` query heads of a kv head are served by ceil(group / 2)
+// workgroups, each reading its K / V rows ONCE for two heads - at batch 32 and 7 heads per kv head 256 workgroups (one round of
+// the 256 CUs) instead of 448, and 4/7 of the L2 -> CU traffic that bounds this kernel (the cached rows are 205 KB per workgroup
+// at 400 fp32 keys: 2.9 us at the ~70 GB/s a CU draws from L2; every head's arithmetic is what it was, in the same order).
+template <typename T, int OM, int HP>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
     const float* __restrict__ rope_tab, const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc,
@@ -585,36 +589,37 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     int nseq) {
     // Single pass ("flash decoding" inside one workgroup): thread = (key group kg of 32, channel chunk dc of 8).
     // For each of its keys a thread loads 16 B of the K row and 16 B of the V row (both in flight together), the 8
-    // threads of a key reduce q.k with 3 xor-shuffles, every key group keeps its own running (max, sum, acc[8]);
+    // threads of a key reduce q.k with 3 xor-shuffles, every key group keeps its own running (max, sum, acc[8]) per head;
     // the 32 groups are merged once through LDS.  Two workgroup barriers in total; the block-table row is staged
     // in LDS up front so no load depends on another load except through `pos`.
     constexpr int D = 64, HALF = 32, NG = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* qs = reinterpret_cast<float*>(smem);        // [D] rope(q) * scale * log2(e)
-    float* kn = qs + D;                                // [D] new key (rounded through T)
+    float* qs = reinterpret_cast<float*>(smem);        // [HP][D] rope(q) * scale * log2(e)
+    float* kn = qs + HP * D;                           // [D] new key (rounded through T)
     float* vn = kn + D;                                // [D] new value
-    float* gm = vn + D;                                // [NG] group max
-    float* gl = gm + NG;                               // [NG] group sum
-    float* part = gl + NG;                             // [NG][D]
-    int* bts = reinterpret_cast<int*>(part + NG * D);  // [max_pages]
+    float* gm = vn + D;                                // [HP][NG] group max
+    float* gl = gm + HP * NG;                          // [HP][NG] group sum
+    float* part = gl + HP * NG;                        // [HP][NG][D]
+    int* bts = reinterpret_cast<int*>(part + HP * NG * D);  // [max_pages]
     const int tid = threadIdx.x;
     // XCD-aware work mapping: workgroups go to the 8 XCDs round robin by their linear id, and each XCD has its own L2.
-    // The `group` query heads that share one KV head read the same cache rows: they are given ids with the same
-    // id % 8, so those rows enter ONE L2 once instead of up to `group` L2s (at batch 32 and 300 keys the cache reads
+    // The workgroups of the query heads that share one KV head read the same cache rows: they are given ids with the same
+    // id % 8, so those rows enter ONE L2 once instead of several (at batch 32 and 300 keys the cache reads
     // of a layer are 4.9 MB unique, 34 MB when every head's XCD misses).
-    const int group = Hq / Hkv;
+    const int group = Hq / Hkv, nsub = (group + HP - 1) / HP;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int kvg = (slot / group) * 8 + xcd;          // (sequence, kv head) pair
+    const int kvg = (slot / nsub) * 8 + xcd;           // (sequence, kv head) pair
     if (kvg >= Hkv * nseq) return;                     // uniform: the grid is padded to a multiple of 8 pairs
-    const int b = kvg / Hkv, hk = kvg % Hkv, h = hk * group + slot % group;
+    const int b = kvg / Hkv, hk = kvg % Hkv, sub = slot % nsub;
+    const int h0 = hk * group + sub * HP, nh = min(HP, group - sub * HP);   // this workgroup's heads h0 .. h0 + nh - 1
     const int32_t* bt = block_table + (long)b * max_pages;
     for (int i = tid; i < max_pages; i += 256) bts[i] = bt[i];
     const int p = pos[b];
     const float* src = qkv + (long)b * ldqkv;
     const float sc2 = scale * 1.44269504088896341f;
-    if (tid < 2 * HALF) {
-        const int which = tid >> 5, d = tid & 31;      // 0: q head h, 1: k head hk
-        const float* x = src + (which == 0 ? h * D : (Hq + hk) * D);
+    if (tid < (HP + 1) * HALF) {
+        const int which = tid >> 5, d = tid & 31;      // 0 .. HP-1: q head h0 + which, HP: k head hk
+        const float* x = src + (which < HP ? (h0 + min(which, nh - 1)) * D : (Hq + hk) * D);
         float c, s;
         if (rope_tab) {                                // [pos][cos 0..31 | sin 0..31], computed like HF on the host
             c = rope_tab[(long)p * D + d];
@@ -625,36 +630,47 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             s = sinf(ang);
         }
         const float y0 = x[d] * c - x[d + HALF] * s, y1 = x[d + HALF] * c + x[d] * s;
-        if (which == 0) { qs[d] = y0 * sc2; qs[d + HALF] = y1 * sc2; }
+        if (which < HP) { qs[which * D + d] = y0 * sc2; qs[which * D + d + HALF] = y1 * sc2; }   // (a head beyond nh repeats the last one: never stored)
         else { kn[d] = Cvt<T>::to_f(Cvt<T>::from_f(y0)); kn[d + HALF] = Cvt<T>::to_f(Cvt<T>::from_f(y1)); }
-    } else if (tid < 2 * HALF + D) {
-        const int d = tid - 2 * HALF;
+    } else if (tid < (HP + 1) * HALF + D) {
+        const int d = tid - (HP + 1) * HALF;
         vn[d] = Cvt<T>::to_f(Cvt<T>::from_f(src[(Hq + Hkv + hk) * D + d]));
     }
     __syncthreads();
-    if (h % group == 0 && tid < D) {                   // one workgroup per kv head appends to the cache
+    if (sub == 0 && tid < D) {                         // one workgroup per kv head appends to the cache
         const long o = (((long)bts[p / page] * Hkv + hk) * page + p % page) * D + tid;
         kc[o] = Cvt<T>::from_f(kn[tid]);
         vc[o] = Cvt<T>::from_f(vn[tid]);
     }
     const int kg = tid >> 3, dc = tid & 7;
-    float qv[8];
+    float qv[HP][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] = qs[dc * 8 + e];
-    float m = -INFINITY, l = 0.f, acc[8];
+    for (int hp = 0; hp < HP; ++hp)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int e = 0; e < 8; ++e) qv[hp][e] = qs[hp * D + dc * 8 + e];
+    float m[HP], l[HP], acc[HP][8];
+#pragma unroll
+    for (int hp = 0; hp < HP; ++hp) {
+        m[hp] = -INFINITY;
+        l[hp] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[hp][e] = 0.f;
+    }
     auto consume = [&](const float kv[8], const float vv[8]) {
-        float sdot = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sdot += qv[e] * kv[e];
-        sdot = group8_sum(sdot);                       // the 8 threads of a key (DPP: no LDS round trip on the key chain)
-        const float mn = fmaxf(m, sdot);
-        const float al = __builtin_amdgcn_exp2f(m - mn), pj = __builtin_amdgcn_exp2f(sdot - mn);
-        l = l * al + pj;
+        for (int hp = 0; hp < HP; ++hp) {
+            // (explicit fused multiply-adds: every instantiation rounds alike, whatever the compiler would contract)
+            float sdot = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * al + pj * vv[e];
-        m = mn;
+            for (int e = 0; e < 8; ++e) sdot = __builtin_fmaf(qv[hp][e], kv[e], sdot);
+            sdot = group8_sum(sdot);                   // the 8 threads of a key (DPP: no LDS round trip on the key chain)
+            const float mn = fmaxf(m[hp], sdot);
+            const float al = __builtin_amdgcn_exp2f(m[hp] - mn), pj = __builtin_amdgcn_exp2f(sdot - mn);
+            l[hp] = __builtin_fmaf(l[hp], al, pj);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[hp][e] = __builtin_fmaf(acc[hp][e], al, pj * vv[e]);
+            m[hp] = mn;
+        }
     };
     // cached keys: U keys per thread in flight at a time (the loop is a chain of memory round trips otherwise:
     // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys
@@ -686,23 +702,30 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
         for (int e = 0; e < 8; ++e) { kv[e] = kn[dc * 8 + e]; vv[e] = vn[dc * 8 + e]; }
         consume(kv, vv);
     }
-    if (dc == 0) { gm[kg] = m; gl[kg] = l; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[kg * D + dc * 8 + e] = acc[e];
+    for (int hp = 0; hp < HP; ++hp) {
+        if (dc == 0) { gm[hp * NG + kg] = m[hp]; gl[hp * NG + kg] = l[hp]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(hp * NG + kg) * D + dc * 8 + e] = acc[hp][e];
+    }
     __syncthreads();
-    if (tid < D) {
+    if (tid < nh * D) {
+        const int hp = tid >> 6, d = tid & 63, h = h0 + hp;
+        const float* gmh = gm + hp * NG;
+        const float* glh = gl + hp * NG;
+        const float* ph = part + hp * NG * D;
         float M = -INFINITY;
 #pragma unroll
-        for (int g2 = 0; g2 < NG; ++g2) M = fmaxf(M, gm[g2]);
+        for (int g2 = 0; g2 < NG; ++g2) M = fmaxf(M, gmh[g2]);
         float L = 0.f, o = 0.f;
 #pragma unroll
         for (int g2 = 0; g2 < NG; ++g2) {
-            const float w = __builtin_amdgcn_exp2f(gm[g2] - M);      // empty groups: exp2(-inf) = 0
-            L += gl[g2] * w;
-            o += part[g2 * D + tid] * w;
+            const float w = __builtin_amdgcn_exp2f(gmh[g2] - M);     // empty groups: exp2(-inf) = 0
+            L = __builtin_fmaf(glh[g2], w, L);
+            o = __builtin_fmaf(ph[g2 * D + d], w, o);
         }
         if constexpr (OM == 2) {
-            const int nkb = Hq * D / 32, col = h * D + tid;
+            const int nkb = Hq * D / 32, col = h * D + d;
             const long ps = (long)((nseq + 15) / 16) * nkb * 512;
             const long idx = ((((long)(b >> 4) * nkb + (col >> 5)) * 64) + (((col & 31) >> 3) << 4) + (b & 15)) * 8 + (col & 7);
             bf16_t* pl = reinterpret_cast<bf16_t*>(out);
@@ -714,7 +737,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             pl[ps + idx] = mm;
             pl[2 * ps + idx] = f2bf(r1 - bf2f(mm));
         } else if constexpr (OM == 3) {
-            const int nkb = Hq * D / 32, col = h * D + tid;
+            const int nkb = Hq * D / 32, col = h * D + d;
             const long ps = (long)((nseq + 15) / 16) * nkb * 512;
             const long idx = ((((long)(b >> 4) * nkb + (col >> 5)) * 64) + (((col & 31) >> 3) << 4) + (b & 15)) * 8 + (col & 7);
             unsigned short* pl = reinterpret_cast<unsigned short*>(out);
@@ -723,7 +746,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             pl[idx] = __builtin_bit_cast(unsigned short, hh);
             pl[ps + idx] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)hh));
         } else {
-            out[OM == 1 ? act_packed_index<T>(b, h * D + tid, Hq * D) : (long)b * ldo + h * D + tid] = Cvt<T>::from_f(o / L);
+            out[OM == 1 ? act_packed_index<T>(b, h * D + d, Hq * D) : (long)b * ldo + h * D + d] = Cvt<T>::from_f(o / L);
         }
     }
 }
@@ -954,18 +977,25 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
                                int page, float scale, void* out, int64_t ldo, int dtype, int out_packed, hipStream_t stream) {
     dtype = MMX_ACT_DTYPE(dtype);
     MMX_CHECK_ARG(qkv && (inv_freq || rope_tab) && pos && kc && vc && block_table && out && B > 0 && D == 64 && Hq % Hkv == 0 && page > 0);
-    MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 15);
+    MMX_CHECK_ARG(out_packed >= 0 && out_packed <= 31);
     const bool gqa_shared = !(out_packed & 2);         // bit 1: force the per-head kernel (A/B measurements, tests)
     const bool split_out = out_packed & 4;             // bit 2: output as split planes (fp32 build of the kernel only)
     const bool split_h2 = out_packed & 8;              // bit 3: output as two fp16 planes (MMX_H2; fp32 build of the kernel only)
+    // bit 4: one query head per workgroup whatever the batch (measurements, tests).  Default: two heads per workgroup only where one
+    // head per workgroup needs more than one round of the 256 CUs (batch > 18 at 14 heads: the kernel is bound by what a CU draws
+    // from L2 there - 882 against 916 us per decode step at batch 32); below that a workgroup's own latency chain is the bound and
+    // the second head only lengthens it
+    const bool one_head = (out_packed & 16) || (long)B * Hq <= 256;
     MMX_CHECK_ARG(!(split_out || split_h2) || (dtype == MMX_F32 && !(out_packed & 1) && !(split_out && split_h2)));
     out_packed &= 1;
     const size_t max_ctx = (size_t)max_pages * page;
     (void)max_ctx;
-    size_t lds = (3 * 64 + 2 * 32 + 32 * 64 + (size_t)max_pages) * 4;
-    MMX_CHECK_ARG(lds <= 160 * 1024);
-    dim3 grid(8 * ((Hkv * B + 7) / 8) * (Hq / Hkv));
-#define DA(T, OM) hipLaunchKernelGGL((decode_attn_kernel<T, OM>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B)
+    const int hp = one_head ? 1 : 2, nsub = (Hq / Hkv + hp - 1) / hp;
+    size_t lds = ((size_t)hp * 64 + 2 * 64 + 2 * hp * 32 + (size_t)hp * 32 * 64 + (size_t)max_pages) * 4;
+    MMX_CHECK_ARG(lds <= 64 * 1024);
+    dim3 grid(8 * ((Hkv * B + 7) / 8) * nsub);
+#define DA(T, OM) do { if (one_head) hipLaunchKernelGGL((decode_attn_kernel<T, OM, 1>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B); \
+                       else hipLaunchKernelGGL((decode_attn_kernel<T, OM, 2>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B); } while (0)
     if (dtype == MMX_BF16 && page == 16 && Hq == 7 * Hkv && gqa_shared) {
         const size_t lds2 = (2 * 16 * 64 + 2 * 64) * 2 + (4 * 8 * 16 * 8 + 3 * 32 + 32 * 7 * 64 + (size_t)max_pages) * 4;
         MMX_CHECK_ARG(lds2 <= 160 * 1024);

@@ -481,13 +481,14 @@ def paged_attn(q, pos, kc, vc, block_table, out, *, B, rows, Hq, Hkv, page, dtyp
 
 
 def decode_attn(qkv, inv_freq, pos, kc, vc, block_table, out, *, B, Hq, Hkv, page, dtype, rope_tab=None, out_packed=False,
-                per_head=False, out_split=False):
-    """per_head: the one-workgroup-per-query-head kernel even where the GQA-shared one applies (measurements, tests).
+                per_head=False, out_split=False, one_head=False):
+    """per_head: the per-query-head kernel even where the GQA-shared one applies (measurements, tests); one_head: that kernel with
+    one head per workgroup instead of two (the round-3 form; identical results).
     out_split: `out` receives split planes (the split build's decode step, include/mmx_hip.h): True = three bf16 planes,
     "f16" = two fp16 planes (MMX_H2)."""
     check(load().mmx_decode_attn(_p(qkv), i64((Hq + 2 * Hkv) * 64), B, Hq, Hkv, 64, _p(inv_freq), _p(rope_tab), _p(pos), _p(kc),
                                  _p(vc), _p(block_table), block_table.shape[1], page, C.c_float(0.125), _p(out),
-                                 i64(Hq * 64), dtype, int(bool(out_packed)) | (2 if per_head else 0) | (8 if out_split == "f16" else (4 if out_split else 0)), stream()), "mmx_decode_attn")
+                                 i64(Hq * 64), dtype, int(bool(out_packed)) | (2 if per_head else 0) | (8 if out_split == "f16" else (4 if out_split else 0)) | (16 if one_head else 0), stream()), "mmx_decode_attn")
 
 
 def swiglu(gu, out, *, rows, I, dtype):

@@ -439,6 +439,11 @@ def test_decode_attn_one_token(env, dt, per_head, ctx):
         ops.decode_attn(qkv, inv, pos, kc, vc, bt, out, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=dt, out_packed=packed,
                         per_head=per_head, rope_tab=tab)
         got = ops.unpack_act(out, B, Hq * D, dt).float().cpu() if packed else out[:B].float().cpu()
+        if dt == 0 or per_head:                            # two query heads per workgroup (the default) = one per workgroup, bit for bit
+            kc1, vc1, out1 = kc0.clone(), vc0.clone(), torch.zeros_like(out)
+            ops.decode_attn(qkv, inv, pos, kc1, vc1, bt, out1, B=B, Hq=Hq, Hkv=Hkv, page=page, dtype=dt, out_packed=packed,
+                            per_head=per_head, rope_tab=tab, one_head=True)
+            assert torch.equal(out1, out) and torch.equal(kc1, kc) and torch.equal(vc1, vc)
         for b in range(B):
             n = lens[b]
             rows = [(int(bt[b, j // page]), j % page) for j in range(n)]
