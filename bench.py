@@ -149,7 +149,7 @@ def _time_est_tail(fl, n, T, polite=False):
     was, fl.polite = fl.polite, polite                  # the tiling the step used for this group (FlowEngine.polite)
     bm, _ = fl._tile_rows(B, T)
     fl.polite = was
-    tpw2 = bool(polite and (fl.split if fl.polite_tpw2 is None else fl.polite_tpw2) and bm in (32, 64)
+    tpw2 = bool(polite and (fl.split if fl.polite_tpw2 is None else fl.polite_tpw2) and bm == 32 and fl.split
                 and B * ((T + bm - 1) // bm) >= fl.polite_tpw2_min_tiles)
 
     def one(i=0):

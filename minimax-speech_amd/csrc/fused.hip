@@ -102,6 +102,59 @@ __device__ __forceinline__ void stage_run(WRing<T, RW, PF>& ring, const char* a_
     // 256 at MF = 4; the LDS latency is ~130 cycles)
     constexpr int AD = (PF % 2) ? PF : ((MF == 1 && PF >= 4) ? 4 : 2);
     static_assert(PF % AD == 0, "ring depths");
+    // 64-row split tile (two planes x four m-fragments): the A fragments are read per (k-step, plane) unit, one unit ahead of
+    // its MFMAs - 32 instead of 64 registers (the k-step-ahead form spilled 76 bytes per lane).  Same MFMA order per accumulator.
+    if constexpr (NS == 2 && MF == 4) {
+        frag_t a2[2][MF];
+        int rt = 0, rc = 0, rs = 0, rp = 0;
+        auto read_u = [&](frag_t (&dst)[MF]) {
+            const char* ap = a_lane + rt * tap_pitch + rc * (KB * (int)sizeof(T)) + rp * plane;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) dst[i] = *reinterpret_cast<const frag_t*>(ap + i * 16 * pitch);
+            if (rp == 0) rp = 1;
+            else {
+                rp = 0;
+                if (rs + 1 < nk) {                         // past the end: re-read the last k-step (never used)
+                    ++rs;
+                    if (++rc == cin_steps) { rc = 0; ++rt; }
+                }
+            }
+        };
+        auto group2 = [&](int ks, auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                frag_t b[NF];
+#pragma unroll
+                for (int jj = 0; jj < NF; ++jj) b[jj] = __builtin_bit_cast(frag_t, ring.w[p][jj]);
+                if constexpr (LAST) {
+                    if (wbn) {
+                        const T* src = wbn + (long)(p < nkn ? p : nkn - 1) * 64 * E;
+#pragma unroll
+                        for (int jj = 0; jj < RW; ++jj) ring.w[p][jj] = *reinterpret_cast<const u32x4_t*>(src + (jj < nfn ? jj : 0) * nsn);
+                    }
+                } else {
+                    const T* src = wb + (long)(ks + p + PF) * 64 * E;
+#pragma unroll
+                    for (int jj = 0; jj < NF; ++jj) ring.w[p][jj] = *reinterpret_cast<const u32x4_t*>(src + jj * ns);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    read_u(a2[(s2 + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < NF; ++jj) acc[i][jj] = mma<T>(a2[s2][i], b[jj], acc[i][jj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        read_u(a2[0]);
+        for (int ks = 0; ks + PF < nk; ks += PF) group2(ks, std::false_type{});
+        group2(nk - PF, std::true_type{});
+        return;
+    }
     frag_t a[AD][NS][MF];
     int rt = 0, rc = 0, rs = 0;                        // tap / k-step inside the tap / k-step of the next A read
     auto read_a = [&](frag_t (&dst)[NS][MF]) {
@@ -202,6 +255,34 @@ __device__ __forceinline__ void to_rows(const float4_t (&acc)[NF], float* patch,
         v[c] = t[0]; v[c + 1] = t[1]; v[c + 2] = t[2]; v[c + 3] = t[3];
     }
     __builtin_amdgcn_wave_barrier();                   // the patch is rewritten by the next fragment
+}
+
+// The same conversion through a ONE-fragment patch (16 rows of 16 + 4 floats) for the 64-row split tile, whose two-plane tiles leave
+// 10 KB of LDS for all eight patches: fragment j serves the lanes whose 8 columns lie in it ((lane & 3) >> 1 == j).  Same values in
+// the same lanes as to_rows<2>.
+constexpr int SPATCH_FLOATS = 16 * 20;
+__device__ __forceinline__ void to_rows_sp(const float4_t (&acc)[2], float* patch, int lane, float (&v)[8]) {
+    constexpr int LDC = 20;
+    const int g = lane >> 4, l16 = lane & 15;
+    const float* src = patch + (lane >> 2) * LDC + (lane & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(4 * g + r) * LDC + l16] = acc[j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (((lane >> 1) & 1) == j) {
+            const float4_t t0 = *reinterpret_cast<const float4_t*>(src), t1 = *reinterpret_cast<const float4_t*>(src + 4);
+            v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3];
+            v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
+        }
+        __builtin_amdgcn_wave_barrier();               // the patch is rewritten by the next fragment
+    }
+}
+template <int NF, bool SP>
+__device__ __forceinline__ void rows_of(const float4_t (&acc)[NF], float* patch, int lane, float (&v)[NF * 4]) {
+    if constexpr (SP) { static_assert(NF == 2, "one-fragment patch: 32-column slices"); to_rows_sp(acc, patch, lane, v); }
+    else to_rows<NF>(acc, patch, lane, v);
 }
 
 template <int N>
@@ -392,7 +473,7 @@ __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lan
 }
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
-template <typename T, int MF, int PF, int NW, int NS = 1, int PW = 4, bool WP = false>
+template <typename T, int MF, int PF, int NW, int NS = 1, int PW = 4, bool WP = false, bool SP = false>
 __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n1g)[64 / NW], const float (&n1b)[64 / NW],
                                        const MmxEstNext& nx, float eps, char* a1, float* patch, float* stats,
                                        WRing<T, PW, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0,
@@ -436,6 +517,35 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
                 bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)s2 * 512 * nx.ldvt + (long)cw * nx.ldvt + t0;
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
+                    if constexpr (SP) {                // one-fragment patch: 16 columns x 16 frames at a time, lanes 0..31 store
+#pragma unroll
+                        for (int j = 0; j < PW; ++j) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                            pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                            *reinterpret_cast<uint2*>(vw + l16 * PV + (4 * g) * 2) = pk;
+                            if (s2 + 1 < NS) {
+                                acc[i][j][0] -= __uint_as_float(pk.x << 16); acc[i][j][1] -= __uint_as_float(pk.x & 0xffff0000u);
+                                acc[i][j][2] -= __uint_as_float(pk.y << 16); acc[i][j][3] -= __uint_as_float(pk.y & 0xffff0000u);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const int colv = j * 16 + ((lane & 31) >> 1), c8 = lane & 1;
+                            uint4 v = *reinterpret_cast<const uint4*>(vw + ((lane & 31) >> 1) * PV + c8 * 16);
+                            const int t = t0 + i * 16 + c8 * 8;
+                            if (lane < 32 && t < Tn) {
+                                if (t + 8 > Tn) {
+                                    unsigned short* h = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e)
+                                        if (t + e >= Tn) h[e] = 0;
+                                }
+                                *reinterpret_cast<uint4*>(dst + (long)colv * nx.ldvt + i * 16 + c8 * 8) = v;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < PW; ++j) {
                         uint2 pk;
@@ -472,7 +582,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[4 * PW], lo[4 * PW];
-                to_rows<PW>(acc[i], patch, lane, v);
+                rows_of<PW, SP>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
                 if (t < Tn) {
 #pragma unroll
@@ -487,7 +597,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[4 * PW];
-                to_rows<PW>(acc[i], patch, lane, v);
+                rows_of<PW, SP>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
                 if (t < Tn) storen_T<TI, 4 * PW>(out + (long)t * nx.ldq + col, v);
             }
@@ -510,10 +620,16 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 // its use, less than an L2 hit takes, so the one-wave-per-SIMD kernel waits in every k-step (tools/tail_lab.py --stamps).
 template <typename T, int BM, int PF, int NW, int NS, int PW, bool WP = false>
 __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const int tile) {
-    constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = 512;
+    // HK (the split build's 64-row tile: two bf16 planes of 64 rows): the 512-wide attention tile enters as two K halves of 256 -
+    // the first in buf0, the second in a1, which the out projection is done with before LayerNorm writes it - and the FF
+    // intermediate passes in four chunks of 256 columns, so that buf0 and a1 are both [2][64][256]: 136 KB + 10 KB of one-fragment
+    // patches (to_rows_sp).  Same arithmetic in the same order per row as the 32-row tile: bit-identical results.
+    constexpr bool HK = NS == 2 && BM == 64 && sizeof(T) == 2;
+    static_assert(!HK || (NW == 8 && PW == 2 && !WP), "64-row split tile: 8 waves, 32-column passes");
+    constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = HK ? 256 : 512, NCH = CF / CH;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PC = 16 * PW, PPC = CH / (PC * NW);
     static_assert(NFN <= PW, "the ring is PW fragments wide");
-    constexpr int P0 = tile_pitch(CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
+    constexpr int P0 = tile_pitch(HK ? C : CI, sizeof(T)), P1 = tile_pitch(C, sizeof(T));
     constexpr int PL0 = BM * P0, PL1 = BM * P1;        // bytes between the planes of a tile (split build)
     // GELU: the fp32 build takes libm's erff; the split build erf_fast (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 absolute -
     // two orders below the 2^-17 its products keep; erff was 3.96 us of every FF1 epilogue, 15 % of the kernel:
@@ -525,7 +641,8 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     char* buf0 = smem;                                 // [NS][BM][512] attention output, then the FF intermediate chunk
     char* a1 = buf0 + NS * PL0;                        // [NS][BM][256] LayerNorm output (A operand of FF1 / QKV)
     float* patch_all = reinterpret_cast<float*>(a1 + NS * PL1);
-    float* stats = patch_all + NW * PATCH_FLOATS;      // [BM][NW]
+    constexpr int PATCHF = HK ? SPATCH_FLOATS : PATCH_FLOATS;
+    float* stats = patch_all + NW * PATCHF;            // [BM][NW]
     // the block's bias / LayerNorm vectors: bo | n3g | n3b | b2 | n1g | n1b (256 each) | b1 (1024).  Epilogues read them
     // from here (lgkmcnt) instead of holding them in registers from before the preceding MFMA stage: a global load issued
     // in an epilogue would wait behind the weight ring (vmcnt counts in issue order)
@@ -533,7 +650,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     constexpr int PRM_BO = 0, PRM_N3G = 256, PRM_N3B = 512, PRM_B2 = 768, PRM_N1G = 1024, PRM_N1B = 1280, PRM_B1 = 1536;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15, rl = lane >> 2;
-    float* patch = patch_all + wave * PATCH_FLOATS;
+    float* patch = patch_all + wave * PATCHF;
     const int b = blockIdx.y, t0 = p.t_begin + tile * BM, Tn = p.T;
     const int col0 = wave * WC + (lane & 3) * CW;      // this lane's CW columns of a 256-wide row
     unsigned long long* st = nullptr;
@@ -546,7 +663,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     const T* wo = reinterpret_cast<const T*>(p.wo) + (long)lane * E;
     const T* w1 = reinterpret_cast<const T*>(p.w1) + (long)lane * E;
     const T* w2 = reinterpret_cast<const T*>(p.w2) + (long)lane * E;
-    constexpr int NK0 = CI / KB, NK1 = C / KB, NK2 = CH / KB, NK2T = CF / KB;
+    constexpr int NK0 = CI / KB, NK1 = C / KB, NK2 = CH / KB, NK2T = CF / KB, NKH = NK0 / 2;
     const long ns0 = (long)NK0 * 64 * E, ns1 = (long)NK1 * 64 * E, ns2 = (long)NK2T * 64 * E;
     WRing<T, PW, PF> ring;
     const T* wo_w = wo + (long)(wave * NFN) * ns0;     // this wave's NFN n-fragments of the 256 output columns
@@ -583,7 +700,10 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             }
         }
         ring.prime(wo_w, ns0, NK0, NFN);
-        if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
+        if constexpr (HK) {
+            load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, C, buf0, P0, PL0, tid, 64 * NW);
+            load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs + C, p.ldao, t0, Tn, BM, C, a1, P1, PL1, tid, 64 * NW);
+        } else if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
         else load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, PL0, tid, 64 * NW);
 #pragma unroll
         for (int k = 0; k < PRM_PER; ++k) {
@@ -595,6 +715,10 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         TSTAMP(2);
         float4_t acc[MF][NFN];
         zero_acc(acc);
+        if constexpr (HK) {                            // k-steps 0 .. 7 over buf0, 8 .. 15 over a1: one accumulator, ascending k
+            stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NKH, wo_w, ns0, NKH, wo_w + (long)NKH * 64 * E, ns0, NKH, NFN, acc, PL0);
+            stage_run<T, MF, NFN, PF, NS, PW>(ring, a1 + l16 * P1 + g * 16, P1, NKH, wo_w + (long)NKH * 64 * E, ns0, NKH, w1_pass(0), ns1, NK1, PW, acc, PL1);
+        } else
         stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, (long)C * CI, w1_pass(0), ns1, NK1, PW, acc, PL0);
         TSTAMP(3);
         float bo[CW];
@@ -602,7 +726,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[CW];
-            to_rows<NFN>(acc[i], patch, lane, v);
+            rows_of<NFN, HK>(acc[i], patch, lane, v);
 #pragma unroll
             for (int c = 0; c < CW; ++c) x1[i][c] += v[c] + bo[c];
             // PARK: the residual rows wait in HBM (x, in place) for the closing epilogue instead of in 8 * MF registers
@@ -636,7 +760,9 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     zero_acc(acc2);
     const T* w2_w = w2 + (long)(wave * NFN) * ns2;     // FF2: this wave's output columns, K walked per chunk
     float rm[MF];
-    for (int ch = 0; ch < 2; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
+        // (lab stamps) HK: five per chunk from 6 on; otherwise the round-3 numbering
+        const int sb = HK ? 6 + ch * 5 : 0;
         for (int h = 0; h < PPC; ++h) {
             const int q = ch * PPC + h;
             const int hc = (wave * PPC + h) * PC + (lane & 3) * (4 * PW);   // column inside the chunk
@@ -646,22 +772,22 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             const T* wn = more ? w1_pass(q + 1) : w2_w + (long)(ch * NK2) * 64 * E;
             stage_run_w<T, MF, PW, PF, NS, PW, WP>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, (long)CF * C, wn, more ? ns1 : ns2,
                                                    more ? NK1 : NK2, more ? PW : NFN, acc, PL1);
-            TSTAMP(6 + ch * 12 + h * 2);
+            TSTAMP(HK ? sb : 6 + ch * 12 + h * 2);
             float b1[4 * PW];
             loadn<4 * PW>(prm + PRM_B1 + ch * CH + hc, b1);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[4 * PW];
-                to_rows<PW>(acc[i], patch, lane, v);
+                rows_of<PW, HK>(acc[i], patch, lane, v);
 #pragma unroll
                 for (int c = 0; c < 4 * PW; ++c) v[c] = act_c<((PRECISE || NS > 1) ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
                 store_tile<T, NS, 4 * PW>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
             }
-            TSTAMP(7 + ch * 12 + h * 2);
+            TSTAMP(HK ? sb + 1 : 7 + ch * 12 + h * 2);
         }
         __syncthreads();                               // the chunk is complete
-        TSTAMP(14 + ch * 12);
-        if (ch == 1) {                                 // global operands of the closing epilogue
+        TSTAMP(HK ? sb + 2 : 14 + ch * 12);
+        if (ch == NCH - 1) {                           // global operands of the closing epilogue
             const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
@@ -672,11 +798,11 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
                 }
             }
         }
-        const T* wn = ch == 0 ? w1_pass(PPC) : (p.next.wqkv ? qkv_pass<T, NW, PW>(p.next.wqkv, wave, lane, 0) : nullptr);
+        const T* wn = ch + 1 < NCH ? w1_pass((ch + 1) * PPC) : (p.next.wqkv ? qkv_pass<T, NW, PW>(p.next.wqkv, wave, lane, 0) : nullptr);
         stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, (long)C * CF, wn, ns1, NK1, PW, acc2, PL0);
-        TSTAMP(15 + ch * 12);
+        TSTAMP(HK ? sb + 3 : 15 + ch * 12);
         __syncthreads();                               // every wave is done reading the chunk
-        TSTAMP(16 + ch * 12);
+        TSTAMP(HK ? sb + 4 : 16 + ch * 12);
     }
     // ---- + bias + residual -> x (fp32 residual stream, in place)
     {
@@ -686,7 +812,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[CW];
-            to_rows<NFN>(acc2[i], patch, lane, v);
+            rows_of<NFN, HK>(acc2[i], patch, lane, v);
             const int t = t0 + i * 16 + rl;
 #pragma unroll
             for (int c = 0; c < CW; ++c) x1[i][c] = (x1[i][c] + v[c] + b2[c]) * rm[i];
@@ -702,7 +828,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         float n1g[CW], n1b[CW];
         loadn<CW>(prm + PRM_N1G + col0, n1g);
         loadn<CW>(prm + PRM_N1B + col0, n1b);
-        ln_qkv<T, MF, PF, NW, NS, PW, WP>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
+        ln_qkv<T, MF, PF, NW, NS, PW, WP, HK>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
     }
     TSTAMP(63);
 }
@@ -1068,6 +1194,8 @@ size_t dac_ru_lds(int dil) {
 
 template <typename T, int BM, int NW, int NS = 1>
 size_t tail_lds() {
+    if (NS == 2 && BM == 64 && sizeof(T) == 2)         // the split build's 64-row tile (HK in est_tail_tile)
+        return (size_t)NS * 2 * BM * tile_pitch(256, sizeof(T)) + (size_t)NW * SPATCH_FLOATS * 4 + (size_t)BM * NW * 4 + (size_t)TAIL_PRM_FLOATS * 4;
     return NS * ((size_t)BM * tile_pitch(512, sizeof(T)) + (size_t)BM * tile_pitch(256, sizeof(T))) + (size_t)NW * PATCH_FLOATS * 4 + (size_t)BM * NW * 4 +
            (size_t)TAIL_PRM_FLOATS * 4;
 }
@@ -1154,11 +1282,14 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     // library defaults of the bf16 build (cfg = 0): the narrow-pass 8-wave kernels for the 64- and 32-row tiles (measured per
     // launch at 10 000 rows: 51.1 us against 58.7 us with 4 waves x 64-column passes; 32 rows, 4 000 rows: 31.8 against 33.0)
     if (cfg == 0 && dtype == MMX_BF16 && (bm == 64 || bm == 32)) { narrow = 1; pf = bm == 64 ? 2 : 8; }
+    // split build, 64 rows: two planes of 64 rows fit with the attention tile in K halves and 256-wide FF chunks (est_tail_tile, HK)
+    if (dtype == MMX_X2 && bm == 64) { narrow = 1; if (pf != 4) pf = 2; }
     if (occ2) return MMX_EARG;                         // (two 4-wave workgroups per CU: measured slower everywhere, spilled; removed)
     if (narrow) {                                      // 8 waves, 32-column passes (PW = 2)
         if (dtype == MMX_BF16 && bm == 64) TAILP(bf16_t, 64, 2, 8, 1, 1, 2);
         else if (dtype == MMX_BF16 && bm == 32) { if (pf == 8) TAILP(bf16_t, 32, 8, 8, 1, 1, 2); else TAILP(bf16_t, 32, 4, 8, 1, 1, 2); }
         else if (dtype == MMX_X2 && bm == 32) { if (pf == 2) TAILP(bf16_t, 32, 2, 8, 2, 1, 2); else TAILP(bf16_t, 32, 4, 8, 2, 1, 2); }
+        else if (dtype == MMX_X2 && bm == 64) { if (pf == 4) TAILP(bf16_t, 64, 4, 8, 2, 1, 2); else TAILP(bf16_t, 64, 2, 8, 2, 1, 2); }
         else return MMX_EARG;
     } else if (dtype == MMX_X2) {
         // split build: two bf16 planes per LDS tile, so the largest tile is 32 rows (137 KB with 8 waves)

@@ -668,11 +668,15 @@ class FlowEngine:
     # through its CU's memory pipe, so a workgroup takes this long whatever else runs; with more of the chip streaming the
     # same weights it takes up to 45 % longer (256 workgroups: 34 / 42 / 65 us)
     _WG_US = {16: 27.1, 32: 29.9, 64: 44.1}
+    # the same for the split build (two MFMAs per weight fragment; 64 rows: the K-halved tile of est_tail_tile, 8 waves):
+    # profiles/r04_tail_lab64_x.txt - 1 000 rows: 29.1 / 35.8 / 62.3; 256 workgroups: - / 53.6 / 92.5
+    _WG_US_X = {16: 29.1, 32: 35.8, 64: 62.3}
 
     @classmethod
-    def _launch_us(cls, bm, tiles):
+    def _launch_us(cls, bm, tiles, split=False):
         """Model of one est_tail launch: full rounds of 256 workgroups, then the remainder."""
-        t = lambda n: cls._WG_US[bm] * (1.0 + 0.45 * (n / 256.0) ** 2)
+        wg = (cls._WG_US_X if split else cls._WG_US)[bm]
+        t = lambda n: wg * (1.0 + 0.45 * (n / 256.0) ** 2)
         full, rem = divmod(tiles, 256)
         return full * t(256) + (t(rem) if rem else 0.0)
 
@@ -685,10 +689,16 @@ class FlowEngine:
             bm = max(bm, getattr(self, "min_tile_rows", 16), 64 if self.polite else 16)
             return bm, bm
         if self.split:
-            # two bf16 planes per LDS tile: 32 rows is the largest tile (the 512-channel ResNet of the up block: 16, see
-            # _estimator_fused); 16-row tiles only when 32-row ones would leave most of the chip idle
-            bm = 32 if (tiles(32) >= 128 or self.polite) else 16
-            return bm, bm
+            # two bf16 planes per LDS tile: the ResNet kernel's largest tile is 32 rows (the 512-channel ResNet of the up block:
+            # 16, see _estimator_fused); the tail kernel has a 64-row form (attention tile in K halves, 256-wide FF chunks) whose
+            # MFMA stages run at the MFMA's rate instead of the weight stream's: the tile with the shortest launch, and 64 rows
+            # (half the workgroups of the 32-row tile at 0.85 of its time per row) beside the decode loop
+            cap = getattr(self, "max_tile_rows", 64)
+            bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (self._launch_us(b, tiles(b), True), -b))
+            if self.polite:
+                bm = max(bm, min(cap, 64))
+            br = 32 if (tiles(32) >= 128 or self.polite) else 16
+            return bm, br
         return (32 if tiles(32) >= 128 else 16), 16            # fp32: tail, resnet (LDS: fp32 tiles are twice as large)
 
     def _estimator_fused(self, x, x_bstride, mu, spks, cond, t, B, T, mask, streaming, out, x_mod, klen=None):
@@ -752,7 +762,7 @@ class FlowEngine:
                 last = j == len(blocks) - 1
                 ops.est_tail(ao, xs, w, B=B, T=T, dtype=dt, bm=bm_t, rowmask=(mask if last else None),
                              act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])),
-                             tpw2=(self.polite and (self.split if self.polite_tpw2 is None else self.polite_tpw2) and bm_t in (32, 64) and dt in (BF16, X2)
+                             tpw2=(self.polite and (self.split if self.polite_tpw2 is None else self.polite_tpw2) and bm_t == 32 and dt == X2
                                    and B * ((T + bm_t - 1) // bm_t) >= self.polite_tpw2_min_tiles))
 
         # down block: its last transformer block drops the masked activation copy into cat[:, :, C:] (the skip)

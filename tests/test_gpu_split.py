@@ -344,6 +344,38 @@ def test_est_tail_two_tiles_per_workgroup_split_build():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,T,masked,with_next", [(3, 150, False, True), (2, 64, True, True), (1, 333, True, False), (5, 97, False, True)])
+def test_est_tail_64_row_split_tile_equals_32_row_tile(B, T, masked, with_next):
+    """mmx_est_tail, split build, 64-row tile (attention tile in two K halves, 256-wide FF chunks, one-fragment patches, A fragments
+    read per plane) == the 32-row tile, bit for bit: the same per-row arithmetic in the same order (ragged last tiles, row mask,
+    with and without the next block's LayerNorm + Q/K/V, both ring depths)."""
+    from mmx import ops, shapes, synth
+    from mmx.flow import FlowEngine
+    fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0), dtype=X2, use_graphs=False)
+    blocks = [w for st in fl.mid for w in st["blocks"]]
+    g = torch.Generator().manual_seed(11 + T)
+    Tp = ops.round_up(T, 8)
+    ao = torch.randn(B, T, 512, generator=g).cuda()
+    x0 = torch.randn(B, T, 256, generator=g).cuda()
+    mask = (torch.rand(B, T, generator=g) > 0.3).float().cuda() if masked else None
+    outs = []
+    for bm, pf in ((32, 0), (64, 0), (64, 4)):
+        x = x0.clone()
+        qk = torch.zeros(B, T, 2048, dtype=torch.bfloat16, device="cuda")
+        vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device="cuda")
+        act = torch.zeros(B, T, 512, device="cuda")
+        w, wn = blocks[0], blocks[1]
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=2048, q_bs=T * 2048, vt_out=vt, ldvt=Tp,
+                           vt_bs=2 * 512 * Tp) if with_next else None
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=X2, bm=bm, nxt=nxt, pf=pf, rowmask=mask, act_out=act[:, :, 256:], act_ld=512)
+        torch.cuda.synchronize()
+        outs.append((x, qk, vt, act))
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------ full-size configs 4 and 5
 def test_config4_rank_share_full_size_split_vs_oracle(case):
     """BASELINE config 4, one rank's share at FULL size on the split build — the shape `bench.py` times: 32 utterances, lengths

@@ -46,7 +46,7 @@ def run(n, T, bm, waves, pf):
 def sweep():
     # waves 2xx: 8 waves with 32-column passes
     # 3xx: the default kernel of (dtype, rows) with two row tiles per workgroup
-    cfgs = ([(32, 8, 0), (32, 208, 4), (32, 300, 0), (16, 8, 0)] if split else
+    cfgs = ([(32, 8, 0), (64, 208, 2), (64, 208, 4), (32, 300, 0), (16, 8, 0)] if split else
             [(64, 4, 2), (64, 208, 2), (32, 208, 8), (16, 8, 4)])
     for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
@@ -98,6 +98,13 @@ def stamps(n=5, T=1000, bm=64, waves=4, pf=2):
         names[14 + ch * 12] = f"ch{ch} chunk barrier"
         names[15 + ch * 12] = f"ch{ch} FF2 MFMA"
         names[16 + ch * 12] = f"ch{ch} barrier"
+    if split and bm == 64:                               # the 64-row split tile: four 256-wide chunks, five stamps each from 6 on
+        for k in range(6, 31):
+            names.pop(k, None)
+        for ch in range(4):
+            sb = 6 + ch * 5
+            names[sb], names[sb + 1], names[sb + 2], names[sb + 3], names[sb + 4] = (f"ch{ch} FF1 MFMA", f"ch{ch} GELU epilogue", f"ch{ch} chunk barrier",
+                                                                                   f"ch{ch} FF2 MFMA", f"ch{ch} barrier")
     names[31] = "closing epilogue (x store)"
     names[32] = "LN1 + A1 + barrier"
     for q in range(12):
@@ -114,7 +121,11 @@ def stamps(n=5, T=1000, bm=64, waves=4, pf=2):
 
 
 if "--stamps" in sys.argv:
-    if split:
+    if split and "--64" in sys.argv:
+        stamps(1, 500, 64, 208, 2)
+        stamps(5, 1000, 64, 208, 2)
+        stamps(8, 896, 64, 208, 2)
+    elif split:
         stamps(5, 1000, 32, 8, 0)
     else:
         stamps(5, 1000, 64, 4, 2)
