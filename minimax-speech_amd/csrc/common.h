@@ -116,6 +116,36 @@ __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(r, x);
 }
 
+// GELU through the same erf (A-S 7.1.26), every operation written out (explicit FMAs, no contraction left to the compiler) and
+// in a two-element form whose multiplies / adds / FMAs are packed instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two
+// elements per issue slot).  The fused estimator kernels evaluate it in two different register layouts (row layout of the 16- / 32-row
+// tiles, the MFMA's own layout in the 64-row split tile); spelled out like this both give the same bits per element, whatever
+// the vectoriser does with the surrounding loop.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t v) {
+#pragma clang fp contract(off)
+    const f32x2_t x = v * 0.70710678118654752f;
+    const f32x2_t ax = __builtin_elementwise_abs(x);
+    const f32x2_t d = __builtin_elementwise_fma(ax, (f32x2_t)(0.3275911f), (f32x2_t)(1.0f));
+    f32x2_t t;
+    t.x = __builtin_amdgcn_rcpf(d.x);
+    t.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2_t p = (f32x2_t)(1.061405429f);
+    p = __builtin_elementwise_fma(p, t, (f32x2_t)(-1.453152027f));
+    p = __builtin_elementwise_fma(p, t, (f32x2_t)(1.421413741f));
+    p = __builtin_elementwise_fma(p, t, (f32x2_t)(-0.284496736f));
+    p = __builtin_elementwise_fma(p, t, (f32x2_t)(0.254829592f));
+    const f32x2_t m = (ax * ax) * -1.4426950408889634f;    // exp(-x^2) = 2^(-x^2 log2 e)
+    f32x2_t e;
+    e.x = __builtin_amdgcn_exp2f(m.x);
+    e.y = __builtin_amdgcn_exp2f(m.y);
+    const f32x2_t r = __builtin_elementwise_fma(-(p * t), e, (f32x2_t)(1.0f));
+    f32x2_t er;
+    er.x = __builtin_copysignf(r.x, x.x);
+    er.y = __builtin_copysignf(r.y, x.y);
+    return (v * 0.5f) * (er + 1.0f);
+}
+
 // erf for the fused bf16 epilogues whose result is rounded to bf16: odd polynomial of degree 17 on |x| <= 3 (clamped
 // beyond: 1 - erf(3) = 2.2e-5), |error| <= 2.4e-5 - no transcendental (v_rcp / v_exp issue at quarter rate; the FF1
 // epilogue of the estimator's fused tail kernel is VALU bound: tools/tail_lab.py --stamps), all FMAs pack into

@@ -458,6 +458,43 @@ __device__ __forceinline__ void load_tile_split(const float* __restrict__ src, l
     }
 }
 
+// the 64-row split tile's attention rows: 512 columns as two K halves into two tiles (columns 0 .. 255 -> tile0, 256 .. 511 -> tile1,
+// same pitch / plane distance), every global load of the workgroup's share in flight before the first LDS store (one memory
+// round trip for the 128 KB; as two load_tile_split calls it was two)
+__device__ __forceinline__ void load_tile_split_halves(const float* __restrict__ src, long ld, int r0, int nvalid, int rows,
+                                                       char* tile0, char* tile1, int pitch, int plane, int tid, int nthreads) {
+    constexpr int U = 16;
+    constexpr int cpr = 512 / 4;
+    const int total = rows * cpr;
+    for (int base = tid; base < total; base += U * nthreads) {
+        float4 v[U];
+        int off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int id = base + u * nthreads;
+            const int idc = id < total ? id : total - 1;
+            const int r = idc / cpr, ch = idc - r * cpr;
+            const int gr = r0 + r;
+            const bool ok = gr >= 0 && gr < nvalid;
+            const int grc = gr < 0 ? 0 : (gr < nvalid ? gr : nvalid - 1);
+            v[u] = *reinterpret_cast<const float4*>(src + (long)grc * ld + ch * 4);
+            if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            off[u] = id < total ? r * pitch + (ch & 63) * 8 + ((ch >> 6) ? (int)(tile1 - tile0) : 0) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (off[u] < 0) continue;
+            uint2 hi, lo;
+            hi.x = pack_bf16x2(v[u].x, v[u].y);
+            hi.y = pack_bf16x2(v[u].z, v[u].w);
+            lo.x = pack_bf16x2(v[u].x - __uint_as_float(hi.x << 16), v[u].y - __uint_as_float(hi.x & 0xffff0000u));
+            lo.y = pack_bf16x2(v[u].z - __uint_as_float(hi.y << 16), v[u].w - __uint_as_float(hi.y & 0xffff0000u));
+            *reinterpret_cast<uint2*>(tile0 + off[u]) = hi;
+            *reinterpret_cast<uint2*>(tile0 + plane + off[u]) = lo;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Shared tail of both kernels: x (row layout) -> LayerNorm(n1) -> A1 tile -> Q/K/V projection.
 // bf16: Q,K row-major [B][T][1024] and V TRANSPOSED vt[b][512][Tp] (what the flash kernel reads);
@@ -701,8 +738,8 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         }
         ring.prime(wo_w, ns0, NK0, NFN);
         if constexpr (HK) {
-            load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, C, buf0, P0, PL0, tid, 64 * NW);
-            load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs + C, p.ldao, t0, Tn, BM, C, a1, P1, PL1, tid, 64 * NW);
+            static_assert(P0 == P1 && PL0 == PL1, "both halves of the attention tile have the shape of a1");
+            load_tile_split_halves(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, buf0, a1, P0, PL0, tid, 64 * NW);
         } else if constexpr (NS == 1) load_tile<T>(reinterpret_cast<const T*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, tid, 64 * NW);
         else load_tile_split(reinterpret_cast<const float*>(p.ao) + (long)b * p.ao_bs, p.ldao, t0, Tn, BM, CI, buf0, P0, PL0, tid, 64 * NW);
 #pragma unroll
@@ -779,8 +816,17 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             for (int i = 0; i < MF; ++i) {
                 float v[4 * PW];
                 rows_of<PW, HK>(acc[i], patch, lane, v);
+                if constexpr (NS > 1 && !PRECISE) {    // split build: the spelled-out two-element form (common.h: the same bits whatever
+                    // the vectoriser does with the loop around it - the 64- and 32-row tiles must agree bit for bit)
 #pragma unroll
-                for (int c = 0; c < 4 * PW; ++c) v[c] = act_c<((PRECISE || NS > 1) ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
+                    for (int c = 0; c < 4 * PW; c += 2) {
+                        const f32x2_t gl = gelu_fast2(f32x2_t{v[c] + b1[c], v[c + 1] + b1[c + 1]});
+                        v[c] = gl.x; v[c + 1] = gl.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4 * PW; ++c) v[c] = act_c<((PRECISE || NS > 1) ? ACT_GELU : ACT_GELU_POLY), PRECISE>(v[c] + b1[c], 0.f);
+                }
                 store_tile<T, NS, 4 * PW>(buf0 + (i * 16 + rl) * P0 + hc * (int)sizeof(T), PL0, v);
             }
             TSTAMP(HK ? sb + 1 : 7 + ch * 12 + h * 2);
@@ -805,6 +851,9 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         TSTAMP(HK ? sb + 4 : 16 + ch * 12);
     }
     // ---- + bias + residual -> x (fp32 residual stream, in place)
+    // HK: buf0 is dead from here on (every wave is past the last chunk's closing barrier): the wide per-wave patches of the
+    // other tiles live there for the closing epilogue and the Q/K/V epilogues (the one-fragment patch serves half the lanes per trip)
+    float* wpatch = HK ? reinterpret_cast<float*>(buf0) + wave * PATCH_FLOATS : patch;
     {
         float* xw = p.x + (long)b * p.x_bs;
         float b2[CW];
@@ -812,7 +861,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             float v[CW];
-            rows_of<NFN, HK>(acc2[i], patch, lane, v);
+            to_rows<NFN>(acc2[i], wpatch, lane, v);
             const int t = t0 + i * 16 + rl;
 #pragma unroll
             for (int c = 0; c < CW; ++c) x1[i][c] = (x1[i][c] + v[c] + b2[c]) * rm[i];
@@ -828,7 +877,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         float n1g[CW], n1b[CW];
         loadn<CW>(prm + PRM_N1G + col0, n1g);
         loadn<CW>(prm + PRM_N1B + col0, n1b);
-        ln_qkv<T, MF, PF, NW, NS, PW, WP, HK>(x1, n1g, n1b, p.next, p.eps, a1, patch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
+        ln_qkv<T, MF, PF, NW, NS, PW, WP>(x1, n1g, n1b, p.next, p.eps, a1, wpatch, stats, ring, b, t0, Tn, wave, lane, PL1, st);
     }
     TSTAMP(63);
 }
@@ -1357,6 +1406,9 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
         if (bm == 32) {
             MMX_CHECK_ARG((resnet_lds<bf16_t, 32, 4, 2>(p.cin)) <= 160 * 1024);
             if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2, true); else RESNN(bf16_t, 32, 2, 4, 2, true); }
+            // 8 waves (two per SIMD: a wave alone on its SIMD issues vector instructions at half the SIMD's rate, and the epilogues
+            // here are vector work) where the per-wave patches still fit beside the two-plane tiles: cin = 256, the twelve mid blocks
+            else if (nw != 4 && (resnet_lds<bf16_t, 32, 8, 2>(p.cin)) <= 160 * 1024) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 8, 2); else RESNN(bf16_t, 32, 2, 8, 2); }
             else if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2); else RESNN(bf16_t, 32, 2, 4, 2);
         } else if (bm == 16) {
             if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2, true); else RESNN(bf16_t, 16, 2, 4, 2, true); }

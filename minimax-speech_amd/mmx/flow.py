@@ -669,8 +669,8 @@ class FlowEngine:
     # same weights it takes up to 45 % longer (256 workgroups: 34 / 42 / 65 us)
     _WG_US = {16: 27.1, 32: 29.9, 64: 44.1}
     # the same for the split build (two MFMAs per weight fragment; 64 rows: the K-halved tile of est_tail_tile, 8 waves):
-    # profiles/r04_tail_lab64_x.txt - 1 000 rows: 29.1 / 35.8 / 62.3; 256 workgroups: - / 53.6 / 92.5
-    _WG_US_X = {16: 29.1, 32: 35.8, 64: 62.3}
+    # profiles/r04_tail_lab64_x.txt - 1 000 rows: 29.1 / 35.8 / 61.2; 256 workgroups: - / 53.5 / 91.5
+    _WG_US_X = {16: 29.1, 32: 35.8, 64: 61.2}
 
     @classmethod
     def _launch_us(cls, bm, tiles, split=False):
