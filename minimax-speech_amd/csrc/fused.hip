@@ -662,7 +662,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     // intermediate passes in four chunks of 256 columns, so that buf0 and a1 are both [2][64][256]: 136 KB + 10 KB of one-fragment
     // patches (to_rows_sp).  Same arithmetic in the same order per row as the 32-row tile: bit-identical results.
     constexpr bool HK = NS == 2 && BM == 64 && sizeof(T) == 2;
-    static_assert(!HK || (NW == 8 && PW == 2 && !WP), "64-row split tile: 8 waves, 32-column passes");
+    static_assert(!HK || (NW == 8 && PW == 2), "64-row split tile: 8 waves, 32-column passes");
     constexpr int MF = BM / 16, E = FT<T>::E, KB = FT<T>::KB, C = 256, CI = 512, CF = 1024, CH = HK ? 256 : 512, NCH = CF / CH;
     constexpr int WC = C / NW, CW = WC / 4, NFN = WC / 16, PC = 16 * PW, PPC = CH / (PC * NW);
     static_assert(NFN <= PW, "the ring is PW fragments wide");
@@ -753,8 +753,17 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         float4_t acc[MF][NFN];
         zero_acc(acc);
         if constexpr (HK) {                            // k-steps 0 .. 7 over buf0, 8 .. 15 over a1: one accumulator, ascending k
-            stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NKH, wo_w, ns0, NKH, wo_w + (long)NKH * 64 * E, ns0, NKH, NFN, acc, PL0);
-            stage_run<T, MF, NFN, PF, NS, PW>(ring, a1 + l16 * P1 + g * 16, P1, NKH, wo_w + (long)NKH * 64 * E, ns0, NKH, w1_pass(0), ns1, NK1, PW, acc, PL1);
+            const T* wo_h = wo_w + (long)NKH * 64 * E;     // second K half of this wave's fragments
+            if constexpr (WP) {                        // weight planes: the hi pack over both halves, then the lo pack against the hi activation plane (stage_run_w's order)
+                const long wlo = (long)C * CI;
+                stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NKH, wo_w, ns0, NKH, wo_h, ns0, NKH, NFN, acc, PL0);
+                stage_run<T, MF, NFN, PF, NS, PW>(ring, a1 + l16 * P1 + g * 16, P1, NKH, wo_h, ns0, NKH, wo_w + wlo, ns0, NKH, NFN, acc, PL1);
+                stage_run<T, MF, NFN, PF, 1, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NKH, wo_w + wlo, ns0, NKH, wo_h + wlo, ns0, NKH, NFN, acc, 0);
+                stage_run<T, MF, NFN, PF, 1, PW>(ring, a1 + l16 * P1 + g * 16, P1, NKH, wo_h + wlo, ns0, NKH, w1_pass(0), ns1, NK1, PW, acc, 0);
+            } else {
+                stage_run<T, MF, NFN, PF, NS, PW>(ring, buf0 + l16 * P0 + g * 16, P0, NKH, wo_w, ns0, NKH, wo_h, ns0, NKH, NFN, acc, PL0);
+                stage_run<T, MF, NFN, PF, NS, PW>(ring, a1 + l16 * P1 + g * 16, P1, NKH, wo_h, ns0, NKH, w1_pass(0), ns1, NK1, PW, acc, PL1);
+            }
         } else
         stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + l16 * P0 + g * 16, P0, NK0, wo_w, ns0, NK0, (long)C * CI, w1_pass(0), ns1, NK1, PW, acc, PL0);
         TSTAMP(3);
@@ -845,6 +854,14 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             }
         }
         const T* wn = ch + 1 < NCH ? w1_pass((ch + 1) * PPC) : (p.next.wqkv ? qkv_pass<T, NW, PW>(p.next.wqkv, wave, lane, 0) : nullptr);
+        if constexpr (WP && !HK) {
+            // weight planes: hi and lo pack alternate per 256 columns of the intermediate (two halves of this 512-wide chunk) - the
+            // order in which the 64-row tile, whose chunks are 256 wide, meets them: both tiles sum acc2 alike, bit for bit
+            constexpr int NKQ = NK2 / 2;
+            const T* wh = w2_w + (long)(ch * NK2) * 64 * E;
+            stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + l16 * P0 + g * 16, P0, NKQ, wh, ns2, NKQ, (long)C * CF, wh + (long)NKQ * 64 * E, ns2, NKQ, NFN, acc2, PL0);
+            stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + NKQ * KB * (int)sizeof(T) + l16 * P0 + g * 16, P0, NKQ, wh + (long)NKQ * 64 * E, ns2, NKQ, (long)C * CF, wn, ns1, NK1, PW, acc2, PL0);
+        } else
         stage_run_w<T, MF, NFN, PF, NS, PW, WP>(ring, buf0 + l16 * P0 + g * 16, P0, NK2, w2_w + (long)(ch * NK2) * 64 * E, ns2, NK2, (long)C * CF, wn, ns1, NK1, PW, acc2, PL0);
         TSTAMP(HK ? sb + 3 : 15 + ch * 12);
         __syncthreads();                               // every wave is done reading the chunk
@@ -1313,7 +1330,8 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     int narrow = (cfg >> 9) & 1;
     int pf = cfg & 15;
     if (wplanes) {                                     // weight planes: the split build's default tiles, one tile per workgroup
-        if (bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 1, true);
+        if (bm == 64) TAILT(bf16_t, 64, 2, 8, 2, 1, 2, 1, true);
+        else if (bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 1, true);
         else if (bm == 16) TAILT(bf16_t, 16, 4, 8, 2, 1, 4, 1, true);
         else return MMX_EARG;
         MMX_LAUNCH_CHECK();

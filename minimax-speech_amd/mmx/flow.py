@@ -671,11 +671,14 @@ class FlowEngine:
     # the same for the split build (two MFMAs per weight fragment; 64 rows: the K-halved tile of est_tail_tile, 8 waves):
     # profiles/r04_tail_lab64_x.txt - 1 000 rows: 29.1 / 35.8 / 61.2; 256 workgroups: - / 53.5 / 91.5
     _WG_US_X = {16: 29.1, 32: 35.8, 64: 61.2}
+    # ... and with weight planes (an fp32-kind checkpoint: three MFMAs per fragment pair, twice the stream): profiles/r04_tail_lab64_xw.txt
+    _WG_US_XW = {16: 46.9, 32: 52.6, 64: 81.2}
 
     @classmethod
     def _launch_us(cls, bm, tiles, split=False):
-        """Model of one est_tail launch: full rounds of 256 workgroups, then the remainder."""
-        wg = (cls._WG_US_X if split else cls._WG_US)[bm]
+        """Model of one est_tail launch: full rounds of 256 workgroups, then the remainder.  split: False (bf16 build), True
+        (split build) or "w" (split build with weight planes)."""
+        wg = (cls._WG_US_XW if split == "w" else cls._WG_US_X if split else cls._WG_US)[bm]
         t = lambda n: wg * (1.0 + 0.45 * (n / 256.0) ** 2)
         full, rem = divmod(tiles, 256)
         return full * t(256) + (t(rem) if rem else 0.0)
@@ -694,7 +697,7 @@ class FlowEngine:
             # MFMA stages run at the MFMA's rate instead of the weight stream's: the tile with the shortest launch, and 64 rows
             # (half the workgroups of the 32-row tile at 0.85 of its time per row) beside the decode loop
             cap = getattr(self, "max_tile_rows", 64)
-            bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (self._launch_us(b, tiles(b), True), -b))
+            bm = min((b for b in (64, 32, 16) if b <= cap), key=lambda b: (self._launch_us(b, tiles(b), "w" if self.wplanes else True), -b))
             if self.polite:
                 bm = max(bm, min(cap, 64))
             br = 32 if (tiles(32) >= 128 or self.polite) else 16

@@ -376,6 +376,35 @@ def test_est_tail_64_row_split_tile_equals_32_row_tile(B, T, masked, with_next):
             assert torch.equal(a, b)
 
 
+def test_est_tail_64_row_split_tile_equals_32_row_tile_with_weight_planes():
+    """The same with weight planes (an fp32-kind checkpoint: every packed weight as hi + lo bf16 packs, MMX_X2W): the 64-row tile and
+    the 32-row tile meet hi and lo packs in the same order (per 256 columns of the FF intermediate) and agree bit for bit."""
+    from mmx import ops, shapes, synth
+    from mmx.flow import FlowEngine
+    fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0, kind="fp32"), dtype=X2, use_graphs=False, wplanes=True)
+    blocks = [w for st in fl.mid for w in st["blocks"]]
+    assert isinstance(blocks[0]["wo_p"], ops.Planed)
+    g = torch.Generator().manual_seed(23)
+    B, T = 3, 150
+    Tp = ops.round_up(T, 8)
+    ao = torch.randn(B, T, 512, generator=g).cuda()
+    x0 = torch.randn(B, T, 256, generator=g).cuda()
+    mask = (torch.rand(B, T, generator=g) > 0.3).float().cuda()
+    outs = []
+    for bm in (32, 64):
+        x = x0.clone()
+        qk = torch.zeros(B, T, 2048, dtype=torch.bfloat16, device="cuda")
+        vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device="cuda")
+        w, wn = blocks[0], blocks[1]
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=2048, q_bs=T * 2048, vt_out=vt, ldvt=Tp, vt_bs=2 * 512 * Tp)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=X2, bm=bm, nxt=nxt, rowmask=mask)
+        torch.cuda.synchronize()
+        outs.append((x, qk, vt))
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------ full-size configs 4 and 5
 def test_config4_rank_share_full_size_split_vs_oracle(case):
     """BASELINE config 4, one rank's share at FULL size on the split build — the shape `bench.py` times: 32 utterances, lengths

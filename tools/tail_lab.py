@@ -15,8 +15,10 @@ from mmx import ops, shapes, synth  # noqa: E402
 from mmx.flow import FlowEngine  # noqa: E402
 from bench import _event_time_graph  # noqa: E402
 
-dt = {"bf16": 1, "x": 2}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
-fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0), dtype=dt, use_graphs=False)
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"     # xw: the split build on an fp32-kind checkpoint (weight planes)
+dt = {"bf16": 1, "x": 2, "xw": 2}[mode]
+fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(), 0, kind=("fp32" if mode == "xw" else "bf16")), dtype=dt, use_graphs=False,
+                wplanes=(mode == "xw"))
 blocks = [w for st in fl.mid for w in st["blocks"]]
 split = dt == 2
 
@@ -46,7 +48,7 @@ def run(n, T, bm, waves, pf):
 def sweep():
     # waves 2xx: 8 waves with 32-column passes
     # 3xx: the default kernel of (dtype, rows) with two row tiles per workgroup
-    cfgs = ([(32, 8, 0), (64, 208, 2), (64, 208, 4), (32, 300, 0), (16, 8, 0)] if split else
+    cfgs = ([(32, 8, 0), (64, 208, 2), (16, 8, 0)] if mode == "xw" else [(32, 8, 0), (64, 208, 2), (64, 208, 4), (32, 300, 0), (16, 8, 0)] if split else
             [(64, 4, 2), (64, 208, 2), (32, 208, 8), (16, 8, 4)])
     for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
