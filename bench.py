@@ -149,14 +149,12 @@ def _time_est_tail(fl, n, T, polite=False):
     was, fl.polite = fl.polite, polite                  # the tiling the step used for this group (FlowEngine.polite)
     bm, _ = fl._tile_rows(B, T)
     fl.polite = was
-    tpw2 = bool(polite and (fl.split if fl.polite_tpw2 is None else fl.polite_tpw2) and bm == 32 and fl.split
-                and B * ((T + bm - 1) // bm) >= fl.polite_tpw2_min_tiles)
 
     def one(i=0):
         w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
         nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt,
                            ldvt=Tp, vt_bs=vt_bs)
-        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, tpw2=tpw2)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt)
 
     return _event_time_graph(one, 2 * len(blocks)), bm
 
@@ -365,10 +363,8 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "single", "longform"])
     ap.add_argument("--per-gpu", type=int, default=32)
     ap.add_argument("--flow-group", default="8", help="utterances per batched flow ODE solve (a list gives a ramp: k-th group)")
-    ap.add_argument("--tpw2-min-tiles", type=int, default=None, help="tuning: two-tile workgroups only for est_tail launches of at least this many row tiles")
     ap.add_argument("--sched-adapt", action="store_true", help="tts_batch's cost model follows its own measurements (TtsEngine.sched_adapt)")
     ap.add_argument("--flash-form", type=int, default=None, help="lab: mmx_attn_flash_xs form of the flow groups beside the decode loop (0 chosen per launch, 1 = 128-query workgroups [default], 2 = 256-query, 3 = 4-wave 64-query)")
-    ap.add_argument("--tpw2", type=int, default=None, help="tuning: 1 / 0 = polite flow groups run est_tail with two / one row tiles per workgroup (FlowEngine.polite_tpw2; default: split build only)")
     ap.add_argument("--flow-priority", type=int, default=None, help="tuning: HIP stream priority of the flow workers' streams (TtsEngine.flow_priority)")
     ap.add_argument("--lm-cfg", default="", help="tuning: LlmEngine.v2_cfg overrides (output tiles per workgroup, k slices), e.g. gu=2,1:down=2,4")
     ap.add_argument("--group-fan", type=int, default=None, help="auxiliary streams per flow group for its per-utterance stages (TtsEngine.group_fan)")
@@ -390,18 +386,12 @@ def main():
     if a.lm_prefetch is not None:
         from mmx.llm import LlmEngine
         LlmEngine.prefetch = a.lm_prefetch
-    if a.tpw2_min_tiles is not None:
-        from mmx.flow import FlowEngine
-        FlowEngine.polite_tpw2_min_tiles_default = a.tpw2_min_tiles
     if a.sched_adapt:
         from mmx.pipeline import TtsEngine
         TtsEngine.sched_adapt = True
     if a.flash_form is not None:
         from mmx.flow import FlowEngine
         FlowEngine.polite_flash_form_default = a.flash_form
-    if a.tpw2 is not None:
-        from mmx.flow import FlowEngine
-        FlowEngine.polite_tpw2_default = bool(a.tpw2)
     if a.lm_cfg:
         from mmx.llm import LlmEngine
         LlmEngine.v2_cfg = dict(LlmEngine.v2_cfg, **{kv.split("=")[0]: tuple(int(v) for v in kv.split("=")[1].split(",")) for kv in a.lm_cfg.split(":")})

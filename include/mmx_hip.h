@@ -420,9 +420,11 @@ typedef struct MmxEstResnetParams {
     float eps;
     MmxEstNext next;
 } MmxEstResnetParams;
-/* cfg = pf + 16 * waves + 256 * occ2 + 512 * narrow + 1024 * tpw2 (0 = the library's defaults; mmx_est_tail only: occ2 = the
- * 4-wave 16- / 32-row variants compiled for two workgroups per CU, narrow = 8 waves with 32-column passes (the bf16 default for
- * 64 / 32 rows), tpw2 = two row tiles per workgroup with the default kernel of (dtype, bm): half the workgroups per launch): pf = k-steps of weight fragments a wave keeps in flight (2 / 4 / 8);
+/* cfg = pf + 16 * waves + 512 * narrow (0 = the library's defaults; mmx_est_tail only: narrow = 8 waves with 32-column passes,
+ * the bf16 default for 64 / 32 rows and the form of the split build's 64-row tile): pf = k-steps of weight fragments a wave keeps in flight (2 / 4 / 8);
+ * bm = rows per workgroup: 64 / 32 / 16 (MMX_BF16, MMX_X2, MMX_X2W), 32 / 16 (MMX_F32).  The split build's 64-row tile takes the
+ * attention rows in two K halves and the FF intermediate in 256-wide chunks (two bf16 planes of 64 rows fit LDS that way) and is
+ * bit-identical to its 32-row tile;
  * waves = 4 (one wave per SIMD, 64-column slices) or 8 (two per SIMD, 32-column slices: one wave's epilogue runs under the
  * other's MFMA stage; bf16 only). */
 int mmx_est_tail(const MmxEstTailParams* p, int dtype, int bm, int cfg, hipStream_t stream);

@@ -899,26 +899,11 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     TSTAMP(63);
 }
 
-// TPW row tiles per workgroup, one after the other (compile-time: TPW = 1 is the plain kernel).  TPW = 2 halves the number of
-// workgroups of a launch at the same work: the flow groups that run beside the LM decode loop then leave more CUs to it
-// (tools/contention_lab.py: the decode step takes 1.6 x beside 160 resident workgroups of this kernel, 2.4 x beside 320).
-template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1, int PW = 4, int TPW = 1, bool WP = false>
+template <typename T, int BM, int PF, int NW, int NS = 1, int OCC = 1, int PW = 4, bool WP = false>
 __global__ __launch_bounds__(64 * NW, OCC) void est_tail_kernel(MmxEstTailParams p) {
-    static_assert(!WP || TPW == 1, "weight planes: one tile per workgroup");
-    if constexpr (TPW == 1) {
-        est_tail_tile<T, BM, PF, NW, NS, PW, WP>(p, blockIdx.x);
-    } else {
-        const int ntiles = (p.T - p.t_begin + BM - 1) / BM;
-        // (two inlined copies: as a rolled loop the compiler spilled 300 - 1700 bytes per lane)
-        est_tail_tile<T, BM, PF, NW, NS, PW>(p, blockIdx.x * TPW);
-        if (blockIdx.x * TPW + 1 < ntiles) {            // uniform
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                            // every wave is done with the previous tile's LDS
-            __builtin_amdgcn_sched_barrier(0);
-            est_tail_tile<T, BM, PF, NW, NS, PW>(p, blockIdx.x * TPW + 1);
-        }
-        static_assert(TPW == 2, "two copies");
-    }
+    // (round 3 / 4 ran the split build's flow groups beside the decode loop with two 32-row tiles per workgroup - half the
+    // workgroups per launch; the 64-row split tile does the same at 0.85 of the time and without that form's 180 bytes of scratch)
+    est_tail_tile<T, BM, PF, NW, NS, PW, WP>(p, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1316,36 +1301,28 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
     MMX_CHECK_ARG(!p.act_out || (p.act_ld % (dtype == MMX_X2 ? 4 : 8) == 0 && p.act_bs % (dtype == MMX_X2 ? 4 : 8) == 0 && ((uintptr_t)p.act_out % 16) == 0));
     if (int rc = check_next(p.next, dtype, p.T)) return rc;
     const int nw = (cfg >> 4) & 15, occ2 = (cfg >> 8) & 1;
-#define TAILT(TT, BM, PF, NW, NS, OCC, PW, TPW, ...)                                                      \
+#define TAILT(TT, BM, PF, NW, NS, OCC, PW, ...)                                                           \
     do {                                                                                                   \
         const size_t lds = tail_lds<TT, BM, NW, NS>();                                                     \
         MMX_CHECK_ARG(lds * OCC <= 160 * 1024);                                                            \
-        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW __VA_OPT__(,) __VA_ARGS__>), lds); \
-        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW, TPW __VA_OPT__(,) __VA_ARGS__>), dim3(((p.T - p.t_begin + BM - 1) / BM + TPW - 1) / TPW, p.B), dim3(64 * NW), lds, stream, p); \
+        MMX_LDS_OPT_IN((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW __VA_OPT__(,) __VA_ARGS__>), lds);     \
+        hipLaunchKernelGGL((est_tail_kernel<TT, BM, PF, NW, NS, OCC, PW __VA_OPT__(,) __VA_ARGS__>), dim3((p.T - p.t_begin + BM - 1) / BM, p.B), dim3(64 * NW), lds, stream, p); \
     } while (0)
-#define TAILP(TT, BM, PF, NW, NS, OCC, PW) TAILT(TT, BM, PF, NW, NS, OCC, PW, 1)
+#define TAILP(TT, BM, PF, NW, NS, OCC, PW) TAILT(TT, BM, PF, NW, NS, OCC, PW)
 #define TAILO(TT, BM, PF, NW, NS, OCC) TAILP(TT, BM, PF, NW, NS, OCC, 4)
 #define TAILN(TT, BM, PF, NW, NS) TAILO(TT, BM, PF, NW, NS, 1)
 #define TAIL(TT, BM, PF, NW) TAILN(TT, BM, PF, NW, 1)
     int narrow = (cfg >> 9) & 1;
     int pf = cfg & 15;
-    if (wplanes) {                                     // weight planes: the split build's default tiles, one tile per workgroup
-        if (bm == 64) TAILT(bf16_t, 64, 2, 8, 2, 1, 2, 1, true);
-        else if (bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 1, true);
-        else if (bm == 16) TAILT(bf16_t, 16, 4, 8, 2, 1, 4, 1, true);
+    if (wplanes) {                                     // weight planes: the split build's default tiles
+        if (bm == 64) TAILT(bf16_t, 64, 2, 8, 2, 1, 2, true);
+        else if (bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, true);
+        else if (bm == 16) TAILT(bf16_t, 16, 4, 8, 2, 1, 4, true);
         else return MMX_EARG;
         MMX_LAUNCH_CHECK();
         return MMX_OK;
     }
-    if ((cfg >> 10) & 1) {                             // two row tiles per workgroup: the split build's flow groups beside the decode loop
-        // (the bf16 build's 64- / 32-row forms measured a loss and spilled 256 - 448 bytes per lane: removed)
-        // (its 32-column-pass form - 172 registers in the one-tile kernel, which would let one-row-tile decode workgroups share the
-        // CU - still takes 255 here; the one-tile narrow form beside the decode loop measured 503 audio-s/s against 505: gpurun_out/r4_13)
-        if (dtype == MMX_X2 && bm == 32) TAILT(bf16_t, 32, 2, 8, 2, 1, 4, 2);
-        else return MMX_EARG;
-        MMX_LAUNCH_CHECK();
-        return MMX_OK;
-    }
+    if ((cfg >> 10) & 1) return MMX_EARG;              // (two row tiles per workgroup: removed, see est_tail_kernel)
     // library defaults of the bf16 build (cfg = 0): the narrow-pass 8-wave kernels for the 64- and 32-row tiles (measured per
     // launch at 10 000 rows: 51.1 us against 58.7 us with 4 waves x 64-column passes; 32 rows, 4 000 rows: 31.8 against 33.0)
     if (cfg == 0 && dtype == MMX_BF16 && (bm == 64 || bm == 32)) { narrow = 1; pf = bm == 64 ? 2 : 8; }
@@ -1423,7 +1400,8 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
         MMX_CHECK_ARG((p.cin / kb) % 2 == 0);
         if (bm == 32) {
             MMX_CHECK_ARG((resnet_lds<bf16_t, 32, 4, 2>(p.cin)) <= 160 * 1024);
-            if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2, true); else RESNN(bf16_t, 32, 2, 4, 2, true); }
+            if (wplanes && nw != 4 && (resnet_lds<bf16_t, 32, 8, 2>(p.cin)) <= 160 * 1024) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 8, 2, true); else RESNN(bf16_t, 32, 2, 8, 2, true); }
+            else if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2, true); else RESNN(bf16_t, 32, 2, 4, 2, true); }
             // 8 waves (two per SIMD: a wave alone on its SIMD issues vector instructions at half the SIMD's rate, and the epilogues
             // here are vector work) where the per-wave patches still fit beside the two-plane tiles: cin = 256, the twelve mid blocks
             else if (nw != 4 && (resnet_lds<bf16_t, 32, 8, 2>(p.cin)) <= 160 * 1024) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 8, 2); else RESNN(bf16_t, 32, 2, 8, 2); }

@@ -161,11 +161,6 @@ class FlowEngine:
         # beside them on another stream (the LM decode loop of TtsEngine.tts_batch) keeps more of the chip
         # (measured, 32-utterance step: decode loop 548 -> 523 ms, step 643 -> 622 ms).  Part of the plan key.
         self.polite = False
-        # polite groups: two row tiles per est_tail workgroup.  On for the split build, whose LDS allows 32-row tiles only (twice
-        # the workgroups of the bf16 build's polite launches): measured on the config-4 share 465 -> 473 audio-s/s (the decode
-        # loop ends 15 ms earlier); off for the bf16 build (64-row tiles: 702 -> 670, the flow groups fall behind)
-        self.polite_tpw2 = getattr(FlowEngine, "polite_tpw2_default", None)
-        self.polite_tpw2_min_tiles = getattr(FlowEngine, "polite_tpw2_min_tiles_default", 0)   # only launches of at least this many tiles
         # polite groups of the split build: flash attention on its 128-query workgroups (96 KB of LDS, 136 registers per wave) instead
         # of the 256-query ones (128 KB, 216) the launch-time rule would pick: a decode workgroup fits beside them on the CU
         # (measured in the step: decode loop done at 524 ms against 541, 520.8 against 512.4 audio-s/s; include/mmx_hip.h, form)
@@ -764,9 +759,7 @@ class FlowEngine:
                 attention()
                 last = j == len(blocks) - 1
                 ops.est_tail(ao, xs, w, B=B, T=T, dtype=dt, bm=bm_t, rowmask=(mask if last else None),
-                             act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])),
-                             tpw2=(self.polite and (self.split if self.polite_tpw2 is None else self.polite_tpw2) and bm_t == 32 and dt == X2
-                                   and B * ((T + bm_t - 1) // bm_t) >= self.polite_tpw2_min_tiles))
+                             act_out=(act_out if last else None), act_ld=act_ld, nxt=(None if last else nxt(blocks[j + 1])))
 
         # down block: its last transformer block drops the masked activation copy into cat[:, :, C:] (the skip)
         stage(self.down, h0, 320, 320, cat[:, :, C:], 2 * C)

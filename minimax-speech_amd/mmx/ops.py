@@ -237,7 +237,7 @@ def est_next(wqkv=None, n1g=None, n1b=None, q_out=None, ldq=0, q_bs=0, vt_out=No
 
 
 def est_tail(ao, x, w, *, B, T, dtype, bm, rowmask=None, act_out=None, act_ld=0, nxt=None, eps=1e-5, pf=0, t_begin=0,
-             Tcap=None, waves=0, occ2=False, narrow=False, tpw2=False):
+             Tcap=None, waves=0, occ2=False, narrow=False):
     """w: dict with packed wo_p / w1_p / w2_p and bo / b1 / b2 / n3g / n3b (mmx/flow.py).  Tcap: frames every buffer is
     allocated for (batch stride; default T); t_begin: first frame to process (streaming hop)."""
     Tc = T if Tcap is None else Tcap
@@ -248,7 +248,7 @@ def est_tail(ao, x, w, *, B, T, dtype, bm, rowmask=None, act_out=None, act_ld=0,
         p.next = nxt
     if isinstance(w["wo_p"], Planed):                   # [hi pack | lo pack] weights (pack_skinny with X2W), the next block's too
         dtype = L.X2W
-    check(load().mmx_est_tail(C.byref(p), C.c_int(dtype), C.c_int(bm), C.c_int(pf + 16 * waves + (256 if occ2 else 0) + (512 if narrow else 0) + (1024 if tpw2 else 0)), stream()),
+    check(load().mmx_est_tail(C.byref(p), C.c_int(dtype), C.c_int(bm), C.c_int(pf + 16 * waves + (256 if occ2 else 0) + (512 if narrow else 0)), stream()),
           "mmx_est_tail")
 
 

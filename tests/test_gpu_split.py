@@ -318,32 +318,6 @@ def test_zero_shot_batch_vs_oracle():
             assert wavs[b].shape == wav.shape and err <= 1e-3, (b, err)
 
 
-def test_est_tail_two_tiles_per_workgroup_split_build():
-    """mmx_est_tail, split build, two row tiles per workgroup (the polite flow groups' launch form) == one tile per workgroup,
-    bit for bit: the same per-tile arithmetic, only the workgroup that runs a tile differs (ragged last tile, odd tile count)."""
-    from mmx import ops, shapes, synth
-    from mmx.flow import FlowEngine
-    fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0), dtype=X2, use_graphs=False)
-    blocks = [w for st in fl.mid for w in st["blocks"]]
-    g = torch.Generator().manual_seed(9)
-    B, T = 3, 150                                       # 5 tiles of 32 rows per batch member, the last one ragged
-    Tp = ops.round_up(T, 8)
-    ao = torch.randn(B, T, 512, generator=g).cuda()
-    x0 = torch.randn(B, T, 256, generator=g).cuda()
-    outs = []
-    for tpw2 in (False, True):
-        x = x0.clone()
-        qk = torch.zeros(B, T, 2048, dtype=torch.bfloat16, device="cuda")
-        vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device="cuda")
-        w, wn = blocks[0], blocks[1]
-        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=2048, q_bs=T * 2048, vt_out=vt, ldvt=Tp, vt_bs=2 * 512 * Tp)
-        ops.est_tail(ao, x, w, B=B, T=T, dtype=X2, bm=32, nxt=nxt, tpw2=tpw2)
-        torch.cuda.synchronize()
-        outs.append((x, qk, vt))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("B,T,masked,with_next", [(3, 150, False, True), (2, 64, True, True), (1, 333, True, False), (5, 97, False, True)])
 def test_est_tail_64_row_split_tile_equals_32_row_tile(B, T, masked, with_next):
     """mmx_est_tail, split build, 64-row tile (attention tile in two K halves, 256-wide FF chunks, one-fragment patches, A fragments
@@ -410,7 +384,7 @@ def test_config4_rank_share_full_size_split_vs_oracle(case):
     """BASELINE config 4, one rank's share at FULL size on the split build — the shape `bench.py` times: 32 utterances, lengths
     U{50..500} tokens (seed 3), 24-layer LM, the overlapped schedule (decode loop with two 16-row MFMA tiles and the ticketed
     split-K down projection, compaction into the 16-slot engine, ragged zero-padded flow groups with the batched encoder,
-    two-tile est_tail workgroups beside the decode loop).  The two shortest and the longest utterance against the CPU oracle's
+    64-row est_tail tiles beside the decode loop, 8-wave two-head decode attention).  The two shortest and the longest utterance against the CPU oracle's
     composed path: ids identical, waveform within 1e-3 (the north star; sequence id = position in the batch keys the Philox
     stream on both sides).  The back-to-back schedule must give the same ids for all 32."""
     from mmx.pipeline import TtsEngine

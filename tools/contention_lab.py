@@ -107,7 +107,7 @@ def measure(name, gr):
 measure("alone", None)
 if SPLIT:
     measure("beside est_tail 5x1000, 32 rows x 8 waves (320 wg)", tail_graph(5, 1000, 32))
-    measure("beside est_tail 5x1000, 32 rows, 2 tiles per wg (160 wg)", tail_graph(5, 1000, 32, tpw2=True))
+    measure("beside est_tail 5x1000, 64 rows (160 wg)", tail_graph(5, 1000, 64))
     measure("beside est_tail 2x1000, 32 rows (128 wg)", tail_graph(2, 1000, 32))
     measure("beside flash_xs 5x1000", flash_graph(5, 1000))
     measure("beside flash_xs 2x1000", flash_graph(2, 1000))

@@ -28,15 +28,10 @@ if [ "$3" = "groups" ]; then
 fi
 if [ "$3" = "tpwmin" ]; then
   run min0
-  run min129 --tpw2-min-tiles 129
-  run min193 --tpw2-min-tiles 193
-  run min257 --tpw2-min-tiles 257
   exit 0
 fi
 if [ "$3" = "tpw" ]; then
   run base
-  run tpw2 --tpw2 1
-  run tpw1 --tpw2 0
   exit 0
 fi
 if [ "$3" = "prio" ]; then

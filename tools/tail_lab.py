@@ -40,15 +40,14 @@ def run(n, T, bm, waves, pf):
         w, wn = blocks[i % len(blocks)], blocks[(i + 1) % len(blocks)]
         nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=ldq, q_bs=T * ldq, vt_out=vt, ldvt=Tp,
                            vt_bs=vt_bs)
-        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=100 <= waves < 200, narrow=200 <= waves < 300, tpw2=waves >= 300)
+        ops.est_tail(ao, x, w, B=B, T=T, dtype=dt, bm=bm, nxt=nxt, waves=waves % 100, pf=pf, occ2=100 <= waves < 200, narrow=200 <= waves < 300)
 
     return _event_time_graph(one, 2 * len(blocks))
 
 
 def sweep():
     # waves 2xx: 8 waves with 32-column passes
-    # 3xx: the default kernel of (dtype, rows) with two row tiles per workgroup
-    cfgs = ([(32, 8, 0), (64, 208, 2), (16, 8, 0)] if mode == "xw" else [(32, 8, 0), (64, 208, 2), (64, 208, 4), (32, 300, 0), (16, 8, 0)] if split else
+    cfgs = ([(32, 8, 0), (64, 208, 2), (16, 8, 0)] if mode == "xw" else [(32, 8, 0), (64, 208, 2), (64, 208, 4), (16, 8, 0)] if split else
             [(64, 4, 2), (64, 208, 2), (32, 208, 8), (16, 8, 4)])
     for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
