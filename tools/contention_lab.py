@@ -57,19 +57,32 @@ def tail_graph(n, T, bm, **cfg):
     return graph_of(one, 112)
 
 
-def flash_graph(n, T):
+def flash_graph(n, T, form=0):
     Bf, Tp = 2 * n, ops.round_up(T, 8)
     if SPLIT:
         qk = torch.randn(Bf, T, 2048, device=dev).bfloat16()
         vt = torch.randn(Bf, 2, 512, Tp, device=dev).bfloat16()
         ao = torch.empty(Bf, T, 512, device=dev)
         return graph_of(lambda i=0: ops.attn_flash_xs(qk, vt, ao, B=Bf, H=8, T=T, ldqk=2048, ldvt=Tp, ldo=512, qk_bs=T * 2048, vt_bs=2 * 512 * Tp,
-                                                      o_bs=T * 512, scale=0.125), 112)
+                                                      o_bs=T * 512, scale=0.125, form=form), 112)
     qk = torch.randn(Bf, T, 1024, device=dev).to(fl.tdt)
     vt = torch.randn(Bf, 512, Tp, device=dev).to(fl.tdt)
     ao = torch.empty(Bf, T, 512, device=dev, dtype=fl.tdt)
     return graph_of(lambda i=0: ops.attn_flash_bf16(qk, qk[:, :, 512:], vt, ao, B=Bf, H=8, T=T, ldq=1024, ldk=1024, ldvt=Tp, ldo=512, q_bs=T * 1024,
                                                     k_bs=T * 1024, vt_bs=512 * Tp, o_bs=T * 512, scale=0.125), 112)
+
+
+def resnet_graph(n, T, waves):
+    res = [st["res"] for st in fl.mid]
+    Bf, Tp = 2 * n, ops.round_up(T, 8)
+    a_in = torch.randn(Bf, T, 256, device=dev); x = torch.randn(Bf, T, 256, device=dev); tv = torch.randn(Bf, 14 * 256, device=dev)
+    qk = torch.empty(Bf, T, 2048, dtype=torch.bfloat16, device=dev); vt = torch.zeros(Bf, 2, 512, Tp, dtype=torch.bfloat16, device=dev)
+
+    def one(i=0):
+        r, wn = res[i % len(res)], blocks[i % len(blocks)]
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=2048, q_bs=T * 2048, vt_out=vt, ldvt=Tp, vt_bs=2 * 512 * Tp)
+        ops.est_resnet(a_in, 256, 256, x, r, tv, 14 * 256, B=Bf, T=T, dtype=2, bm=32, nxt=nxt, waves=waves)
+    return graph_of(one, 96)
 
 
 def measure(name, gr):
@@ -109,8 +122,12 @@ if SPLIT:
     measure("beside est_tail 5x1000, 32 rows x 8 waves (320 wg)", tail_graph(5, 1000, 32))
     measure("beside est_tail 5x1000, 64 rows (160 wg)", tail_graph(5, 1000, 64))
     measure("beside est_tail 2x1000, 32 rows (128 wg)", tail_graph(2, 1000, 32))
-    measure("beside flash_xs 5x1000", flash_graph(5, 1000))
+    measure("beside est_tail 2x1000, 64 rows (64 wg)", tail_graph(2, 1000, 64))
+    measure("beside flash_xs 5x1000 (launch-time form)", flash_graph(5, 1000))
+    measure("beside flash_xs 5x1000, form 1 (128-query wgs)", flash_graph(5, 1000, 1))
     measure("beside flash_xs 2x1000", flash_graph(2, 1000))
+    measure("beside est_resnet 5x1000, 32 rows x 4 waves", resnet_graph(5, 1000, 4))
+    measure("beside est_resnet 5x1000, 32 rows x 8 waves", resnet_graph(5, 1000, 8))
     measure("alone again", None)
     sys.exit(0)
 measure("beside est_tail 5x1000, 64 rows x 8 waves (160 wg)", tail_graph(5, 1000, 64))
