@@ -344,7 +344,7 @@ __device__ __forceinline__ void store_tile(char* p, int plane, const float (&v)[
 
 // LayerNorm of the rows of a [rows x 256] tile held in the row layout (v[i][CW] per wave, NW waves x 256/NW columns).
 // Two-pass statistics like torch (mean, then the mean of squared deviations), partial sums exchanged through
-// stats[rows][NW].  Contains 4 workgroup barriers; all waves must call it.  Leaves normalised*gamma+beta in v.
+// stats[rows][NW].  Contains 3 workgroup barriers; all waves must call it.  Leaves normalised*gamma+beta in v.
 // gamma / beta: this lane's CW columns, loaded by the caller BEFORE the preceding MFMA stage (see "epilogue operands").
 template <int MFR, int CW, int NW>
 __device__ __forceinline__ void layernorm_rows(float (&v)[MFR][CW], float* stats, const float (&g)[CW], const float (&be)[CW],
@@ -360,7 +360,8 @@ __device__ __forceinline__ void layernorm_rows(float (&v)[MFR][CW], float* stats
         }
         return t;
     };
-    __syncthreads();                                   // stats free (previous readers done)
+    // (no barrier in front: every caller has a workgroup barrier between the last read of `stats` by the previous call and this one -
+    // the FF chunk barriers in est_tail, the tile barriers in est_resnet)
 #pragma unroll
     for (int i = 0; i < MFR; ++i) {
         float s = 0.f;
@@ -510,7 +511,7 @@ __device__ __forceinline__ const T* qkv_pass(const void* wqkv, int wave, int lan
 }
 
 // the weight ring must already hold the head of pass 0 (the caller's last stage chains into qkv_pass(.., 0))
-template <typename T, int MF, int PF, int NW, int NS = 1, int PW = 4, bool WP = false, bool SP = false>
+template <typename T, int MF, int PF, int NW, int NS = 1, int PW = 4, bool WP = false>
 __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n1g)[64 / NW], const float (&n1b)[64 / NW],
                                        const MmxEstNext& nx, float eps, char* a1, float* patch, float* stats,
                                        WRing<T, PW, PF>& ring, int b, int t0, int Tn, int wave, int lane, int plane = 0,
@@ -554,35 +555,6 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
                 bf16_t* dst = reinterpret_cast<bf16_t*>(nx.vt_out) + (long)b * nx.vt_bs + (long)s2 * 512 * nx.ldvt + (long)cw * nx.ldvt + t0;
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
-                    if constexpr (SP) {                // one-fragment patch: 16 columns x 16 frames at a time, lanes 0..31 store
-#pragma unroll
-                        for (int j = 0; j < PW; ++j) {
-                            uint2 pk;
-                            pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                            pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                            *reinterpret_cast<uint2*>(vw + l16 * PV + (4 * g) * 2) = pk;
-                            if (s2 + 1 < NS) {
-                                acc[i][j][0] -= __uint_as_float(pk.x << 16); acc[i][j][1] -= __uint_as_float(pk.x & 0xffff0000u);
-                                acc[i][j][2] -= __uint_as_float(pk.y << 16); acc[i][j][3] -= __uint_as_float(pk.y & 0xffff0000u);
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            const int colv = j * 16 + ((lane & 31) >> 1), c8 = lane & 1;
-                            uint4 v = *reinterpret_cast<const uint4*>(vw + ((lane & 31) >> 1) * PV + c8 * 16);
-                            const int t = t0 + i * 16 + c8 * 8;
-                            if (lane < 32 && t < Tn) {
-                                if (t + 8 > Tn) {
-                                    unsigned short* h = reinterpret_cast<unsigned short*>(&v);
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e)
-                                        if (t + e >= Tn) h[e] = 0;
-                                }
-                                *reinterpret_cast<uint4*>(dst + (long)colv * nx.ldvt + i * 16 + c8 * 8) = v;
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        continue;
-                    }
 #pragma unroll
                     for (int j = 0; j < PW; ++j) {
                         uint2 pk;
@@ -619,7 +591,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[4 * PW], lo[4 * PW];
-                rows_of<PW, SP>(acc[i], patch, lane, v);
+                to_rows<PW>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
                 if (t < Tn) {
 #pragma unroll
@@ -634,7 +606,7 @@ __device__ __forceinline__ void ln_qkv(float (&xv)[MF][64 / NW], const float (&n
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 float v[4 * PW];
-                rows_of<PW, SP>(acc[i], patch, lane, v);
+                to_rows<PW>(acc[i], patch, lane, v);
                 const int t = t0 + i * 16 + rl;
                 if (t < Tn) storen_T<TI, 4 * PW>(out + (long)t * nx.ldq + col, v);
             }
@@ -672,7 +644,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     // two orders below the 2^-17 its products keep; erff was 3.96 us of every FF1 epilogue, 15 % of the kernel:
     // profiles/r04_tail_stamps_x.txt); the bf16 build the degree-17 polynomial
     constexpr bool PRECISE = sizeof(T) == 4;
-    constexpr bool PARK = PW == 2;
+    constexpr bool PARK = PW == 2 && !(NS == 2 && BM == 64 && !WP);   // (64-row split tile without weight planes: 218 registers leave room for the residual rows)
     typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* buf0 = smem;                                 // [NS][BM][512] attention output, then the FF intermediate chunk
@@ -712,6 +684,15 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     // FF1 pass q = ch*PPC + h: PC columns at ch*512 + (wave*PPC + h)*PC of the 1024-wide intermediate
     auto w1_pass = [&](int q) { return w1 + (long)(((q / PPC) * CH + (wave * PPC + q % PPC) * PC) / 16) * ns1; };
     float x1[MF][CW];
+    float rm[MF];                                      // row mask of the closing epilogue: requested here, with everything else
+    {
+        const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int t = t0 + i * 16 + rl;
+            rm[i] = (rmk && t < Tn) ? rmk[t] : 1.f;
+        }
+    }
     {
         // Everything the prologue reads from global memory is requested before the first wait (the tile copy's): the
         // parameter vectors into registers, the residual rows (clamped, no branch around a load), the head of the weight
@@ -805,7 +786,6 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     float4_t acc2[MF][NFN];
     zero_acc(acc2);
     const T* w2_w = w2 + (long)(wave * NFN) * ns2;     // FF2: this wave's output columns, K walked per chunk
-    float rm[MF];
     for (int ch = 0; ch < NCH; ++ch) {
         // (lab stamps) HK: five per chunk from 6 on; otherwise the round-3 numbering
         const int sb = HK ? 6 + ch * 5 : 0;
@@ -819,6 +799,41 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             stage_run_w<T, MF, PW, PF, NS, PW, WP>(ring, a1 + l16 * P1 + g * 16, P1, NK1, w1_pass(q), ns1, NK1, (long)CF * C, wn, more ? ns1 : ns2,
                                                    more ? NK1 : NK2, more ? PW : NFN, acc, PL1);
             TSTAMP(HK ? sb : 6 + ch * 12 + h * 2);
+            if constexpr (HK) {
+                // 64-row split tile: the epilogue in the MFMA's own layout (lane = column l16 of a fragment, four rows 4g .. 4g + 3) - no
+                // patch round trip, every element independent of the others.  Lanes l16 / l16 ^ 1 swap two values (DPP) so that each
+                // stores two rows of two adjacent columns as one dword per plane.  The same values as the row-layout form below.
+                const bool odd = lane & 1;
+                const int cb = (wave * PPC + h) * PC;      // this wave's PC columns inside the chunk
+                float bj[PW];
+#pragma unroll
+                for (int j = 0; j < PW; ++j) bj[j] = prm[PRM_B1 + ch * CH + cb + j * 16 + l16];
+                char* dst = buf0 + (4 * g + (odd ? 2 : 0)) * P0 + (cb + (l16 & ~1)) * (int)sizeof(T);
+#pragma unroll
+                for (int r = 0; r < MF; ++r)
+#pragma unroll
+                    for (int j = 0; j < PW; ++j) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2_t gl = gelu_fast2(f32x2_t{acc[r][j][e] + bj[j], acc[r][j][e + 1] + bj[j]});
+                            v[e] = gl.x; v[e + 1] = gl.y;
+                        }
+                        const float y0 = dpp_f32<0xB1>(odd ? v[0] : v[2]), y1 = dpp_f32<0xB1>(odd ? v[1] : v[3]);
+                        // even lane: rows 0, 1 = (own column, partner's); odd lane: rows 2, 3 = (partner's column, own)
+                        const float a0 = odd ? y0 : v[0], c0 = odd ? v[2] : y0, a1v = odd ? y1 : v[1], c1 = odd ? v[3] : y1;
+                        const unsigned h0 = pack_bf16x2(a0, c0), h1 = pack_bf16x2(a1v, c1);
+                        const unsigned l0 = pack_bf16x2(a0 - __uint_as_float(h0 << 16), c0 - __uint_as_float(h0 & 0xffff0000u));
+                        const unsigned l1 = pack_bf16x2(a1v - __uint_as_float(h1 << 16), c1 - __uint_as_float(h1 & 0xffff0000u));
+                        char* q2 = dst + r * 16 * P0 + j * 16 * (int)sizeof(T);
+                        *reinterpret_cast<unsigned*>(q2) = h0;
+                        *reinterpret_cast<unsigned*>(q2 + P0) = h1;
+                        *reinterpret_cast<unsigned*>(q2 + PL0) = l0;
+                        *reinterpret_cast<unsigned*>(q2 + PL0 + P0) = l1;
+                    }
+                TSTAMP(sb + 1);
+                continue;
+            }
             float b1[4 * PW];
             loadn<4 * PW>(prm + PRM_B1 + ch * CH + hc, b1);
 #pragma unroll
@@ -842,13 +857,13 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         }
         __syncthreads();                               // the chunk is complete
         TSTAMP(HK ? sb + 2 : 14 + ch * 12);
-        if (ch == NCH - 1) {                           // global operands of the closing epilogue
-            const float* rmk = p.rowmask ? p.rowmask + (long)b * p.rm_bs : nullptr;
+        if constexpr (PARK) {
+            if (ch == NCH - 1) {                       // the parked residual rows (written by this lane, several barriers ago): a global
+                // load in front of this stage costs it one memory round trip (vmcnt counts in issue order: the ring's
+                // next refill waits behind it, 1.5 us at 64 rows) - the 64-row split tile keeps the rows in registers instead
 #pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const int t = t0 + i * 16 + rl;
-                rm[i] = (rmk && t < Tn) ? rmk[t] : 1.f;
-                if constexpr (PARK) {                  // the parked residual rows (written by this lane, a barrier ago)
+                for (int i = 0; i < MF; ++i) {
+                    const int t = t0 + i * 16 + rl;
                     loadn<CW>(p.x + (long)b * p.x_bs + (long)(t < Tn ? t : Tn - 1) * C + col0, x1[i]);
                 }
             }

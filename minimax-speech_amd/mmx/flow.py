@@ -664,8 +664,8 @@ class FlowEngine:
     # same weights it takes up to 45 % longer (256 workgroups: 34 / 42 / 65 us)
     _WG_US = {16: 27.1, 32: 29.9, 64: 44.1}
     # the same for the split build (two MFMAs per weight fragment; 64 rows: the K-halved tile of est_tail_tile, 8 waves):
-    # profiles/r04_tail_lab64_x.txt - 1 000 rows: 29.1 / 35.8 / 61.2; 256 workgroups: - / 53.5 / 91.5
-    _WG_US_X = {16: 29.1, 32: 35.8, 64: 61.2}
+    # profiles/r04_tail_lab64_x.txt - 1 000 rows: 29.1 / 35.8 / 60.3; 256 workgroups: - / 53.5 / 89.8
+    _WG_US_X = {16: 29.1, 32: 35.8, 64: 60.3}
     # ... and with weight planes (an fp32-kind checkpoint: three MFMAs per fragment pair, twice the stream): profiles/r04_tail_lab64_xw.txt
     _WG_US_XW = {16: 46.9, 32: 52.6, 64: 81.2}
 
