@@ -644,7 +644,6 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     // two orders below the 2^-17 its products keep; erff was 3.96 us of every FF1 epilogue, 15 % of the kernel:
     // profiles/r04_tail_stamps_x.txt); the bf16 build the degree-17 polynomial
     constexpr bool PRECISE = sizeof(T) == 4;
-    constexpr bool PARK = PW == 2 && !(NS == 2 && BM == 64 && !WP);   // (64-row split tile without weight planes: 218 registers leave room for the residual rows)
     typedef std::conditional_t<NS == 1, T, float> TI;   // activation type in HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* buf0 = smem;                                 // [NS][BM][512] attention output, then the FF intermediate chunk
@@ -756,9 +755,10 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
             rows_of<NFN, HK>(acc[i], patch, lane, v);
 #pragma unroll
             for (int c = 0; c < CW; ++c) x1[i][c] += v[c] + bo[c];
-            // PARK: the residual rows wait in HBM (x, in place) for the closing epilogue instead of in 8 * MF registers
-            // through both FF stages - the narrow-pass 8-wave kernels have 256 registers per wave
-            if (PARK && t0 + i * 16 + rl < Tn) storen<CW>(p.x + (long)b * p.x_bs + (long)(t0 + i * 16 + rl) * C + col0, x1[i]);
+            // (the residual rows stay in registers through both FF stages.  Rounds 3 - 4 parked them in HBM in the narrow-pass 8-wave
+            // kernels; reloading them in front of the last FF2 stage cost that stage a memory round trip - vmcnt counts in issue
+            // order, the weight ring's next refill waits behind the reload: 3.7 instead of 2.2 us at 64 rows - and without the parking
+            // code the same kernels need FEWER registers: 222 / 204 instead of 232 / 218)
         }
         TSTAMP(4);
     }
@@ -766,11 +766,7 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
     float n3g[CW], n3b[CW];
     loadn<CW>(prm + PRM_N3G + col0, n3g);
     loadn<CW>(prm + PRM_N3B + col0, n3b);
-    if constexpr (PARK) {
-        layernorm_rows<MF, CW, NW>(x1, stats, n3g, n3b, p.eps, wave, lane);
-#pragma unroll
-        for (int i = 0; i < MF; ++i) store_tile<T, NS, CW>(a1 + (i * 16 + rl) * P1 + col0 * (int)sizeof(T), PL1, x1[i]);
-    } else {
+    {
         float hn[MF][CW];
 #pragma unroll
         for (int i = 0; i < MF; ++i)
@@ -857,17 +853,6 @@ __device__ __forceinline__ void est_tail_tile(const MmxEstTailParams& p, const i
         }
         __syncthreads();                               // the chunk is complete
         TSTAMP(HK ? sb + 2 : 14 + ch * 12);
-        if constexpr (PARK) {
-            if (ch == NCH - 1) {                       // the parked residual rows (written by this lane, several barriers ago): a global
-                // load in front of this stage costs it one memory round trip (vmcnt counts in issue order: the ring's
-                // next refill waits behind it, 1.5 us at 64 rows) - the 64-row split tile keeps the rows in registers instead
-#pragma unroll
-                for (int i = 0; i < MF; ++i) {
-                    const int t = t0 + i * 16 + rl;
-                    loadn<CW>(p.x + (long)b * p.x_bs + (long)(t < Tn ? t : Tn - 1) * C + col0, x1[i]);
-                }
-            }
-        }
         const T* wn = ch + 1 < NCH ? w1_pass((ch + 1) * PPC) : (p.next.wqkv ? qkv_pass<T, NW, PW>(p.next.wqkv, wave, lane, 0) : nullptr);
         if constexpr (WP && !HK) {
             // weight planes: hi and lo pack alternate per 256 columns of the intermediate (two halves of this 512-wide chunk) - the

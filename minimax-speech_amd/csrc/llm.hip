@@ -581,11 +581,8 @@ struct Raw8 {
 // workgroups, each reading its K / V rows ONCE for two heads - at batch 32 and 7 heads per kv head 256 workgroups (one round of
 // the 256 CUs) instead of 448, and 4/7 of the L2 -> CU traffic that bounds this kernel (the cached rows are 205 KB per workgroup
 // at 400 fp32 keys: 2.9 us at the ~70 GB/s a CU draws from L2; every head's arithmetic is what it was, in the same order).
-// NG: key groups = 8-thread teams of the workgroup (NG * 8 threads).  The two-head form runs 64 teams on 8 waves: the key loop is
-// vector work (8 + 17 FMAs, two exp2 and a 3-step DPP sum per key and head), and a wave alone on its SIMD issues vector
-// instructions at half the SIMD's rate (est_tail's alternating-set experiment) - two waves per SIMD, each with half the keys.
-template <typename T, int OM, int HP, int NG = 32>
-__global__ __launch_bounds__(NG * 8) void decode_attn_kernel(
+template <typename T, int OM, int HP>
+__global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ qkv, long ldqkv, int Hq, int Hkv, const float* __restrict__ inv_freq,
     const float* __restrict__ rope_tab, const int32_t* __restrict__ pos, T* __restrict__ kc, T* __restrict__ vc,
     const int32_t* __restrict__ block_table, int max_pages, int page, float scale, T* __restrict__ out, long ldo,
@@ -595,7 +592,7 @@ __global__ __launch_bounds__(NG * 8) void decode_attn_kernel(
     // threads of a key reduce q.k with 3 xor-shuffles, every key group keeps its own running (max, sum, acc[8]) per head;
     // the 32 groups are merged once through LDS.  Two workgroup barriers in total; the block-table row is staged
     // in LDS up front so no load depends on another load except through `pos`.
-    constexpr int D = 64, HALF = 32, NT = NG * 8;
+    constexpr int D = 64, HALF = 32, NG = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = reinterpret_cast<float*>(smem);        // [HP][D] rope(q) * scale * log2(e)
     float* kn = qs + HP * D;                           // [D] new key (rounded through T)
@@ -616,7 +613,7 @@ __global__ __launch_bounds__(NG * 8) void decode_attn_kernel(
     const int b = kvg / Hkv, hk = kvg % Hkv, sub = slot % nsub;
     const int h0 = hk * group + sub * HP, nh = min(HP, group - sub * HP);   // this workgroup's heads h0 .. h0 + nh - 1
     const int32_t* bt = block_table + (long)b * max_pages;
-    for (int i = tid; i < max_pages; i += NT) bts[i] = bt[i];
+    for (int i = tid; i < max_pages; i += 256) bts[i] = bt[i];
     const int p = pos[b];
     const float* src = qkv + (long)b * ldqkv;
     const float sc2 = scale * 1.44269504088896341f;
@@ -677,7 +674,7 @@ __global__ __launch_bounds__(NG * 8) void decode_attn_kernel(
     };
     // cached keys: U keys per thread in flight at a time (the loop is a chain of memory round trips otherwise:
     // 37 us at 1500 keys with 4 in flight); one pass covers 32*U keys
-    constexpr int U = NG > 32 ? (sizeof(T) == 2 ? 6 : 4) : (sizeof(T) == 2 ? 12 : 10);   // (fp32 cache, 32 teams: 10 x 64 B per thread in flight, 320 keys per pass; 64 teams: 4, 256 keys per pass - 8 waves keep as many bytes in flight per CU, inside 128 registers: two such waves fit a SIMD beside two flash-attention waves)
+    constexpr int U = sizeof(T) == 2 ? 12 : 10;       // (fp32 cache: 10 x 64 B per thread in flight, 320 keys per pass)
     for (int j0 = kg; j0 < p; j0 += NG * U) {
         Raw8<T> rk[U], rv[U];
 #pragma unroll
@@ -712,42 +709,20 @@ __global__ __launch_bounds__(NG * 8) void decode_attn_kernel(
         for (int e = 0; e < 8; ++e) part[(hp * NG + kg) * D + dc * 8 + e] = acc[hp][e];
     }
     __syncthreads();
-    // merge of the NG teams.  32 teams: one thread per (head, channel) walks them in order.  64 teams (HP = 2, 512 threads): four
-    // threads per (head, channel), 16 teams each in order, their partial sums added as (q0 + q1) + (q2 + q3) through DPP - a fixed
-    // order again, and a chain a quarter as long
-    constexpr bool M4 = NG == 64;
-    static_assert(!M4 || HP == 2, "four merge threads per (head, channel): 512 = 2 x 64 x 4");
-    if (M4 || tid < nh * D) {
-        const int hp = M4 ? tid >> 8 : tid >> 6, d = M4 ? (tid >> 2) & 63 : tid & 63, h = h0 + hp;
+    if (tid < nh * D) {
+        const int hp = tid >> 6, d = tid & 63, h = h0 + hp;
         const float* gmh = gm + hp * NG;
         const float* glh = gl + hp * NG;
         const float* ph = part + hp * NG * D;
-        float M = -INFINITY, L = 0.f, o = 0.f;
-        if constexpr (M4) {
-            const int q = tid & 3;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) M = fmaxf(M, gmh[q * 16 + k]);
-            M = fmaxf(M, dpp_f32<0xB1>(M));
-            M = fmaxf(M, dpp_f32<0x4E>(M));
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int g2 = q * 16 + k;
-                const float w = __builtin_amdgcn_exp2f(gmh[g2] - M);
-                L = __builtin_fmaf(glh[g2], w, L);
-                o = __builtin_fmaf(ph[g2 * D + d], w, o);
-            }
-            L += dpp_f32<0xB1>(L); L += dpp_f32<0x4E>(L);
-            o += dpp_f32<0xB1>(o); o += dpp_f32<0x4E>(o);
-            if (q != 0 || hp >= nh) return;
-        } else {
+        float M = -INFINITY;
 #pragma unroll
         for (int g2 = 0; g2 < NG; ++g2) M = fmaxf(M, gmh[g2]);
+        float L = 0.f, o = 0.f;
 #pragma unroll
         for (int g2 = 0; g2 < NG; ++g2) {
             const float w = __builtin_amdgcn_exp2f(gmh[g2] - M);     // empty groups: exp2(-inf) = 0
             L = __builtin_fmaf(glh[g2], w, L);
             o = __builtin_fmaf(ph[g2 * D + d], w, o);
-        }
         }
         if constexpr (OM == 2) {
             const int nkb = Hq * D / 32, col = h * D + d;
@@ -1016,12 +991,11 @@ extern "C" int mmx_decode_attn(const float* qkv, int64_t ldqkv, int B, int Hq, i
     const size_t max_ctx = (size_t)max_pages * page;
     (void)max_ctx;
     const int hp = one_head ? 1 : 2, nsub = (Hq / Hkv + hp - 1) / hp;
-    const int ng = one_head ? 32 : 64;                 // key teams per workgroup (256 / 512 threads)
-    size_t lds = ((size_t)hp * 64 + 2 * 64 + 2 * hp * ng + (size_t)hp * ng * 64 + (size_t)max_pages) * 4;
+    size_t lds = ((size_t)hp * 64 + 2 * 64 + 2 * hp * 32 + (size_t)hp * 32 * 64 + (size_t)max_pages) * 4;
     MMX_CHECK_ARG(lds <= 64 * 1024);
     dim3 grid(8 * ((Hkv * B + 7) / 8) * nsub);
 #define DA(T, OM) do { if (one_head) hipLaunchKernelGGL((decode_attn_kernel<T, OM, 1>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B); \
-                       else hipLaunchKernelGGL((decode_attn_kernel<T, OM, 2, 64>), grid, dim3(512), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B); } while (0)
+                       else hipLaunchKernelGGL((decode_attn_kernel<T, OM, 2>), grid, dim3(256), lds, stream, qkv, ldqkv, Hq, Hkv, inv_freq, rope_tab, pos, (T*)kc, (T*)vc, block_table, max_pages, page, scale, (T*)out, ldo, B); } while (0)
     if (dtype == MMX_BF16 && page == 16 && Hq == 7 * Hkv && gqa_shared) {
         const size_t lds2 = (2 * 16 * 64 + 2 * 64) * 2 + (4 * 8 * 16 * 8 + 3 * 32 + 32 * 7 * 64 + (size_t)max_pages) * 4;
         MMX_CHECK_ARG(lds2 <= 160 * 1024);

@@ -384,7 +384,7 @@ def test_config4_rank_share_full_size_split_vs_oracle(case):
     """BASELINE config 4, one rank's share at FULL size on the split build — the shape `bench.py` times: 32 utterances, lengths
     U{50..500} tokens (seed 3), 24-layer LM, the overlapped schedule (decode loop with two 16-row MFMA tiles and the ticketed
     split-K down projection, compaction into the 16-slot engine, ragged zero-padded flow groups with the batched encoder,
-    64-row est_tail tiles beside the decode loop, 8-wave two-head decode attention).  The two shortest and the longest utterance against the CPU oracle's
+    64-row est_tail tiles beside the decode loop).  The two shortest and the longest utterance against the CPU oracle's
     composed path: ids identical, waveform within 1e-3 (the north star; sequence id = position in the batch keys the Philox
     stream on both sides).  The back-to-back schedule must give the same ids for all 32."""
     from mmx.pipeline import TtsEngine
