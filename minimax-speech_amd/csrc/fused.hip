@@ -1340,7 +1340,9 @@ extern "C" int mmx_est_tail(const MmxEstTailParams* pp, int dtype, int bm, int c
         // (a ring 4 k-steps deep measured no faster: 35.7 / 38.5 / 54.6 us at 32 / 128 / 256 workgroups against 37.4 / 40.4 / 55.2 -
         // the stages are bound by the CU's L2 read rate, not by the latency of the loads in flight: profiles/r04_tail_lab_x.txt)
         if (bm == 32) { if (nw == 4) TAILN(bf16_t, 32, 4, 4, 2); else TAILN(bf16_t, 32, 2, 8, 2); }
-        else if (bm == 16) { if (nw == 8) TAILN(bf16_t, 16, 4, 8, 2); else TAILN(bf16_t, 16, 8, 4, 2); }
+        // (16 rows: 8 waves by default like the taller tiles - every split tile then sums its LayerNorms alike and an utterance's bits do
+        // not depend on the tile height its flow group was given; 4 waves with an explicit cfg)
+        else if (bm == 16) { if (nw == 4) TAILN(bf16_t, 16, 8, 4, 2); else TAILN(bf16_t, 16, 4, 8, 2); }
         else return MMX_EARG;
     } else if (dtype == MMX_BF16) {
         if (bm == 64) {                                // (reached with an explicit cfg only: the round-2 / round-3 forms, tools/tail_lab.py)
@@ -1407,7 +1409,12 @@ extern "C" int mmx_est_resnet(const MmxEstResnetParams* pp, int dtype, int bm, i
             else if (nw != 4 && (resnet_lds<bf16_t, 32, 8, 2>(p.cin)) <= 160 * 1024) { if (pfx >= 4) RESNN(bf16_t, 32, 4, 8, 2); else RESNN(bf16_t, 32, 2, 8, 2); }
             else if (pfx >= 4) RESNN(bf16_t, 32, 4, 4, 2); else RESNN(bf16_t, 32, 2, 4, 2);
         } else if (bm == 16) {
-            if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2, true); else RESNN(bf16_t, 16, 2, 4, 2, true); }
+            // (8 waves under the same condition as the 32-row tile: both tile heights then sum every LayerNorm alike - bit-identical)
+            if (nw != 4 && (resnet_lds<bf16_t, 32, 8, 2>(p.cin)) <= 160 * 1024) {
+                if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 16, 4, 8, 2, true); else RESNN(bf16_t, 16, 2, 8, 2, true); }
+                else if (pfx >= 4) RESNN(bf16_t, 16, 4, 8, 2); else RESNN(bf16_t, 16, 2, 8, 2);
+            }
+            else if (wplanes) { if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2, true); else RESNN(bf16_t, 16, 2, 4, 2, true); }
             else if (pfx >= 4) RESNN(bf16_t, 16, 4, 4, 2); else RESNN(bf16_t, 16, 2, 4, 2);
         } else return MMX_EARG;
         MMX_LAUNCH_CHECK();

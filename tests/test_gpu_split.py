@@ -350,6 +350,46 @@ def test_est_tail_64_row_split_tile_equals_32_row_tile(B, T, masked, with_next):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("wp", [False, True])
+def test_split_tiles_of_every_height_agree_bit_for_bit(wp):
+    """Which tile height a fused estimator kernel runs with depends on the size of the flow group an utterance lands in; the split
+    build's result must not.  est_tail on 16- / 32- / 64-row tiles (all 8 waves) and est_resnet (cin = 256) on 16- / 32-row tiles
+    (both 8 waves): identical bits, with and without weight planes."""
+    from mmx import ops, shapes, synth
+    from mmx.flow import FlowEngine
+    fl = FlowEngine(synth.synth_state_dict(shapes.flow_manifest(num_mid_blocks=1), 0, kind=("fp32" if wp else "bf16")), dtype=X2, use_graphs=False,
+                    wplanes=wp)
+    blocks = [w for st in fl.mid for w in st["blocks"]]
+    res = [st["res"] for st in fl.mid]
+    g = torch.Generator().manual_seed(31)
+    B, T = 2, 173
+    Tp = ops.round_up(T, 8)
+    ao = torch.randn(B, T, 512, generator=g).cuda()
+    a_in = torch.randn(B, T, 256, generator=g).cuda()
+    x0 = torch.randn(B, T, 256, generator=g).cuda()
+    tv = torch.randn(B, 14 * 256, generator=g).cuda()
+    mask = (torch.rand(B, T, generator=g) > 0.3).float().cuda()
+    w, wn = blocks[0], blocks[1]
+
+    def run(fn):
+        x = x0.clone()
+        qk = torch.zeros(B, T, 2048, dtype=torch.bfloat16, device="cuda")
+        vt = torch.zeros(B, 2, 512, Tp, dtype=torch.bfloat16, device="cuda")
+        nxt = ops.est_next(wqkv=wn["wqkv_p"], n1g=wn["n1g"], n1b=wn["n1b"], q_out=qk, ldq=2048, q_bs=T * 2048, vt_out=vt, ldvt=Tp, vt_bs=2 * 512 * Tp)
+        fn(x, nxt)
+        torch.cuda.synchronize()
+        assert torch.isfinite(x).all() and float(x.abs().max()) > 0
+        return x, qk, vt
+
+    tails = [run(lambda x, nxt, bm=bm: ops.est_tail(ao, x, w, B=B, T=T, dtype=X2, bm=bm, nxt=nxt, rowmask=mask)) for bm in (16, 32, 64)]
+    resn = [run(lambda x, nxt, bm=bm: ops.est_resnet(a_in, 256, 256, x, res[0], tv, 14 * 256, B=B, T=T, dtype=X2, bm=bm, rowmask=mask, nxt=nxt))
+            for bm in (16, 32)]
+    for outs in (tails, resn):
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert torch.equal(a, b)
+
+
 def test_est_tail_64_row_split_tile_equals_32_row_tile_with_weight_planes():
     """The same with weight planes (an fp32-kind checkpoint: every packed weight as hi + lo bf16 packs, MMX_X2W): the 64-row tile and
     the 32-row tile meet hi and lo packs in the same order (per 256 columns of the FF intermediate) and agree bit for bit."""

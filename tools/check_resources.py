@@ -19,7 +19,7 @@ GATED = [
     "est_tail_kernel<unsigned short, 16, 8, 4, 1, 1, 4, false>",      # bf16 build, 16-row tiles
     "est_tail_kernel<unsigned short, 64, 2, 8, 2, 1, 2, false>",         # split build, 64-row tiles (K-halved attention tile)
     "est_tail_kernel<unsigned short, 32, 2, 8, 2, 1, 4, false>",         # split build
-    "est_tail_kernel<unsigned short, 16, 8, 4, 2, 1, 4, false>",      # split build, 16-row tiles
+    "est_tail_kernel<unsigned short, 16, 4, 8, 2, 1, 4, false>",      # split build, 16-row tiles (8 waves)
     "est_tail_kernel<unsigned short, 64, 2, 8, 2, 1, 2, true>", "est_tail_kernel<unsigned short, 32, 2, 8, 2, 1, 4, true>",       # split build, weight planes
     "est_tail_kernel<unsigned short, 16, 4, 8, 2, 1, 4, true>",
     "est_resnet_kernel<unsigned short, 64, 2, 8, 1, false>", "est_resnet_kernel<unsigned short, 32, 4, 8, 1, false>",

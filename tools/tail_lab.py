@@ -47,9 +47,9 @@ def run(n, T, bm, waves, pf):
 
 def sweep():
     # waves 2xx: 8 waves with 32-column passes
-    cfgs = ([(32, 8, 0), (64, 208, 2), (16, 8, 0)] if mode == "xw" else [(32, 8, 0), (64, 208, 2), (64, 208, 4), (16, 8, 0)] if split else
+    cfgs = ([(32, 8, 0), (64, 208, 2), (16, 8, 0)] if mode == "xw" else [(32, 8, 0), (64, 208, 2), (64, 208, 4), (16, 8, 0), (16, 4, 0)] if split else
             [(64, 4, 2), (64, 208, 2), (32, 208, 8), (16, 8, 4)])
-    for n, T in [(1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
+    for n, T in [(1, 150), (1, 500), (2, 1000), (4, 1000), (5, 1000), (6, 1000), (8, 896), (8, 1000), (12, 1000), (16, 1000)]:
         rows = 2 * n * T
         line = []
         for bm, waves, pf in cfgs:
