@@ -226,3 +226,27 @@ def test_integration_doc_names_every_entry_point():
     assert [s for s in _lib.SYMBOLS if f"`{s}`" not in doc] == []
     assert [s for s in _lib.SYMBOLS if not re.search(r"\b" + s + r"\(", hdr)] == []
     assert f"mmx_abi_version() == {_lib.ABI_VERSION}" in doc
+
+
+def test_flow_tile_rule_of_the_split_build():
+    """FlowEngine._tile_rows (host logic, no GPU): the split build's fused tail kernel runs on the tile height with the shortest
+    modelled launch (profiles/r04_tail_lab64_x.txt: 16 rows for one utterance, 32 rows up to one round of 256 workgroups, 64 rows where
+    32-row tiles would need a second round) and on 64 rows beside the decode loop; the ResNet kernel never on more than 32 rows.  The
+    choice never changes results (tests/test_gpu_split.py::test_split_tiles_of_every_height_agree_bit_for_bit)."""
+    from mmx.flow import FlowEngine
+    fl = object.__new__(FlowEngine)
+    fl.dtype, fl.split, fl.wplanes, fl.polite = 2, True, False, False
+    assert fl._tile_rows(2, 500) == (16, 16)              # one 10 s utterance with its CFG pair: 64 workgroups of 16 rows
+    assert fl._tile_rows(8, 1000)[0] == 32                # 8 000 rows: 250 workgroups of 32 rows, one round
+    assert fl._tile_rows(10, 1000) == (64, 32)            # 10 000 rows: 313 32-row tiles would take a second round
+    assert fl._tile_rows(16, 896) == (64, 32)             # the step's largest group
+    fl.polite = True                                      # beside the decode loop: 64 rows whatever the size
+    assert fl._tile_rows(4, 700) == (64, 32)
+    fl.max_tile_rows = 32                                 # bench.py --flow-bm 32
+    assert fl._tile_rows(4, 700) == (32, 32)
+    del fl.max_tile_rows
+    fl.polite, fl.wplanes = False, True                   # weight planes: their own launch model, the same shape of rule
+    assert fl._tile_rows(2, 500)[0] == 16 and fl._tile_rows(16, 896)[0] == 64
+    # the model itself: full rounds of 256 workgroups, then the remainder; a fuller chip streams the shared weights slower
+    assert FlowEngine._launch_us(64, 256, True) > FlowEngine._launch_us(64, 16, True) > FlowEngine._launch_us(32, 16, True)
+    assert abs(FlowEngine._launch_us(32, 512, True) - 2 * FlowEngine._launch_us(32, 256, True)) < 1e-9
