@@ -26,14 +26,6 @@ if [ "$3" = "groups" ]; then
   run hold70 --hold-steps 70
   exit 0
 fi
-if [ "$3" = "tpwmin" ]; then
-  run min0
-  exit 0
-fi
-if [ "$3" = "tpw" ]; then
-  run base
-  exit 0
-fi
 if [ "$3" = "prio" ]; then
   run base
   run prio1 --flow-priority 1
